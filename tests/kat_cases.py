@@ -1,0 +1,105 @@
+"""Inputs of the reference's recorded known-answer tests.
+
+Everything here is DATA restated from the reference scripts (constants, protocol shapes, output
+grids) with file:line citations; the expected values live in tests/golden/kat_losses.json.
+Each KAT = mean |i_model - i_truth| of two solves on the same protocol (train-s1.py:319-330).
+"""
+import json
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+MODEL_HH2, MODEL_MARKOV6, MODEL_NNF, MODEL_NND = 0, 1, 2, 3
+
+# train-s1.py:139-146 (HH ground truth of s1/s2; NN-f uses p5-p8 :211-214; NN-d s2 all eight, train-s2.py:210-217)
+P_HH = np.array([1.12592345582957387e-01, 8.26751134920666146e+01, 3.38768033864048357e-02,
+                 4.67106147665183542e+01, 8.47769667061995875e+01, 2.04001345352499328e+01,
+                 1.02860743916105211e+01, 2.78201179336874098e+01]) * 1e-3
+# train-d1.py:139-150 (6-state ground truth of d1/d2)
+P_M6 = np.array([5.94625498751561316e-02, 1.21417701632850410e+02, 4.76436985414236425e+00,
+                 3.49383233960778904e-03, 9.62243079990877703e+01, 2.26404683824047979e+01,
+                 8.00924780462999131e+00, 2.43749808069009823e+01, 2.06822607368134157e+02,
+                 3.30791433507312362e+01, 1.26069071928587784e+00, 2.24844970727316245e+01]) * 1e-3
+# NN RHS of d1 (train-d1.py:220-223) and d2 (train-d2.py:221-232): p1-p4 from the HH fit, p5-p8 from the 6-state fit
+P_NN_D = np.concatenate([P_HH[:4], P_M6[4:8]])
+
+MODELS = {
+    # name: (truth model, truth params, truth y0, nn model, nn params)
+    "s1": (MODEL_HH2, P_HH, [0.0, 1.0], MODEL_NNF, P_HH),
+    "s2": (MODEL_HH2, P_HH, [0.0, 1.0], MODEL_NND, P_HH),
+    "d1": (MODEL_MARKOV6, P_M6, [0.0, 1.0, 0.0, 0.0, 0.0, 0.0], MODEL_NNF, P_NN_D),
+    "d2": (MODEL_MARKOV6, P_M6, [0.0, 1.0, 0.0, 0.0, 0.0, 0.0], MODEL_NND, P_NN_D),
+}
+NN_Y0 = [0.0, 1.0]  # true_y0s[1], train-s1.py:116
+MLP_L, MLP_N = 5, 200  # architectures/s00.py
+
+
+def f32_linspace(a, b, n):
+    """torch.linspace(a, b, n) in float32 as torch computes it (symmetric halves), widened to fp64."""
+    import torch
+    return torch.linspace(float(a), float(b), n).double().numpy()
+
+
+def load_weights(name):
+    return np.fromfile(os.path.join(GOLDEN, f"weights_{name}.f32"), dtype="<f4")
+
+
+def load_kats():
+    with open(os.path.join(GOLDEN, "kat_losses.json")) as f:
+        return json.load(f)
+
+
+def ap2hz():
+    """test-protocols/ap2hz.csv with time in ms (train-s1.py:44-45); output grid :65."""
+    p = np.fromfile(os.path.join(GOLDEN, "ap2hz.f64"), dtype="<f8").reshape(-1, 2)
+    return p[:, 0].copy(), p[:, 1].copy(), f32_linspace(0, 3000, 1501)
+
+
+def activation(v_i):
+    """Pr3, train-s1.py:431-444 (1 ms grid, 8001 points)."""
+    t = f32_linspace(0, 8000, 8001)
+    v = np.zeros(8001)
+    v[:1000] = -80
+    v[1000:6000] = v_i
+    v[6000:7000] = -40
+    v[7000:7500] = -120
+    v[7500:] = -80
+    return t.copy(), v, t
+
+
+def deactivation(v_i):
+    """Pr5, train-s1.py:471-484 (10001 points)."""
+    t = f32_linspace(0, 10000, 10001)
+    v = np.zeros(10001)
+    v[:1000] = -80
+    v[1000:3000] = 50
+    v[3000:9000] = v_i
+    v[9000:9500] = -120
+    v[9500:] = -80
+    return t.copy(), v, t
+
+
+def atau(t_i):
+    """Pr2, train-s1.py:511-521 (5001 points)."""
+    t = f32_linspace(0, 5000, 5001)
+    v = np.zeros(5001)
+    v[:1000] = -80
+    v[1000:1000 + t_i] = 40
+    v[1000 + t_i:3500 + t_i] = -120
+    v[3500 + t_i:] = -80
+    return t.copy(), v, t
+
+
+def all_cases():
+    """[(section, key, (prot_t, prot_v, t_eval))] for the 23 reproducible KATs per model."""
+    cases = [("AP 2Hz", None, ap2hz())]
+    cases += [("act", f"{float(v):.1f}", activation(v)) for v in (-60, -40, -20, 0, 20, 40, 60)]
+    cases += [("deact", f"{float(v):.1f}", deactivation(v)) for v in (-120, -110, -100, -90, -80, -70, -60, -50, -40)]
+    cases += [("atau", f"{float(t):.1f}", atau(t)) for t in (3, 10, 30, 100, 300, 1000)]
+    return cases
+
+
+def expected(kats, model, section, key):
+    return kats[model][section] if key is None else kats[model][section][key]

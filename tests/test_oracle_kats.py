@@ -1,0 +1,125 @@
+"""Pin the CPU oracle against the reference's own recorded results.
+
+torchdiffeq (the integrator the reference calls) is absent from the reference tree and from this
+container, so these artefacts are what pins parity at the odeint boundary:
+  * 92 '--pred' losses recorded in {s1,s2,d1,d2}/log2, each = mean|i_model - i_truth| over two
+    dopri5 solves in fp32 state (NN RHS + ground-truth RHS) -> tests/golden/kat_losses.json
+  * the 80 001-sample HH current trace cached in figure-0-s/i_n.pt (seeded noise removed)
+
+Tolerances: the reference's solves run with rtol = 1e-7 ~ fp32 epsilon, so its accept/reject
+sequence is rounding-noise driven and not reproducible across BLAS builds; an independent fp32
+restatement lands within ~1e-5 of the 6-decimal logged values (SURVEY.md finding 4).  We assert
+|loss - logged| <= 5e-5 for every KAT and a median <= 5e-6.
+"""
+import numpy as np
+import pytest
+
+import kat_cases as K
+
+ABS_TOL = 5e-5
+MEDIAN_TOL = 5e-6
+
+
+def test_tableau_identities(oracle):
+    se, ss, sm, mb = oracle.selfcheck()
+    assert abs(se) < 1e-16 and abs(ss - 1) < 1e-15 and abs(sm - 0.5) < 1e-15 and mb < 1e-15
+
+
+def _kat_loss(oracle, m, case, state_f32=True):
+    tm, tp, ty0, nm, npar = K.MODELS[m]
+    pt, pv, te = case
+    w = K.load_weights(m)
+    tr = oracle.solve(tm, tp, pv, ty0, te, prot_t=pt, state_f32=state_f32)
+    nn = oracle.solve(nm, npar, pv, K.NN_Y0, te, prot_t=pt, weights=w, mlp_layers=K.MLP_L,
+                      mlp_width=K.MLP_N, state_f32=state_f32)
+    assert tr["status"][0] == 0 and nn["status"][0] == 0
+    v, inr = oracle.protocol_v(pv, te, prot_t=pt)
+    assert inr.all()
+    i_t = oracle.current(tr["y"][0], v, open_state_only=(tm == K.MODEL_MARKOV6), state_f32=state_f32)
+    i_m = oracle.current(nn["y"][0], v, state_f32=state_f32)
+    return float(np.mean(np.abs(i_m - i_t)))
+
+
+@pytest.mark.parametrize("m", ["s1", "s2", "d1", "d2"])
+def test_logged_prediction_losses(oracle, m):
+    kats = K.load_kats()
+    diffs = []
+    for sec, key, case in K.all_cases():
+        got = _kat_loss(oracle, m, case)
+        exp = K.expected(kats, m, sec, key)
+        diffs.append(abs(got - exp))
+        assert abs(got - exp) <= ABS_TOL, f"{m} {sec} {key}: {got:.6f} vs logged {exp:.6f}"
+    assert len(diffs) == 23
+    assert np.median(diffs) <= MEDIAN_TOL
+
+
+def test_fp64_state_agrees_with_logged_losses(oracle):
+    """fp64 state (BASELINE configs 2-3) is the tighter solve of the same problem: same KATs, same tolerance."""
+    kats = K.load_kats()
+    for sec, key, case in K.all_cases()[:8]:
+        got = _kat_loss(oracle, "s1", case, state_f32=False)
+        assert abs(got - K.expected(kats, "s1", sec, key)) <= ABS_TOL
+
+
+def _fig0s_protocol():
+    # figure-0-s.py:45-56 (pr3 with a +40 mV step, 0.1 ms grid), t1 = linspace(0, 8000, 80001) fp32 (:36)
+    pt = np.linspace(0.0, 8000.0, 80001)
+    v = np.zeros(80001)
+    v[:10000] = -80
+    v[10000:60000] = 40
+    v[60000:70000] = -40
+    v[70000:75000] = -120
+    v[75000:] = -80
+    return pt, v, K.f32_linspace(0, 8000, 80001)
+
+
+def test_figure0s_golden_trace(oracle):
+    gold = np.fromfile(K.GOLDEN + "/fig0s_hh_current.f64", dtype="<f8")
+    pt, v, te = _fig0s_protocol()
+    r = oracle.solve(K.MODEL_HH2, K.P_HH, v, [0.0, 1.0], te, prot_t=pt, state_f32=True)
+    vv, _ = oracle.protocol_v(v, te, prot_t=pt)
+    i = oracle.current(r["y"][0], vv, state_f32=True)[::10]
+    rel = np.linalg.norm(i - gold) / np.linalg.norm(gold)
+    assert rel <= 5e-6, rel  # <= 5e-6 rel-L2; the reference itself sits 2.6e-6 from truth
+    # away from the four voltage steps the agreement is ~1e-6 relative per segment
+    mask = np.ones(gold.size, bool)
+    for s in (1000, 6000, 7000, 7500):
+        mask[s - 2:s + 6] = False
+    assert np.abs(i - gold)[mask].max() <= 2e-4
+
+
+def test_uniform_grid_lookup_equals_explicit_times(oracle):
+    """The arithmetic index rule used by the HIP kernels reproduces interp1d's searchsorted rule."""
+    rng = np.random.default_rng(0)
+    v = rng.uniform(-120, 60, 5001)
+    pt = np.arange(5001) * 1.0
+    t = np.concatenate([rng.uniform(-5, 5005, 20000), pt, [-1e-9, 5000 + 1e-9, 0.0, 5000.0]])
+    a, ia = oracle.protocol_v(v, t, prot_t=pt)
+    b, ib = oracle.protocol_v(v, t, prot_t0=0.0, prot_dt=1.0)
+    assert (ia == ib).all() and np.array_equal(a, b)
+    assert a[~ia].tolist() == [-80.0] * int((~ia).sum())
+
+
+def test_failure_status_codes(oracle):
+    """max-steps and non-finite states end a trajectory with a status code and NaN-filled tail."""
+    pt, v, te = K.activation(20)
+    r = oracle.solve(K.MODEL_HH2, K.P_HH, v, [0.0, 1.0], te, prot_t=pt, max_steps=50)
+    assert r["status"][0] == 3 and np.isnan(r["y"][0, -1]).all() and np.isfinite(r["y"][0, 0]).all()
+    # a non-finite start makes dt NaN: torchdiffeq's first assertion ('underflow in dt') fires before
+    # the 'non-finite values in state' one, so status is 1 here; both are failures with a NaN tail
+    r = oracle.solve(K.MODEL_HH2, K.P_HH, v, [np.inf, 1.0], te, prot_t=pt)
+    assert r["status"][0] in (1, 2) and np.isnan(r["y"][0, 1:]).all()
+
+
+def test_batch_is_trajectory_independent(oracle):
+    """B trajectories in one call == B single calls (per-trajectory params and protocols)."""
+    rng = np.random.default_rng(1)
+    cases = [K.activation(v)[1] for v in (-40, 0, 40)]
+    pv = np.stack(cases)
+    te = K.activation(0)[2][:2001]
+    params = K.P_HH[None, :] * rng.uniform(0.5, 2.0, (6, 8))
+    pot = np.array([0, 1, 2, 2, 1, 0], dtype=np.int32)
+    rb = oracle.solve(K.MODEL_HH2, params, pv, [0.0, 1.0], te, prot_t0=0.0, prot_dt=1.0, prot_of_traj=pot, nthreads=3)
+    for b in range(6):
+        r1 = oracle.solve(K.MODEL_HH2, params[b], pv[pot[b]], [0.0, 1.0], te, prot_t0=0.0, prot_dt=1.0)
+        assert np.array_equal(r1["y"][0], rb["y"][b]) and np.array_equal(r1["stats"][0], rb["stats"][b])
