@@ -1,0 +1,122 @@
+/*
+ * ionode.h -- C ABI of libionode.so: the MI355X-native batched neural-ODE integrator for
+ * ion-channel gating models (adaptive Dormand-Prince RK45 + dense output, HIP, gfx950).
+ *
+ * What it replaces.  The reference (chonlei/neural-ode-ion-channels) has no FFI: its hot path is the
+ * Python call
+ *     odeint(func, y0, t)                      train-s1.py:322,327  train-d0.py:428  train-r1.py:273 ...
+ * into torchdiffeq==0.2.1 (requirements.txt:1), which calls back func.forward(t, y) six times per
+ * step (train-s1.py:231-247 NN-f, train-d2.py:257-272 NN-d, train-s1.py:161-177 HH,
+ * train-d1.py:165-187 6-state).  The entry points below are what a binding for that call binds:
+ * ONE launch integrates a whole batch of independent trajectories, with the RHS fused into the
+ * kernel.  Caller owns every buffer; the library allocates nothing and keeps no state.
+ *
+ *   reference interface                                    entry point here
+ *   -----------------------------------------------------  --------------------------------------
+ *   odeint(func, y0, t, rtol, atol, method='dopri5')       ionode_dopri5()
+ *   func.net state_dict  (net.{0,2,..}.weight/.bias)       ionode_mlp_packed_floats()/ionode_mlp_pack()
+ *   func.set_fixed_form_voltage_protocol(t, v)             prot_v / prot_t / prot_t0 / prot_dt arguments
+ *   pred_y[:,0,0]*pred_y[:,0,1]*(func._v(t)+86)            optional fused epilogue -> i_out
+ *       (train-s1.py:328, train-r1.py:274, train-d1.py:299)
+ *   AssertionError 'underflow in dt' / 'non-finite' /      per-trajectory status[] codes
+ *       'max_num_steps exceeded' (torchdiffeq)
+ *
+ * All pointers passed to ionode_dopri5 are DEVICE pointers (HBM), except the descriptor.
+ */
+#ifndef IONODE_H
+#define IONODE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IONODE_ABI_VERSION 1
+
+/* RHS families (func.forward variants of the reference) */
+#define IONODE_MODEL_HH2 0     /* 2-state Hodgkin-Huxley: Lambda, train-s1.py:134-177; candidate ODEFunc train-d0.py:321-374 */
+#define IONODE_MODEL_MARKOV6 1 /* 6-state Markov: Lambda, train-d1.py:134-187 */
+#define IONODE_MODEL_NNF 2     /* NN-f: da/dt = MLP(V/100, a)/1000, train-s1.py:181-247 */
+#define IONODE_MODEL_NND 3     /* NN-d: da/dt = HH + MLP(V/100, a)/1000, train-d2.py:191-272 */
+
+/* per-trajectory status (torchdiffeq's assertion messages) */
+#define IONODE_STATUS_OK 0
+#define IONODE_STATUS_DT_UNDERFLOW 1 /* 'underflow in dt' */
+#define IONODE_STATUS_NONFINITE 2    /* 'non-finite values in state `y`' */
+#define IONODE_STATUS_MAX_STEPS 3    /* 'max_num_steps exceeded' */
+
+/* return codes of the entry points */
+#define IONODE_OK 0
+#define IONODE_ERR_ARG (-1)      /* inconsistent descriptor / NULL where a buffer is required */
+#define IONODE_ERR_UNSUPPORTED (-2) /* shape outside what the kernels are built for */
+#define IONODE_ERR_LAUNCH (-3)   /* hipLaunchKernel failed; see ionode_last_error() */
+
+typedef struct ionode_desc {
+  int32_t model;       /* IONODE_MODEL_* */
+  int32_t state_f32;   /* 1: solver state (y, k, dense output) in fp32 = the reference scripts' y0.dtype;
+                          0: fp64 state (BASELINE configs 2-3).  Time/step control is fp64 either way. */
+  int32_t n_state;     /* D: 2 (HH2, NNF, NND) or 6 (MARKOV6) */
+  int32_t n_out;       /* len(t) */
+  int32_t n_traj;      /* B */
+  int32_t n_prot;      /* P voltage protocols of prot_n samples each */
+  int32_t prot_n;      /* samples per protocol */
+  int32_t mlp_layers;  /* L: hidden N x N Linear layers (architectures/sNN.py: n_layers) */
+  int32_t mlp_width;   /* N: nodes per layer (architectures/sNN.py: n_nodes) */
+  int32_t n_params;    /* doubles per trajectory in params[]: >= 8 (p1..p8), >= 12 for MARKOV6 */
+  int64_t max_steps;   /* accepted + rejected steps allowed per trajectory */
+  double prot_t0;      /* uniform protocol grid t_i = prot_t0 + i*prot_dt (used when prot_t == NULL) */
+  double prot_dt;
+  double v_oob;        /* voltage substituted outside the protocol's time range: -80 (train-s1.py:237) */
+  double rtol, atol;   /* torchdiffeq defaults 1e-7 / 1e-9; the reference never overrides them */
+  double obs_g;        /* observation epilogue i = g * gate * (V(t_k) - obs_e); gate = y0*y1 or y[D-1] */
+  double obs_e;
+  int32_t obs_open_state_only; /* 1: gate = last state (6-state O, train-d1.py:299) */
+  int32_t tile_waves;  /* MLP models: wavefronts cooperating on one 16-trajectory tile (0 = auto, 1, 2, 4) */
+} ionode_desc;
+
+/* Number of floats of the device-side weight image for an (L, N) MLP  Linear(2,N) + L x Linear(N,N) + Linear(N,1). */
+size_t ionode_mlp_packed_floats(int32_t mlp_layers, int32_t mlp_width);
+
+/* HOST -> HOST.  Re-lays a state dict (flat fp32, order net.0.weight [N][2], net.0.bias [N],
+ * {net.2i.weight [N][N], net.2i.bias [N]} x L, net.last.weight [1][N], net.last.bias [1]; row-major as
+ * torch stores nn.Linear) into the MFMA-fragment order the kernels stream.  The caller uploads `packed`. */
+int ionode_mlp_pack(const float *state_dict_flat, int32_t mlp_layers, int32_t mlp_width, float *packed);
+
+/*
+ * Integrate d->n_traj independent trajectories on the current device, asynchronously on `stream`.
+ *
+ *   mlp_packed    device, ionode_mlp_packed_floats() floats (NULL for HH2 / MARKOV6)
+ *   params        device, [B][n_params] fp64: p1..p8 (NNF reads p5..p8) or p1..p12
+ *   prot_v        device, [P][prot_n] fp64 mV
+ *   prot_t        device, [prot_n] fp64 ms shared by all protocols, or NULL for the uniform grid
+ *   prot_of_traj  device, [B] int32 protocol index per trajectory, or NULL (trajectory b uses b % P)
+ *   y0            device, [B][D] in the state dtype
+ *   t_eval        device, [n_out] fp64, strictly increasing; t_eval[0] is the initial time
+ *   y_out         device, [B][n_out][D] in the state dtype
+ *   i_out         device, [B][n_out] fp64 current trace, or NULL
+ *   status        device, [B] int32 IONODE_STATUS_*
+ *   stats         device, [B][4] int64 {accepted steps, rejected steps, RHS evaluations, status}, or NULL
+ *   stream        hipStream_t (NULL = default stream)
+ *
+ * Returns IONODE_OK once the kernel is enqueued; per-trajectory failures are reported in status[]
+ * (their remaining outputs are NaN), never as a return code.
+ */
+int ionode_dopri5(const ionode_desc *d, const float *mlp_packed, const double *params, const double *prot_v,
+                  const double *prot_t, const int32_t *prot_of_traj, const void *y0, const double *t_eval,
+                  void *y_out, double *i_out, int32_t *status, int64_t *stats, void *stream);
+
+/* Launch geometry the dispatcher would use for `d` (for tests / bench reporting): grid, block, LDS bytes, tile_waves. */
+int ionode_launch_geometry(const ionode_desc *d, int32_t out[4]);
+
+/* Name of the kernel instantiation ionode_dopri5 would launch for `d` (matches rocprofv3 kernel-trace). */
+const char *ionode_kernel_name(const ionode_desc *d);
+
+const char *ionode_last_error(void);
+int32_t ionode_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IONODE_H */

@@ -1,0 +1,187 @@
+"""ctypes binding of libionode.so (include/ionode.h).  torch is used for device memory and streams only.
+
+There is no CPU fallback: if the HIP library is missing or no GPU is visible, the calls raise.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libionode.so")
+
+MODEL_HH2, MODEL_MARKOV6, MODEL_NNF, MODEL_NND = 0, 1, 2, 3
+STATUS_OK, STATUS_DT_UNDERFLOW, STATUS_NONFINITE, STATUS_MAX_STEPS = 0, 1, 2, 3
+STATUS_TEXT = {
+    0: "ok",
+    1: "underflow in dt",                 # torchdiffeq's assertion messages
+    2: "non-finite values in state `y`",
+    3: "max_num_steps exceeded",
+}
+ABI_VERSION = 1
+
+EXPORTS = (
+    "ionode_abi_version", "ionode_last_error", "ionode_mlp_packed_floats", "ionode_mlp_pack",
+    "ionode_launch_geometry", "ionode_kernel_name", "ionode_dopri5",
+)
+
+
+class IonodeDesc(C.Structure):
+    _fields_ = [
+        ("model", C.c_int32), ("state_f32", C.c_int32), ("n_state", C.c_int32), ("n_out", C.c_int32),
+        ("n_traj", C.c_int32), ("n_prot", C.c_int32), ("prot_n", C.c_int32), ("mlp_layers", C.c_int32),
+        ("mlp_width", C.c_int32), ("n_params", C.c_int32), ("max_steps", C.c_int64),
+        ("prot_t0", C.c_double), ("prot_dt", C.c_double), ("v_oob", C.c_double),
+        ("rtol", C.c_double), ("atol", C.c_double), ("obs_g", C.c_double), ("obs_e", C.c_double),
+        ("obs_open_state_only", C.c_int32), ("tile_waves", C.c_int32),
+    ]
+
+
+class IonodeError(RuntimeError):
+    pass
+
+
+def build(force=False, jobs=8):
+    """Compile libionode.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-C", csrc, "-s", "clean"])
+    subprocess.check_call(["make", "-C", csrc, "-s", f"-j{jobs}"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise IonodeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(there is no CPU fallback for the integrator)")
+        L = C.CDLL(LIB_PATH)
+        L.ionode_abi_version.restype = C.c_int32
+        L.ionode_last_error.restype = C.c_char_p
+        L.ionode_kernel_name.restype = C.c_char_p
+        L.ionode_kernel_name.argtypes = [C.POINTER(IonodeDesc)]
+        L.ionode_mlp_packed_floats.restype = C.c_size_t
+        L.ionode_mlp_packed_floats.argtypes = [C.c_int32, C.c_int32]
+        L.ionode_mlp_pack.restype = C.c_int
+        L.ionode_mlp_pack.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        L.ionode_launch_geometry.restype = C.c_int
+        L.ionode_launch_geometry.argtypes = [C.POINTER(IonodeDesc), C.POINTER(C.c_int32 * 4)]
+        L.ionode_dopri5.restype = C.c_int
+        L.ionode_dopri5.argtypes = [C.POINTER(IonodeDesc)] + [C.c_void_p] * 12
+        if L.ionode_abi_version() != ABI_VERSION:
+            raise IonodeError("libionode.so ABI version mismatch; rebuild")
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return lib().ionode_last_error().decode()
+
+
+def mlp_pack(state_dict_flat, mlp_layers, mlp_width):
+    """Flat fp32 state dict (numpy, reference order) -> packed fp32 image (numpy) for upload."""
+    w = np.ascontiguousarray(np.asarray(state_dict_flat, dtype=np.float32).reshape(-1))
+    N, L = int(mlp_width), int(mlp_layers)
+    expect = 2 * N + N + L * (N * N + N) + N + 1
+    if w.size != expect:
+        raise IonodeError(f"state dict has {w.size} floats, (L={L}, N={N}) needs {expect}")
+    out = np.empty(lib().ionode_mlp_packed_floats(L, N), dtype=np.float32)
+    rc = lib().ionode_mlp_pack(w.ctypes.data, L, N, out.ctypes.data)
+    if rc != 0:
+        raise IonodeError(last_error())
+    return out
+
+
+def make_desc(**kw):
+    d = IonodeDesc()
+    for k, v in kw.items():
+        setattr(d, k, v)
+    return d
+
+
+def launch_geometry(desc):
+    out = (C.c_int32 * 4)()
+    rc = lib().ionode_launch_geometry(C.byref(desc), C.byref(out))
+    if rc != 0:
+        raise IonodeError(last_error())
+    return {"grid": out[0], "block": out[1], "lds_bytes": out[2], "tile_waves": out[3]}
+
+
+def kernel_name(desc):
+    return lib().ionode_kernel_name(C.byref(desc)).decode()
+
+
+def _dev_ptr(t, dtype, name, shape=None):
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise IonodeError(f"{name}: expected a CUDA/HIP tensor (the integrator has no CPU path)")
+    if t.dtype != dtype or not t.is_contiguous():
+        raise IonodeError(f"{name}: expected contiguous {dtype}, got {t.dtype} contiguous={t.is_contiguous()}")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise IonodeError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return C.c_void_p(t.data_ptr())
+
+
+def dopri5(model, params, prot_v, y0, t_eval, *, mlp_packed=None, mlp_layers=0, mlp_width=0, prot_t=None,
+           prot_t0=0.0, prot_dt=1.0, prot_of_traj=None, rtol=1e-7, atol=1e-9, v_oob=-80.0, max_steps=0,
+           current=False, obs_g=1.0, obs_e=-86.0, obs_open_state_only=False, tile_waves=0, stats=True,
+           out=None, stream=None):
+    """Launch one batched solve.  Every tensor lives on the current HIP device.
+
+    params [B, n_params] f64, prot_v [P, Np] f64, y0 [B, D] f32|f64 (selects the state dtype),
+    t_eval [Nt] f64.  Returns dict(y [B, Nt, D], i [B, Nt] | None, status [B] i32, stats [B, 4] i64 | None);
+    asynchronous on the current stream.
+    """
+    if not torch.cuda.is_available():
+        raise IonodeError("no HIP device visible: ionode has no CPU fallback")
+    B, D = y0.shape
+    Nt = t_eval.shape[0]
+    P, Np = prot_v.shape
+    sdt = y0.dtype
+    if sdt not in (torch.float32, torch.float64):
+        raise IonodeError("y0 must be float32 or float64")
+    desc = make_desc(model=model, state_f32=int(sdt == torch.float32), n_state=D, n_out=Nt, n_traj=B, n_prot=P,
+                     prot_n=Np, mlp_layers=mlp_layers, mlp_width=mlp_width, n_params=params.shape[1],
+                     max_steps=max_steps, prot_t0=prot_t0, prot_dt=prot_dt, v_oob=v_oob, rtol=rtol, atol=atol,
+                     obs_g=obs_g, obs_e=obs_e, obs_open_state_only=int(obs_open_state_only), tile_waves=tile_waves)
+    dev = y0.device
+    if out is None:
+        out = {}
+    y = out.get("y")
+    if y is None:
+        y = torch.empty((B, Nt, D), dtype=sdt, device=dev)
+    i_out = out.get("i")
+    if current and i_out is None:
+        i_out = torch.empty((B, Nt), dtype=torch.float64, device=dev)
+    status = out.get("status")
+    if status is None:
+        status = torch.empty((B,), dtype=torch.int32, device=dev)
+    st = out.get("stats")
+    if stats and st is None:
+        st = torch.empty((B, 4), dtype=torch.int64, device=dev)
+    s = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
+    rc = lib().ionode_dopri5(
+        C.byref(desc),
+        _dev_ptr(mlp_packed, torch.float32, "mlp_packed"),
+        _dev_ptr(params, torch.float64, "params", (B, params.shape[1])),
+        _dev_ptr(prot_v, torch.float64, "prot_v"),
+        _dev_ptr(prot_t, torch.float64, "prot_t", (Np,)) if prot_t is not None else None,
+        _dev_ptr(prot_of_traj, torch.int32, "prot_of_traj", (B,)) if prot_of_traj is not None else None,
+        _dev_ptr(y0, sdt, "y0"),
+        _dev_ptr(t_eval, torch.float64, "t_eval"),
+        _dev_ptr(y, sdt, "y_out", (B, Nt, D)),
+        _dev_ptr(i_out, torch.float64, "i_out", (B, Nt)) if i_out is not None else None,
+        _dev_ptr(status, torch.int32, "status", (B,)),
+        _dev_ptr(st, torch.int64, "stats", (B, 4)) if st is not None else None,
+        C.c_void_p(s),
+    )
+    if rc != 0:
+        raise IonodeError(f"ionode_dopri5 failed ({rc}): {last_error()}")
+    return {"y": y, "i": i_out, "status": status, "stats": st, "desc": desc}

@@ -1,0 +1,9 @@
+// Closed-form RHS kernels: HH 2-state and 6-state Markov, fp32 and fp64 state.
+#include "ionode_launch.hpp"
+namespace ionode {
+static const Variant kTab[] = {
+    IONODE_VARIANT(0, double, 0, 1, 1), IONODE_VARIANT(0, float, 1, 1, 1),
+    IONODE_VARIANT(1, double, 0, 1, 1), IONODE_VARIANT(1, float, 1, 1, 1),
+};
+const Variant *variants_closed(int *n) { *n = sizeof(kTab) / sizeof(kTab[0]); return kTab; }
+}  // namespace ionode

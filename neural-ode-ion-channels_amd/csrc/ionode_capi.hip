@@ -1,0 +1,167 @@
+// ionode_capi.hip -- the C ABI of libionode.so (include/ionode.h): argument checking, choice of
+// kernel instantiation and launch geometry, and the host-side re-layout of an nn.Sequential
+// state dict into the MFMA fragment order the kernels stream.
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "ionode_launch.hpp"
+
+namespace {
+
+thread_local char g_err[256] = "";
+
+void set_err(const char *fmt, const char *detail = "") { snprintf(g_err, sizeof g_err, fmt, detail); }
+
+inline int np_of(int N) { return 16 * ((N + 15) / 16); }
+
+struct Plan {
+  const ionode::Variant *v = nullptr;
+  unsigned grid = 0;
+  unsigned block = 0;
+  size_t lds = 0;
+};
+
+const ionode::Variant *find_variant(int model, int f32, int G, int RT) {
+  using namespace ionode;
+  typedef const Variant *(*TabFn)(int *);
+  static const TabFn tabs[] = {variants_closed, variants_nnf_f64, variants_nnf_f32, variants_nnd_f64, variants_nnd_f32};
+  for (TabFn tf : tabs) {
+    int n = 0;
+    const Variant *t = tf(&n);
+    for (int i = 0; i < n; ++i)
+      if (t[i].model == model && t[i].f32 == f32 && t[i].G == G && t[i].RT == RT) return &t[i];
+  }
+  return nullptr;
+}
+
+int make_plan(const ionode_desc *d, Plan *pl) {
+  if (!d) { set_err("null descriptor"); return IONODE_ERR_ARG; }
+  const bool mlp = d->model == IONODE_MODEL_NNF || d->model == IONODE_MODEL_NND;
+  const int D = d->model == IONODE_MODEL_MARKOV6 ? 6 : 2;
+  if (d->model < 0 || d->model > 3) { set_err("unknown model"); return IONODE_ERR_ARG; }
+  if (d->n_state != D) { set_err("n_state does not match model"); return IONODE_ERR_ARG; }
+  if (d->n_traj < 1 || d->n_out < 1 || d->n_prot < 1 || d->prot_n < 2) { set_err("empty batch / grid / protocol"); return IONODE_ERR_ARG; }
+  if (d->n_params < (D == 6 ? 12 : 8)) { set_err("n_params too small for model"); return IONODE_ERR_ARG; }
+  if (!(d->rtol > 0) || !(d->atol >= 0) || !(d->prot_dt > 0)) { set_err("rtol/atol/prot_dt must be positive"); return IONODE_ERR_ARG; }
+  const int f32 = d->state_f32 ? 1 : 0;
+  if (!mlp) {
+    pl->v = find_variant(d->model, f32, 1, 1);
+    pl->grid = (unsigned)((d->n_traj + 63) / 64);
+    pl->block = 64;
+    pl->lds = 0;
+  } else {
+    if (d->mlp_width < 1 || d->mlp_layers < 0) { set_err("bad MLP shape"); return IONODE_ERR_ARG; }
+    const int NP = np_of(d->mlp_width), NT = NP / 16;
+    int G = d->tile_waves;
+    if (G == 0) G = (NT == 1) ? 1 : 4;
+    if (G != 1 && G != 4) { set_err("tile_waves must be 0, 1 or 4"); return IONODE_ERR_UNSUPPORTED; }
+    const int need = (NT + G - 1) / G;
+    int RT = 0;
+    for (int c : {1, 2, 4, 8}) {
+      if (c >= need && find_variant(d->model, f32, G, c)) { RT = c; break; }
+    }
+    if (!RT) { set_err("MLP width outside the compiled kernel variants (N <= 512 with 4 waves, N <= 16 with 1)"); return IONODE_ERR_UNSUPPORTED; }
+    pl->v = find_variant(d->model, f32, G, RT);
+    pl->grid = (unsigned)((d->n_traj + 15) / 16);
+    pl->block = 64u * G;
+    pl->lds = ((size_t)2 * NT * 64 + NP) * 16;
+  }
+  if (!pl->v) { set_err("no kernel variant compiled for this descriptor"); return IONODE_ERR_UNSUPPORTED; }
+  return IONODE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t ionode_abi_version(void) { return IONODE_ABI_VERSION; }
+
+const char *ionode_last_error(void) { return g_err; }
+
+size_t ionode_mlp_packed_floats(int32_t L, int32_t N) {
+  if (L < 0 || N < 1) return 0;
+  const size_t NP = (size_t)np_of(N);
+  return 4 * NP + (size_t)L * (NP * NP + NP) + NP + 4;
+}
+
+int ionode_mlp_pack(const float *w, int32_t L, int32_t N, float *out) {
+  if (!w || !out || L < 0 || N < 1) { set_err("ionode_mlp_pack: bad argument"); return IONODE_ERR_ARG; }
+  const int NP = np_of(N), NT = NP / 16;
+  memset(out, 0, ionode_mlp_packed_floats(L, N) * sizeof(float));
+  // layer 0: rows {b0, w00, w01, 0}
+  const float *W0 = w, *b0 = w + (size_t)N * 2;
+  for (int r = 0; r < N; ++r) {
+    out[4 * r + 0] = b0[r];
+    out[4 * r + 1] = W0[2 * r + 0];
+    out[4 * r + 2] = W0[2 * r + 1];
+  }
+  const float *src = b0 + N;
+  float *dst = out + 4 * (size_t)NP;
+  for (int l = 0; l < L; ++l) {
+    const float *W = src, *b = src + (size_t)N * N;
+    // A fragments of v_mfma_f32_16x16x4_f32: lane = 16q + m holds row 16rt + m, k = 16kt + 4q + r
+    for (int rt = 0; rt < NT; ++rt)
+      for (int kt = 0; kt < NT; ++kt)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int m = lane & 15, q = lane >> 4;
+          const int row = 16 * rt + m;
+          for (int r = 0; r < 4; ++r) {
+            const int k = 16 * kt + 4 * q + r;
+            const float val = (row < N && k < N) ? W[(size_t)row * N + k] : 0.0f;
+            dst[(((size_t)rt * NT + kt) * 64 + lane) * 4 + r] = val;
+          }
+        }
+    float *bias = dst + (size_t)NP * NP;
+    for (int r = 0; r < N; ++r) bias[r] = b[r];
+    src += (size_t)N * N + N;
+    dst += (size_t)NP * NP + NP;
+  }
+  for (int k = 0; k < N; ++k) dst[k] = src[k];
+  dst[NP] = src[N];
+  return IONODE_OK;
+}
+
+int ionode_launch_geometry(const ionode_desc *d, int32_t out[4]) {
+  Plan pl;
+  const int rc = make_plan(d, &pl);
+  if (rc != IONODE_OK) return rc;
+  out[0] = (int32_t)pl.grid;
+  out[1] = (int32_t)pl.block;
+  out[2] = (int32_t)pl.lds;
+  out[3] = pl.v->G;
+  return IONODE_OK;
+}
+
+const char *ionode_kernel_name(const ionode_desc *d) {
+  Plan pl;
+  if (make_plan(d, &pl) != IONODE_OK) return "";
+  return pl.v->name;
+}
+
+int ionode_dopri5(const ionode_desc *d, const float *mlp_packed, const double *params, const double *prot_v,
+                  const double *prot_t, const int32_t *prot_of_traj, const void *y0, const double *t_eval,
+                  void *y_out, double *i_out, int32_t *status, int64_t *stats, void *stream) {
+  Plan pl;
+  const int rc = make_plan(d, &pl);
+  if (rc != IONODE_OK) return rc;
+  const bool mlp = d->model == IONODE_MODEL_NNF || d->model == IONODE_MODEL_NND;
+  if (!params || !prot_v || !y0 || !t_eval || !y_out || !status || (mlp && !mlp_packed)) {
+    set_err("ionode_dopri5: required buffer is NULL");
+    return IONODE_ERR_ARG;
+  }
+  ionode::KArgs a;
+  memset(&a, 0, sizeof a);
+  a.mlp = mlp_packed; a.params = params; a.prot_v = prot_v; a.prot_t = prot_t; a.prot_of_traj = prot_of_traj;
+  a.y0 = y0; a.t_eval = t_eval; a.y_out = y_out; a.i_out = i_out; a.status = status; a.stats = stats;
+  a.B = d->n_traj; a.Nt = d->n_out; a.P = d->n_prot; a.Np = d->prot_n; a.n_params = d->n_params;
+  if (mlp) { a.L = d->mlp_layers; a.N = d->mlp_width; a.NP = np_of(d->mlp_width); a.NT = a.NP / 16; }
+  a.max_steps = d->max_steps > 0 ? d->max_steps : (int64_t)1 << 40;
+  a.prot_t0 = d->prot_t0; a.prot_dt = d->prot_dt; a.v_oob = d->v_oob; a.rtol = d->rtol; a.atol = d->atol;
+  a.obs_g = d->obs_g; a.obs_e = d->obs_e; a.obs_open = d->obs_open_state_only;
+  const hipError_t e = pl.v->fn(a, pl.grid, pl.lds, reinterpret_cast<hipStream_t>(stream));
+  if (e != hipSuccess) { set_err("kernel launch failed: %s", hipGetErrorString(e)); return IONODE_ERR_LAUNCH; }
+  return IONODE_OK;
+}
+
+}  // extern "C"

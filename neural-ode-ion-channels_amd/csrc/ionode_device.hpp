@@ -1,0 +1,652 @@
+// ionode_device.hpp -- gfx950 (CDNA4, MI355X) device code of the batched dopri5 integrator.
+//
+// Execution model (DESIGN.md "Kernels"):
+//   * A *tile* of trajectories advances in lock-step over step ATTEMPTS (every attempt costs the
+//     same six RHS evaluations whether it is accepted or not), each trajectory with its own
+//     t, dt and accept/reject decision.  Closed-form models: 64 trajectories per wavefront, one
+//     per lane.  MLP models (NN-f / NN-d): 16 trajectories per tile, lane = 16*q + j holds
+//     trajectory j (replicated over q = 0..3 and over the G wavefronts of the workgroup), which
+//     is exactly the B-operand / accumulator column layout of v_mfma_f32_16x16x4_f32.
+//   * The stage MLP of the tile is a chain of [NP x NP] x [NP x 16] products on the fp32 MFMA
+//     (bit-for-bit an fmaf chain, i.e. the reference's fp32 arithmetic; same rate as the fp32 VALU
+//     but one VGPR per operand and no broadcast traffic).  Accumulator tiles are handed to the
+//     next layer as B operands without any transpose by permuting the contraction index:
+//     register r of lane-group q of tile kt is k = 16*kt + 4*q + r.  Weights stream from L2 in
+//     that fragment order (host-packed, 1 KiB per wave-load); activations are exchanged between
+//     the G wavefronts through LDS (double-buffered, one barrier per layer).
+//   * Dense output is emitted cooperatively: for every trajectory whose step was accepted, the
+//     wavefront evaluates the 4th-order interpolant at 64 consecutive output times at once and
+//     stores them coalesced (D*sizeof(S) bytes per lane).
+//
+// Arithmetic follows torchdiffeq 0.2.1's dopri5 operation by operation in the
+// dtype torch would use; this translation unit is compiled with -ffp-contract=off so every a*b+c in
+// the source is two IEEE operations, and the only fused operations are the explicit fmaf()/MFMA
+// chains of the MLP.  Reference RHS definitions: train-s1.py:161-177 (HH), train-d1.py:165-187
+// (6-state), train-s1.py:231-247 (NN-f), train-d2.py:247-272 (NN-d); protocol rule train-s1.py:218-237.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ionode.h"
+
+namespace ionode {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+struct KArgs {
+  const float *mlp;  // packed image (ionode_mlp_pack)
+  const double *params;
+  const double *prot_v;
+  const double *prot_t;
+  const int32_t *prot_of_traj;
+  const void *y0;
+  const double *t_eval;
+  void *y_out;
+  double *i_out;
+  int32_t *status;
+  int64_t *stats;
+  int32_t B, Nt, P, Np, n_params, L, N, NP, NT;
+  int64_t max_steps;
+  double prot_t0, prot_dt, v_oob, rtol, atol, obs_g, obs_e;
+  int32_t obs_open;
+};
+
+// Dormand-Prince / Shampine coefficients.
+__device__ constexpr double kAlpha[6] = {1.0 / 5, 3.0 / 10, 4.0 / 5, 8.0 / 9, 1.0, 1.0};
+__device__ constexpr double kBeta[6][6] = {
+    {1.0 / 5, 0, 0, 0, 0, 0},
+    {3.0 / 40, 9.0 / 40, 0, 0, 0, 0},
+    {44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0, 0},
+    {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729, 0, 0},
+    {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656, 0},
+    {35.0 / 384, 0.0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84},
+};
+__device__ constexpr double kCerr[7] = {
+    35.0 / 384 - 1951.0 / 21600,       0.0,
+    500.0 / 1113 - 22642.0 / 50085,    125.0 / 192 - 451.0 / 720,
+    -2187.0 / 6784 - -12231.0 / 42400, 11.0 / 84 - 649.0 / 6300,
+    -1.0 / 60.0,
+};
+__device__ constexpr double kCmid[7] = {
+    6025192743.0 / 30085553152.0 / 2,     0.0,
+    51252292925.0 / 65400821598.0 / 2,    -2691868925.0 / 45128329728.0 / 2,
+    187940372067.0 / 1594534317056.0 / 2, -1776094331.0 / 19743644256.0 / 2,
+    11237099.0 / 235043384.0 / 2,
+};
+
+template <typename S> struct Real;
+template <> struct Real<float> {
+  static __device__ __forceinline__ float sqrt_(float x) { return sqrtf(x); }
+  static __device__ __forceinline__ float pow_(float x, float y) { return powf(x, y); }
+  static __device__ __forceinline__ float prev_(float x) { return nextafterf(x, x - 1.0f); }
+};
+template <> struct Real<double> {
+  static __device__ __forceinline__ double sqrt_(double x) { return sqrt(x); }
+  static __device__ __forceinline__ double pow_(double x, double y) { return pow(x, y); }
+  static __device__ __forceinline__ double prev_(double x) { return nextafter(x, x - 1.0); }
+};
+
+template <int MODEL> struct ModelTraits {
+  static constexpr int D = (MODEL == IONODE_MODEL_MARKOV6) ? 6 : 2;
+  static constexpr int NPAR = (MODEL == IONODE_MODEL_MARKOV6) ? 12 : 8;
+  static constexpr bool MLP = (MODEL == IONODE_MODEL_NNF || MODEL == IONODE_MODEL_NND);
+};
+
+__device__ __forceinline__ double bcast_f64(double x, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float bcast_f32(float x, int src) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src));
+}
+template <typename S> __device__ __forceinline__ S bcast(S x, int src);
+template <> __device__ __forceinline__ double bcast<double>(double x, int src) { return bcast_f64(x, src); }
+template <> __device__ __forceinline__ float bcast<float>(float x, int src) { return bcast_f32(x, src); }
+
+// interp1d(t, v) (linear) with the reference's out-of-range rule (train-s1.py:218-229, :234-237).
+// scipy: i = searchsorted(x, t) [left], clipped to [1, n-1]; y = slope*(t - x[i-1]) + y[i-1].
+// Uniform grids find i arithmetically (i = ceil((t - t0)/dt)); explicit grids by bisection.
+__device__ __forceinline__ bool protocol_v(const KArgs &a, const double *__restrict__ pv, double t, double &v) {
+  const int n = a.Np;
+  if (a.prot_t != nullptr) {
+    const double *__restrict__ x = a.prot_t;
+    if (t < x[0] || t > x[n - 1] || t != t) { v = a.v_oob; return false; }
+    int lo = 0, hi = n;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (x[mid] < t) lo = mid + 1; else hi = mid;
+    }
+    const int i = lo < 1 ? 1 : (lo > n - 1 ? n - 1 : lo);
+    const double slope = (pv[i] - pv[i - 1]) / (x[i] - x[i - 1]);
+    v = slope * (t - x[i - 1]) + pv[i - 1];
+    return true;
+  }
+  const double t_last = a.prot_t0 + (double)(n - 1) * a.prot_dt;
+  if (t < a.prot_t0 || t > t_last || t != t) { v = a.v_oob; return false; }
+  const double u = (t - a.prot_t0) / a.prot_dt;
+  double ci = ceil(u);
+  if (ci < 1.0) ci = 1.0;
+  if (ci > (double)(n - 1)) ci = (double)(n - 1);
+  const int i = (int)ci;
+  const double x_lo = a.prot_t0 + (double)(i - 1) * a.prot_dt;
+  const double slope = (pv[i] - pv[i - 1]) / a.prot_dt;
+  v = slope * (t - x_lo) + pv[i - 1];
+  return true;
+}
+
+__device__ __forceinline__ float lrelu(float x) { return x > 0.0f ? x : x * 0.01f; }
+
+// ---------------------------------------------------------------------------------------------
+// Stage MLP of one 16-trajectory tile on the fp32 MFMA.  Called by all G wavefronts of the
+// workgroup in uniform control flow.  Returns net([x0, x1]) for the lane's trajectory.
+//   image layout (ionode_mlp_pack):  [NP][4] {b0,w00,w01,0} | L x { A[rt][kt][lane][4], bias[NP] } | wl[NP], bl
+//   canonical order: acc = bias; for kt: for r: for q: acc = fmaf(W[row][16kt+4q+r], h[16kt+4q+r], acc)
+// ---------------------------------------------------------------------------------------------
+template <int G, int RT>
+__device__ __forceinline__ float mlp_tile_eval(const KArgs &a, float x0, float x1, f32x4 *__restrict__ Hs,
+                                               const f32x4 *__restrict__ W0s, int wave, int lane) {
+  const int NP = a.NP, NT = a.NT, L = a.L;
+  const int q = lane >> 4;
+  const int tstride = NT * 64;
+
+  // layer 0: Linear(2, N) + LeakyReLU on the VALU, written in accumulator layout
+#pragma unroll
+  for (int i = 0; i < RT; ++i) {
+    const int rt = wave + i * G;
+    if (rt < NT) {
+      f32x4 h;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const f32x4 w = W0s[16 * rt + 4 * q + r];
+        h[r] = lrelu(fmaf(w[2], x1, fmaf(w[1], x0, w[0])));
+      }
+      Hs[rt * 64 + lane] = h;
+    }
+  }
+  if (G > 1) __syncthreads();
+
+  const size_t lstride = (size_t)NP * NP + NP;
+  for (int l = 0; l < L; ++l) {
+    const f32x4 *__restrict__ Hin = Hs + (l & 1) * tstride;
+    f32x4 *__restrict__ Hout = Hs + ((l + 1) & 1) * tstride;
+    const float *__restrict__ Wl = a.mlp + 4 * (size_t)NP + (size_t)l * lstride;
+    const float *__restrict__ bias = Wl + (size_t)NP * NP;
+    const f32x4 *__restrict__ Ap = reinterpret_cast<const f32x4 *>(Wl) + lane;
+
+    f32x4 acc[RT], a_nxt[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+      const int rt = wave + i * G;
+      if (rt < NT) {
+        acc[i] = *reinterpret_cast<const f32x4 *>(bias + 16 * rt + 4 * q);
+        a_nxt[i] = Ap[(size_t)(rt * NT) * 64];
+      } else {
+        acc[i] = f32x4{0, 0, 0, 0};
+        a_nxt[i] = f32x4{0, 0, 0, 0};
+      }
+    }
+    for (int kt = 0; kt < NT; ++kt) {
+      f32x4 a_cur[RT];
+#pragma unroll
+      for (int i = 0; i < RT; ++i) a_cur[i] = a_nxt[i];
+      if (kt + 1 < NT) {
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+          const int rt = wave + i * G;
+          if (rt < NT) a_nxt[i] = Ap[(size_t)(rt * NT + kt + 1) * 64];
+        }
+      }
+      const f32x4 b = Hin[kt * 64 + lane];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+          const int rt = wave + i * G;
+          if (rt < NT) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[i][r], b[r], acc[i], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+      const int rt = wave + i * G;
+      if (rt < NT) {
+        f32x4 h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = lrelu(acc[i][r]);
+        Hout[rt * 64 + lane] = h;
+      }
+    }
+    if (G > 1) __syncthreads();
+  }
+
+  // Linear(N, 1): one MFMA row tile whose only non-zero row is row 0 (lanes with lane&15 == 0
+  // carry the weights); every wavefront computes it redundantly from the shared activations.
+  const f32x4 *__restrict__ Hin = Hs + (L & 1) * tstride;
+  const float *__restrict__ wl = a.mlp + 4 * (size_t)NP + (size_t)L * lstride;
+  const bool row0 = (lane & 15) == 0;
+  f32x4 acc = {0, 0, 0, 0};
+  acc[0] = (q == 0) ? wl[NP] : 0.0f;
+  for (int kt = 0; kt < NT; ++kt) {
+    f32x4 w = *reinterpret_cast<const f32x4 *>(wl + 16 * kt + 4 * q);
+    if (!row0) w = f32x4{0, 0, 0, 0};
+    const f32x4 b = Hin[kt * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], b[r], acc, 0, 0, 0);
+  }
+  const float out = __shfl(acc[0], lane & 15);
+  if (G > 1 && (L & 1) == 0) __syncthreads();  // next evaluation's layer 0 rewrites buffer 0
+  return out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// func.forward(t, y) of the reference, per lane (t already in the state dtype, as _PerturbFunc casts it)
+// ---------------------------------------------------------------------------------------------
+template <int MODEL, typename S, int G, int RT>
+__device__ __forceinline__ void rhs(const KArgs &a, const double *__restrict__ pv, const double *p, S t, const S *y,
+                                    S *f, f32x4 *Hs, const f32x4 *W0s, int wave, int lane) {
+  using MT = ModelTraits<MODEL>;
+  constexpr bool F32 = sizeof(S) == 4;
+  double v;
+  const bool inrange = protocol_v(a, pv, (double)t, v);
+
+  if constexpr (MODEL == IONODE_MODEL_MARKOV6) {
+    if (F32 && !inrange) {
+      // v = torch.tensor([-80]) is int64: `p * v` is float32 and exp runs in fp32 (train-d1.py:169-178)
+      const float vf = (float)a.v_oob;
+      const float a1 = (float)p[0] * expf((float)p[1] * vf);
+      const float b1 = (float)p[2] * expf((float)(-p[3]) * vf);
+      const float bh = (float)p[4] * expf((float)p[5] * vf);
+      const float ah = (float)p[6] * expf((float)(-p[7]) * vf);
+      const float a2 = (float)p[8] * expf((float)p[9] * vf);
+      const float b2 = (float)p[10] * expf((float)(-p[11]) * vf);
+      const float c1 = y[0], c2 = y[1], i_ = y[2], ic1 = y[3], ic2 = y[4], o = y[5];
+      f[0] = a1 * c2 + ah * ic1 + b2 * o - (b1 + bh + a2) * c1;
+      f[1] = b1 * c1 + ah * ic2 - (a1 + bh) * c2;
+      f[2] = a2 * ic1 + bh * o - (b2 + ah) * i_;
+      f[3] = a1 * ic2 + bh * c1 + b2 * i_ - (b1 + ah + a2) * ic1;
+      f[4] = b1 * ic1 + bh * c2 - (ah + a1) * ic2;
+      f[5] = a2 * c1 + ah * i_ - (b2 + bh) * o;
+      return;
+    }
+    const double a1 = p[0] * exp(p[1] * v);
+    const double b1 = p[2] * exp(-p[3] * v);
+    const double bh = p[4] * exp(p[5] * v);
+    const double ah = p[6] * exp(-p[7] * v);
+    const double a2 = p[8] * exp(p[9] * v);
+    const double b2 = p[10] * exp(-p[11] * v);
+    const double c1 = y[0], c2 = y[1], i_ = y[2], ic1 = y[3], ic2 = y[4], o = y[5];
+    f[0] = (S)(a1 * c2 + ah * ic1 + b2 * o - (b1 + bh + a2) * c1);
+    f[1] = (S)(b1 * c1 + ah * ic2 - (a1 + bh) * c2);
+    f[2] = (S)(a2 * ic1 + bh * o - (b2 + ah) * i_);
+    f[3] = (S)(a1 * ic2 + bh * c1 + b2 * i_ - (b1 + ah + a2) * ic1);
+    f[4] = (S)(b1 * ic1 + bh * c2 - (ah + a1) * ic2);
+    f[5] = (S)(a2 * c1 + ah * i_ - (b2 + bh) * o);
+    return;
+  } else {
+    constexpr bool HAS_HH_A = (MODEL == IONODE_MODEL_HH2 || MODEL == IONODE_MODEL_NND);
+    const S av = y[0], rv = y[1];
+    const bool oob32 = F32 && !inrange;
+
+    // MLP term first: it is a tile-wide collective, so every lane takes part whatever its branch below
+    float net = 0.0f;
+    if constexpr (MT::MLP) {
+      const float vf = (float)a.v_oob;
+      const float nv = oob32 ? vf / 100.0f : (float)(v / 100.0);  // v / self.vrange, then .float()
+      net = mlp_tile_eval<G, RT>(a, nv, (float)av, Hs, W0s, wave, lane) / 1000.0f;  // / self.netscale
+    }
+
+    if (oob32) {
+      const float vf = (float)a.v_oob;
+      const float af = (float)av, rf = (float)rv;
+      const float k3 = (float)p[4] * expf((float)p[5] * vf);
+      const float k4 = (float)p[6] * expf((float)(-p[7]) * vf);
+      const float drdt = -k3 * rf + k4 * (1.0f - rf);
+      float dadt = 0.0f;
+      if constexpr (HAS_HH_A) {
+        const float k1 = (float)p[0] * expf((float)p[1] * vf);
+        const float k2 = (float)p[2] * expf((float)(-p[3]) * vf);
+        dadt = k1 * (1.0f - af) - k2 * af;
+      }
+      if constexpr (MT::MLP) dadt = (MODEL == IONODE_MODEL_NND) ? dadt + net : net;
+      f[0] = (S)dadt;
+      f[1] = (S)drdt;
+      return;
+    }
+    const S one_m_a = (S)1 - av;  // `1. - a` / `self.unity - r` are formed in y.dtype
+    const S one_m_r = (S)1 - rv;
+    const double k3 = p[4] * exp(p[5] * v);
+    const double k4 = p[6] * exp(-p[7] * v);
+    const double drdt = -k3 * (double)rv + k4 * (double)one_m_r;
+    double dadt = 0.0;
+    if constexpr (HAS_HH_A) {
+      const double k1 = p[0] * exp(p[1] * v);
+      const double k2 = p[2] * exp(-p[3] * v);
+      dadt = k1 * (double)one_m_a - k2 * (double)av;
+    }
+    if constexpr (MT::MLP) dadt = (MODEL == IONODE_MODEL_NND) ? dadt + (double)net : (double)net;
+    f[0] = (S)dadt;
+    f[1] = (S)drdt;
+  }
+}
+
+template <typename S, int D> __device__ __forceinline__ S rms_norm(const S *x) {
+  S s = x[0] * x[0];
+#pragma unroll
+  for (int i = 1; i < D; ++i) s = s + x[i] * x[i];
+  s = s / (S)D;
+  return Real<S>::sqrt_(s);
+}
+template <typename S> __device__ __forceinline__ S abs_(S x) { return x < 0 ? -x : x; }
+
+template <typename S, int D> __device__ __forceinline__ void store_state(S *dst, const S *v) {
+  if constexpr (D == 2 && sizeof(S) == 8) {
+    *reinterpret_cast<double2 *>(dst) = make_double2(v[0], v[1]);
+  } else if constexpr (D == 2 && sizeof(S) == 4) {
+    *reinterpret_cast<float2 *>(dst) = make_float2(v[0], v[1]);
+  } else if constexpr (sizeof(S) == 8) {
+#pragma unroll
+    for (int d = 0; d < D; d += 2) *reinterpret_cast<double2 *>(dst + d) = make_double2(v[d], v[d + 1]);
+  } else {
+#pragma unroll
+    for (int d = 0; d < D; d += 2) *reinterpret_cast<float2 *>(dst + d) = make_float2(v[d], v[d + 1]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The integrator.  One workgroup = one tile of TPW trajectories (G wavefronts for MLP models).
+// ---------------------------------------------------------------------------------------------
+template <int MODEL, typename S, int G, int RT>
+__global__ void __launch_bounds__(64 * G) ionode_dopri5_kernel(const KArgs a) {
+  using MT = ModelTraits<MODEL>;
+  using R = Real<S>;
+  constexpr int D = MT::D, NPAR = MT::NPAR;
+  constexpr int TPW = MT::MLP ? 16 : 64;
+  static_assert(MT::MLP || G == 1, "closed-form models use one wavefront per tile");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  f32x4 *Hs = reinterpret_cast<f32x4 *>(smem);
+  f32x4 *W0s = Hs + 2 * a.NT * 64;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int j = lane % TPW;
+  const bool primary = (lane < TPW) && (wave == 0);  // the replica that writes per-trajectory scalars
+  const int traj_raw = blockIdx.x * TPW + j;
+  const bool valid = traj_raw < a.B;
+  const int traj = valid ? traj_raw : a.B - 1;
+
+  if constexpr (MT::MLP) {
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(a.mlp);
+    for (int i = threadIdx.x; i < a.NP; i += 64 * G) W0s[i] = src[i];
+    __syncthreads();
+  }
+
+  double p[NPAR];
+#pragma unroll
+  for (int i = 0; i < NPAR; ++i) p[i] = a.params[(size_t)traj * a.n_params + i];
+  const int pidx = a.prot_of_traj ? a.prot_of_traj[traj] : (traj % a.P);
+  const double *__restrict__ pv = a.prot_v + (size_t)pidx * a.Np;
+
+  const S rtol = (S)a.rtol, atol = (S)a.atol;
+  S *__restrict__ yout = reinterpret_cast<S *>(a.y_out) + (size_t)traj * a.Nt * D;
+  double *__restrict__ iout = a.i_out ? a.i_out + (size_t)traj * a.Nt : nullptr;
+  const int Nt = a.Nt;
+
+  S y[D], f[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) y[d] = reinterpret_cast<const S *>(a.y0)[(size_t)traj * D + d];
+
+  double t = a.t_eval[0];
+  rhs<MODEL, S, G, RT>(a, pv, p, (S)t, y, f, Hs, W0s, wave, lane);  // f0 = func(t[0], y0)
+
+  // _select_initial_step (order argument 4), all in the state dtype
+  double dt;
+  {
+    const S t0s = (S)t;
+    S scale[D], tmp[D], y1[D], f1[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) scale[d] = atol + abs_(y[d]) * rtol;
+#pragma unroll
+    for (int d = 0; d < D; ++d) tmp[d] = y[d] / scale[d];
+    const S d0 = rms_norm<S, D>(tmp);
+#pragma unroll
+    for (int d = 0; d < D; ++d) tmp[d] = f[d] / scale[d];
+    const S d1 = rms_norm<S, D>(tmp);
+    S h0;
+    if (d0 < (S)1e-5 || d1 < (S)1e-5) h0 = (S)1e-6;
+    else h0 = (S)0.01 * d0 / d1;
+#pragma unroll
+    for (int d = 0; d < D; ++d) y1[d] = y[d] + h0 * f[d];
+    rhs<MODEL, S, G, RT>(a, pv, p, t0s + h0, y1, f1, Hs, W0s, wave, lane);
+#pragma unroll
+    for (int d = 0; d < D; ++d) tmp[d] = (f1[d] - f[d]) / scale[d];
+    const S d2 = rms_norm<S, D>(tmp) / h0;
+    S h1;
+    if (d1 <= (S)1e-15 && d2 <= (S)1e-15) {
+      const S c = h0 * (S)1e-3;
+      h1 = (S)1e-6 > c ? (S)1e-6 : c;
+    } else {
+      h1 = R::pow_((S)0.01 / (d1 > d2 ? d1 : d2), (S)(1.0 / 5.0));
+    }
+    const S h = ((S)100 * h0 < h1) ? (S)100 * h0 : h1;
+    dt = (double)h;
+  }
+
+  // solution[0] = y0
+  if (valid && primary) {
+    store_state<S, D>(yout, y);
+    if (iout) {
+      double v0;
+      protocol_v(a, pv, t, v0);
+      S gate;
+      if (a.obs_open) gate = y[D - 1]; else gate = y[0] * y[1];
+      if (a.obs_g != 1.0) gate = (S)a.obs_g * gate;
+      iout[0] = (double)gate * (v0 - a.obs_e);
+    }
+  }
+
+  int oi = 1;  // next output index
+  int nacc = 0, nrej = 0;
+  int status = IONODE_STATUS_OK;
+  bool active = valid && Nt > 1;
+  const S nan_s = (S)__builtin_nan("");
+
+  for (;;) {
+    // ---- per-trajectory assertions of _adaptive_step / _advance ----
+    bool failed_now = false;
+    if (active) {
+      if ((int64_t)nacc + nrej >= a.max_steps) { status = IONODE_STATUS_MAX_STEPS; failed_now = true; }
+      else if (!(t + dt > t)) { status = IONODE_STATUS_DT_UNDERFLOW; failed_now = true; }
+      else {
+        bool fin = true;
+#pragma unroll
+        for (int d = 0; d < D; ++d) fin = fin && isfinite((double)y[d]);
+        if (!fin) { status = IONODE_STATUS_NONFINITE; failed_now = true; }
+      }
+      if (failed_now) active = false;
+    }
+    // failed trajectories: the rest of their output is NaN (cooperative fill)
+    {
+      unsigned long long fm = __ballot(failed_now && lane < TPW);
+      while (fm) {
+        const int jj = __builtin_ctzll(fm);
+        fm &= fm - 1;
+        if (G == 1 || (jj % G) == wave) {
+          const int o0 = __builtin_amdgcn_readlane(oi, jj);
+          const int tr = __builtin_amdgcn_readlane(traj, jj);
+          S *__restrict__ yo = reinterpret_cast<S *>(a.y_out) + (size_t)tr * Nt * D;
+          for (int idx = o0 + lane; idx < Nt; idx += 64) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) yo[(size_t)idx * D + d] = nan_s;
+            if (a.i_out) a.i_out[(size_t)tr * Nt + idx] = __builtin_nan("");
+          }
+        }
+      }
+    }
+    if (__ballot(active) == 0ull) break;
+
+    // ---- _runge_kutta_step ----
+    const double t0 = t;
+    const double t1 = t0 + dt;
+    const S t0s = (S)t0, dts = (S)dt, t1s = (S)t1;
+    S k[7][D], yi[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) k[0][d] = f[d];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const S ti = (i >= 4) ? R::prev_(t1s) : t0s + (S)kAlpha[i] * dts;  // alpha == 1: Perturb.PREV
+      S bd[6];
+#pragma unroll
+      for (int jx = 0; jx <= i; ++jx) bd[jx] = (S)kBeta[i][jx] * dts;
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        S s = k[0][d] * bd[0];
+#pragma unroll
+        for (int jx = 1; jx <= i; ++jx) s = s + k[jx][d] * bd[jx];
+        yi[d] = y[d] + s;
+      }
+      rhs<MODEL, S, G, RT>(a, pv, p, ti, yi, k[i + 1], Hs, W0s, wave, lane);
+    }
+    // y1 = y_5 (c_sol == beta[5] + [0]); error estimate; _compute_error_ratio
+    S tmp[D];
+    {
+      S be[7];
+#pragma unroll
+      for (int jx = 0; jx < 7; ++jx) be[jx] = dts * (S)kCerr[jx];
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        S e = k[0][d] * be[0];
+#pragma unroll
+        for (int jx = 1; jx < 7; ++jx) e = e + k[jx][d] * be[jx];
+        const S ay0 = abs_(y[d]), ay1 = abs_(yi[d]);
+        const S tol = atol + rtol * (ay0 > ay1 ? ay0 : ay1);
+        tmp[d] = e / tol;
+      }
+    }
+    const S ratio = abs_(rms_norm<S, D>(tmp));
+    const bool accept = ratio <= (S)1;
+
+    // _optimal_step_size (fp64)
+    double dt_next;
+    if (ratio == (S)0) dt_next = dt * 10.0;
+    else {
+      const double dfactor = (ratio < (S)1) ? 1.0 : 0.2;
+      const double er = (double)ratio;
+      double fac = 0.9 / pow(er, 0.2);
+      if (!(fac > dfactor)) fac = dfactor;
+      if (!(fac < 10.0)) fac = 10.0;
+      if (er != er) fac = __builtin_nan("");
+      dt_next = dt * fac;
+    }
+
+    const bool acc_now = active && accept;
+    if (active) { if (accept) ++nacc; else ++nrej; }
+
+    // ---- _interp_fit + cooperative dense output ----
+    S ic[5][D];  // e, d, c, b, a
+    {
+      S bm[7];
+#pragma unroll
+      for (int jx = 0; jx < 7; ++jx) bm[jx] = dts * (S)kCmid[jx];
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        S s = k[0][d] * bm[0];
+#pragma unroll
+        for (int jx = 1; jx < 7; ++jx) s = s + k[jx][d] * bm[jx];
+        const S YM = y[d] + s;
+        const S F0 = k[0][d], F1 = k[6][d], Y0 = y[d], Y1 = yi[d];
+        ic[4][d] = ((S)2 * dts) * (F1 - F0) - (S)8 * (Y1 + Y0) + (S)16 * YM;
+        ic[3][d] = dts * ((S)5 * F0 - (S)3 * F1) + (S)18 * Y0 + (S)14 * Y1 - (S)32 * YM;
+        ic[2][d] = dts * (F1 - (S)4 * F0) - (S)11 * Y0 - (S)5 * Y1 + (S)16 * YM;
+        ic[1][d] = dts * F0;
+        ic[0][d] = Y0;
+      }
+    }
+    {
+      unsigned long long em = __ballot(acc_now && lane < TPW);
+      while (em) {
+        const int jj = __builtin_ctzll(em);
+        em &= em - 1;
+        const bool owner = (G == 1) || ((jj % G) == wave);
+        int o = __builtin_amdgcn_readlane(oi, jj);
+        const double t1b = bcast_f64(t1, jj);
+        // every wavefront advances the output cursor; only the owner evaluates and stores
+        double t0b = 0.0;
+        S cb[5][D];
+        S *__restrict__ yo = nullptr;
+        double *__restrict__ io = nullptr;
+        const double *__restrict__ pvb = nullptr;
+        if (owner) {
+          t0b = bcast_f64(t0, jj);
+#pragma unroll
+          for (int c = 0; c < 5; ++c)
+#pragma unroll
+            for (int d = 0; d < D; ++d) cb[c][d] = bcast<S>(ic[c][d], jj);
+          const int tr = __builtin_amdgcn_readlane(traj, jj);
+          yo = reinterpret_cast<S *>(a.y_out) + (size_t)tr * Nt * D;
+          if (a.i_out) {
+            io = a.i_out + (size_t)tr * Nt;
+            const int pj = a.prot_of_traj ? a.prot_of_traj[tr] : (tr % a.P);
+            pvb = a.prot_v + (size_t)pj * a.Np;
+          }
+        }
+        for (;;) {
+          const int idx = o + lane;
+          const double tk = (idx < Nt) ? a.t_eval[idx] : __builtin_inf();
+          const bool ok = tk <= t1b;
+          if (owner && ok) {
+            // _interp_evaluate: x in fp64, cast; running powers
+            const S x = (S)((tk - t0b) / (t1b - t0b));
+            S out[D];
+            S xp = x;
+#pragma unroll
+            for (int d = 0; d < D; ++d) out[d] = cb[0][d] + x * cb[1][d];
+#pragma unroll
+            for (int c = 2; c < 5; ++c) {
+              xp = xp * x;
+#pragma unroll
+              for (int d = 0; d < D; ++d) out[d] = out[d] + xp * cb[c][d];
+            }
+            store_state<S, D>(yo + (size_t)idx * D, out);
+            if (io) {
+              double vk;
+              protocol_v(a, pvb, tk, vk);
+              S gate;
+              if (a.obs_open) gate = out[D - 1]; else gate = out[0] * out[1];
+              if (a.obs_g != 1.0) gate = (S)a.obs_g * gate;
+              io[idx] = (double)gate * (vk - a.obs_e);
+            }
+          }
+          const int n = __builtin_popcountll(__ballot(ok));
+          o += n;
+          if (n < 64) break;
+        }
+        if (j == jj) oi = o;
+      }
+    }
+
+    // ---- advance the RK state ----
+    if (acc_now) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) { y[d] = yi[d]; f[d] = k[6][d]; }
+      t = t1;
+      if (oi >= Nt) active = false;  // all requested outputs produced
+    }
+    if (active || acc_now) dt = dt_next;
+  }
+
+  if (valid && primary) {
+    a.status[traj] = status;
+    if (a.stats) {
+      int64_t *st = a.stats + (size_t)traj * 4;
+      st[0] = nacc;
+      st[1] = nrej;
+      st[2] = 2 + 6 * ((int64_t)nacc + nrej);
+      st[3] = status;
+    }
+  }
+}
+
+}  // namespace ionode
