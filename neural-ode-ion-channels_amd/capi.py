@@ -36,6 +36,7 @@ class IonodeDesc(C.Structure):
         ("prot_t0", C.c_double), ("prot_dt", C.c_double), ("v_oob", C.c_double),
         ("rtol", C.c_double), ("atol", C.c_double), ("obs_g", C.c_double), ("obs_e", C.c_double),
         ("obs_open_state_only", C.c_int32), ("tile_waves", C.c_int32),
+        ("step_log", C.c_void_p), ("step_log_cap", C.c_int64),
     ]
 
 
@@ -132,7 +133,7 @@ def _dev_ptr(t, dtype, name, shape=None):
 def dopri5(model, params, prot_v, y0, t_eval, *, mlp_packed=None, mlp_layers=0, mlp_width=0, prot_t=None,
            prot_t0=0.0, prot_dt=1.0, prot_of_traj=None, rtol=1e-7, atol=1e-9, v_oob=-80.0, max_steps=0,
            current=False, obs_g=1.0, obs_e=-86.0, obs_open_state_only=False, tile_waves=0, stats=True,
-           out=None, stream=None):
+           step_log=None, out=None, stream=None):
     """Launch one batched solve.  Every tensor lives on the current HIP device.
 
     params [B, n_params] f64, prot_v [P, Np] f64, y0 [B, D] f32|f64 (selects the state dtype),
@@ -151,6 +152,10 @@ def dopri5(model, params, prot_v, y0, t_eval, *, mlp_packed=None, mlp_layers=0, 
                      prot_n=Np, mlp_layers=mlp_layers, mlp_width=mlp_width, n_params=params.shape[1],
                      max_steps=max_steps, prot_t0=prot_t0, prot_dt=prot_dt, v_oob=v_oob, rtol=rtol, atol=atol,
                      obs_g=obs_g, obs_e=obs_e, obs_open_state_only=int(obs_open_state_only), tile_waves=tile_waves)
+    if step_log is not None:  # [cap, 4] f64 device tensor: (t0, dt, ratio, accepted) per attempt of trajectory 0
+        _dev_ptr(step_log, torch.float64, "step_log")
+        desc.step_log = step_log.data_ptr()
+        desc.step_log_cap = step_log.shape[0]
     dev = y0.device
     if out is None:
         out = {}

@@ -156,9 +156,10 @@ int ionode_dopri5(const ionode_desc *d, const float *mlp_packed, const double *p
   a.y0 = y0; a.t_eval = t_eval; a.y_out = y_out; a.i_out = i_out; a.status = status; a.stats = stats;
   a.B = d->n_traj; a.Nt = d->n_out; a.P = d->n_prot; a.Np = d->prot_n; a.n_params = d->n_params;
   if (mlp) { a.L = d->mlp_layers; a.N = d->mlp_width; a.NP = np_of(d->mlp_width); a.NT = a.NP / 16; }
-  a.max_steps = d->max_steps > 0 ? d->max_steps : (int64_t)1 << 40;
+  a.max_steps = d->max_steps > 0 ? d->max_steps : (int64_t)2147483647;  // torchdiffeq max_num_steps default 2**31 - 1
   a.prot_t0 = d->prot_t0; a.prot_dt = d->prot_dt; a.v_oob = d->v_oob; a.rtol = d->rtol; a.atol = d->atol;
   a.obs_g = d->obs_g; a.obs_e = d->obs_e; a.obs_open = d->obs_open_state_only;
+  a.step_log = d->step_log; a.step_log_cap = d->step_log ? d->step_log_cap : 0;
   const hipError_t e = pl.v->fn(a, pl.grid, pl.lds, reinterpret_cast<hipStream_t>(stream));
   if (e != hipSuccess) { set_err("kernel launch failed: %s", hipGetErrorString(e)); return IONODE_ERR_LAUNCH; }
   return IONODE_OK;

@@ -50,6 +50,8 @@ struct KArgs {
   int64_t max_steps;
   double prot_t0, prot_dt, v_oob, rtol, atol, obs_g, obs_e;
   int32_t obs_open;
+  double *step_log;
+  int64_t step_log_cap;
 };
 
 // Dormand-Prince / Shampine coefficients.
@@ -75,15 +77,59 @@ __device__ constexpr double kCmid[7] = {
     11237099.0 / 235043384.0 / 2,
 };
 
+// Deterministic exp() and fifth root (DESIGN.md "Deterministic transcendentals"): dopri5's controller
+// amplifies last-ulp differences of these two functions chaotically, so results are only reproducible
+// across devices/libraries if both are fixed IEEE operation sequences.  < 1 ulp / <= 2 ulp accurate.
+__device__ __forceinline__ double pow2i(int k) { return __longlong_as_double((long long)(k + 1023) << 52); }
+
+__device__ __forceinline__ double det_exp(double x) {
+  if (x != x) return x;
+  if (x > 709.782712893384) return __builtin_inf();
+  if (x < -745.1332191019412) return 0.0;
+  const double kf = rint(x * 0x1.71547652b82fep+0);
+  double r = fma(-kf, 0x1.62e42fee00000p-1, x);
+  r = fma(-kf, 0x1.a39ef35793c76p-33, r);
+  double p = 1.0 / 6227020800.0;
+  p = fma(p, r, 1.0 / 479001600.0);
+  p = fma(p, r, 1.0 / 39916800.0);
+  p = fma(p, r, 1.0 / 3628800.0);
+  p = fma(p, r, 1.0 / 362880.0);
+  p = fma(p, r, 1.0 / 40320.0);
+  p = fma(p, r, 1.0 / 5040.0);
+  p = fma(p, r, 1.0 / 720.0);
+  p = fma(p, r, 1.0 / 120.0);
+  p = fma(p, r, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  const int k = (int)kf;
+  const int k1 = k / 2;
+  return (p * pow2i(k1)) * pow2i(k - k1);
+}
+__device__ __forceinline__ float det_expf(float x) { return (float)det_exp((double)x); }
+
+__device__ __forceinline__ double det_root5(double x) {
+  if (!(x < __builtin_inf()) || !(x > 0.0)) return x;
+  unsigned long long u = (unsigned long long)__double_as_longlong(x);
+  u = u / 5ull + 0x3325999999999999ull;
+  double y = __longlong_as_double((long long)u);
+#pragma unroll
+  for (int it = 0; it < 7; ++it) {
+    const double y2 = y * y;
+    const double y4 = y2 * y2;
+    y = (4.0 * y + x / y4) / 5.0;
+  }
+  return y;
+}
+
 template <typename S> struct Real;
 template <> struct Real<float> {
   static __device__ __forceinline__ float sqrt_(float x) { return sqrtf(x); }
-  static __device__ __forceinline__ float pow_(float x, float y) { return powf(x, y); }
   static __device__ __forceinline__ float prev_(float x) { return nextafterf(x, x - 1.0f); }
 };
 template <> struct Real<double> {
   static __device__ __forceinline__ double sqrt_(double x) { return sqrt(x); }
-  static __device__ __forceinline__ double pow_(double x, double y) { return pow(x, y); }
   static __device__ __forceinline__ double prev_(double x) { return nextafter(x, x - 1.0); }
 };
 
@@ -255,12 +301,12 @@ __device__ __forceinline__ void rhs(const KArgs &a, const double *__restrict__ p
     if (F32 && !inrange) {
       // v = torch.tensor([-80]) is int64: `p * v` is float32 and exp runs in fp32 (train-d1.py:169-178)
       const float vf = (float)a.v_oob;
-      const float a1 = (float)p[0] * expf((float)p[1] * vf);
-      const float b1 = (float)p[2] * expf((float)(-p[3]) * vf);
-      const float bh = (float)p[4] * expf((float)p[5] * vf);
-      const float ah = (float)p[6] * expf((float)(-p[7]) * vf);
-      const float a2 = (float)p[8] * expf((float)p[9] * vf);
-      const float b2 = (float)p[10] * expf((float)(-p[11]) * vf);
+      const float a1 = (float)p[0] * det_expf((float)p[1] * vf);
+      const float b1 = (float)p[2] * det_expf((float)(-p[3]) * vf);
+      const float bh = (float)p[4] * det_expf((float)p[5] * vf);
+      const float ah = (float)p[6] * det_expf((float)(-p[7]) * vf);
+      const float a2 = (float)p[8] * det_expf((float)p[9] * vf);
+      const float b2 = (float)p[10] * det_expf((float)(-p[11]) * vf);
       const float c1 = y[0], c2 = y[1], i_ = y[2], ic1 = y[3], ic2 = y[4], o = y[5];
       f[0] = a1 * c2 + ah * ic1 + b2 * o - (b1 + bh + a2) * c1;
       f[1] = b1 * c1 + ah * ic2 - (a1 + bh) * c2;
@@ -270,12 +316,12 @@ __device__ __forceinline__ void rhs(const KArgs &a, const double *__restrict__ p
       f[5] = a2 * c1 + ah * i_ - (b2 + bh) * o;
       return;
     }
-    const double a1 = p[0] * exp(p[1] * v);
-    const double b1 = p[2] * exp(-p[3] * v);
-    const double bh = p[4] * exp(p[5] * v);
-    const double ah = p[6] * exp(-p[7] * v);
-    const double a2 = p[8] * exp(p[9] * v);
-    const double b2 = p[10] * exp(-p[11] * v);
+    const double a1 = p[0] * det_exp(p[1] * v);
+    const double b1 = p[2] * det_exp(-p[3] * v);
+    const double bh = p[4] * det_exp(p[5] * v);
+    const double ah = p[6] * det_exp(-p[7] * v);
+    const double a2 = p[8] * det_exp(p[9] * v);
+    const double b2 = p[10] * det_exp(-p[11] * v);
     const double c1 = y[0], c2 = y[1], i_ = y[2], ic1 = y[3], ic2 = y[4], o = y[5];
     f[0] = (S)(a1 * c2 + ah * ic1 + b2 * o - (b1 + bh + a2) * c1);
     f[1] = (S)(b1 * c1 + ah * ic2 - (a1 + bh) * c2);
@@ -300,13 +346,13 @@ __device__ __forceinline__ void rhs(const KArgs &a, const double *__restrict__ p
     if (oob32) {
       const float vf = (float)a.v_oob;
       const float af = (float)av, rf = (float)rv;
-      const float k3 = (float)p[4] * expf((float)p[5] * vf);
-      const float k4 = (float)p[6] * expf((float)(-p[7]) * vf);
+      const float k3 = (float)p[4] * det_expf((float)p[5] * vf);
+      const float k4 = (float)p[6] * det_expf((float)(-p[7]) * vf);
       const float drdt = -k3 * rf + k4 * (1.0f - rf);
       float dadt = 0.0f;
       if constexpr (HAS_HH_A) {
-        const float k1 = (float)p[0] * expf((float)p[1] * vf);
-        const float k2 = (float)p[2] * expf((float)(-p[3]) * vf);
+        const float k1 = (float)p[0] * det_expf((float)p[1] * vf);
+        const float k2 = (float)p[2] * det_expf((float)(-p[3]) * vf);
         dadt = k1 * (1.0f - af) - k2 * af;
       }
       if constexpr (MT::MLP) dadt = (MODEL == IONODE_MODEL_NND) ? dadt + net : net;
@@ -316,13 +362,13 @@ __device__ __forceinline__ void rhs(const KArgs &a, const double *__restrict__ p
     }
     const S one_m_a = (S)1 - av;  // `1. - a` / `self.unity - r` are formed in y.dtype
     const S one_m_r = (S)1 - rv;
-    const double k3 = p[4] * exp(p[5] * v);
-    const double k4 = p[6] * exp(-p[7] * v);
+    const double k3 = p[4] * det_exp(p[5] * v);
+    const double k4 = p[6] * det_exp(-p[7] * v);
     const double drdt = -k3 * (double)rv + k4 * (double)one_m_r;
     double dadt = 0.0;
     if constexpr (HAS_HH_A) {
-      const double k1 = p[0] * exp(p[1] * v);
-      const double k2 = p[2] * exp(-p[3] * v);
+      const double k1 = p[0] * det_exp(p[1] * v);
+      const double k2 = p[2] * det_exp(-p[3] * v);
       dadt = k1 * (double)one_m_a - k2 * (double)av;
     }
     if constexpr (MT::MLP) dadt = (MODEL == IONODE_MODEL_NND) ? dadt + (double)net : (double)net;
@@ -428,7 +474,7 @@ __global__ void __launch_bounds__(64 * G) ionode_dopri5_kernel(const KArgs a) {
       const S c = h0 * (S)1e-3;
       h1 = (S)1e-6 > c ? (S)1e-6 : c;
     } else {
-      h1 = R::pow_((S)0.01 / (d1 > d2 ? d1 : d2), (S)(1.0 / 5.0));
+      h1 = (S)det_root5((double)((S)0.01 / (d1 > d2 ? d1 : d2)));
     }
     const S h = ((S)100 * h0 < h1) ? (S)100 * h0 : h1;
     dt = (double)h;
@@ -534,7 +580,7 @@ __global__ void __launch_bounds__(64 * G) ionode_dopri5_kernel(const KArgs a) {
     else {
       const double dfactor = (ratio < (S)1) ? 1.0 : 0.2;
       const double er = (double)ratio;
-      double fac = 0.9 / pow(er, 0.2);
+      double fac = 0.9 / det_root5(er);
       if (!(fac > dfactor)) fac = dfactor;
       if (!(fac < 10.0)) fac = 10.0;
       if (er != er) fac = __builtin_nan("");
@@ -542,6 +588,10 @@ __global__ void __launch_bounds__(64 * G) ionode_dopri5_kernel(const KArgs a) {
     }
 
     const bool acc_now = active && accept;
+    if (a.step_log != nullptr && active && primary && traj_raw == 0 && (int64_t)nacc + nrej < a.step_log_cap) {
+      double *row = a.step_log + 4 * ((int64_t)nacc + nrej);
+      row[0] = t0; row[1] = dt; row[2] = (double)ratio; row[3] = accept ? 1.0 : 0.0;
+    }
     if (active) { if (accept) ++nacc; else ++nrej; }
 
     // ---- _interp_fit + cooperative dense output ----

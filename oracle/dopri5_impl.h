@@ -62,12 +62,12 @@ static void SFX(rhs)(const ctx_t *c, REAL t, const REAL *y, REAL *f) {
      * and exp runs in fp32; every product below is then fp32 x fp32. */
     const float vf = (float)c->v_oob;
     if (c->model == MODEL_MARKOV6) {
-      const float a1 = (float)p[0] * expf((float)p[1] * vf);
-      const float b1 = (float)p[2] * expf((float)(-p[3]) * vf);
-      const float bh = (float)p[4] * expf((float)p[5] * vf);
-      const float ah = (float)p[6] * expf((float)(-p[7]) * vf);
-      const float a2 = (float)p[8] * expf((float)p[9] * vf);
-      const float b2 = (float)p[10] * expf((float)(-p[11]) * vf);
+      const float a1 = (float)p[0] * det_expf((float)p[1] * vf);
+      const float b1 = (float)p[2] * det_expf((float)(-p[3]) * vf);
+      const float bh = (float)p[4] * det_expf((float)p[5] * vf);
+      const float ah = (float)p[6] * det_expf((float)(-p[7]) * vf);
+      const float a2 = (float)p[8] * det_expf((float)p[9] * vf);
+      const float b2 = (float)p[10] * det_expf((float)(-p[11]) * vf);
       const float c1 = y[0], c2 = y[1], i_ = y[2], ic1 = y[3], ic2 = y[4], o = y[5];
       f[0] = a1 * c2 + ah * ic1 + b2 * o - (b1 + bh + a2) * c1;
       f[1] = b1 * c1 + ah * ic2 - (a1 + bh) * c2;
@@ -78,13 +78,13 @@ static void SFX(rhs)(const ctx_t *c, REAL t, const REAL *y, REAL *f) {
       return;
     }
     const float a = y[0], r = y[1];
-    const float k3 = (float)p[4] * expf((float)p[5] * vf);
-    const float k4 = (float)p[6] * expf((float)(-p[7]) * vf);
+    const float k3 = (float)p[4] * det_expf((float)p[5] * vf);
+    const float k4 = (float)p[6] * det_expf((float)(-p[7]) * vf);
     const float drdt = -k3 * r + k4 * (1.0f - r);
     float dadt = 0.0f;
     if (c->model == MODEL_HH2 || c->model == MODEL_NND) {
-      const float k1 = (float)p[0] * expf((float)p[1] * vf);
-      const float k2 = (float)p[2] * expf((float)(-p[3]) * vf);
+      const float k1 = (float)p[0] * det_expf((float)p[1] * vf);
+      const float k2 = (float)p[2] * det_expf((float)(-p[3]) * vf);
       dadt = k1 * (1.0f - a) - k2 * a;
     }
     if (c->model == MODEL_NNF || c->model == MODEL_NND) {
@@ -102,12 +102,12 @@ static void SFX(rhs)(const ctx_t *c, REAL t, const REAL *y, REAL *f) {
 
   if (c->model == MODEL_MARKOV6) {
     /* train-d1.py:173-185; rates are fp64 (1,) tensors, states 0-dim y.dtype tensors */
-    const double a1 = p[0] * exp(p[1] * v);
-    const double b1 = p[2] * exp(-p[3] * v);
-    const double bh = p[4] * exp(p[5] * v);
-    const double ah = p[6] * exp(-p[7] * v);
-    const double a2 = p[8] * exp(p[9] * v);
-    const double b2 = p[10] * exp(-p[11] * v);
+    const double a1 = p[0] * det_exp(p[1] * v);
+    const double b1 = p[2] * det_exp(-p[3] * v);
+    const double bh = p[4] * det_exp(p[5] * v);
+    const double ah = p[6] * det_exp(-p[7] * v);
+    const double a2 = p[8] * det_exp(p[9] * v);
+    const double b2 = p[10] * det_exp(-p[11] * v);
     const double c1 = y[0], c2 = y[1], i_ = y[2], ic1 = y[3], ic2 = y[4], o = y[5];
     f[0] = (REAL)(a1 * c2 + ah * ic1 + b2 * o - (b1 + bh + a2) * c1);
     f[1] = (REAL)(b1 * c1 + ah * ic2 - (a1 + bh) * c2);
@@ -122,13 +122,13 @@ static void SFX(rhs)(const ctx_t *c, REAL t, const REAL *y, REAL *f) {
   /* `1. - a`, `self.unity - r`: computed in y.dtype before meeting the fp64 rate */
   const REAL one_m_a = (REAL)1 - a;
   const REAL one_m_r = (REAL)1 - r;
-  const double k3 = p[4] * exp(p[5] * v);
-  const double k4 = p[6] * exp(-p[7] * v);
+  const double k3 = p[4] * det_exp(p[5] * v);
+  const double k4 = p[6] * det_exp(-p[7] * v);
   const double drdt = -k3 * (double)r + k4 * (double)one_m_r;
   double dadt = 0.0;
   if (c->model == MODEL_HH2 || c->model == MODEL_NND) {
-    const double k1 = p[0] * exp(p[1] * v);
-    const double k2 = p[2] * exp(-p[3] * v);
+    const double k1 = p[0] * det_exp(p[1] * v);
+    const double k2 = p[2] * det_exp(-p[3] * v);
     dadt = k1 * (double)one_m_a - k2 * (double)a;
   }
   if (c->model == MODEL_NNF || c->model == MODEL_NND) {
@@ -168,7 +168,7 @@ static double SFX(select_initial_step)(const ctx_t *c, double t0d, const REAL *y
   const REAL d2 = SFX(rms)(tmp, D) / h0;
   REAL h1;
   if (d1 <= (REAL)1e-15 && d2 <= (REAL)1e-15) h1 = SFX(r_max)((REAL)1e-6, h0 * (REAL)1e-3);
-  else h1 = R_POW((REAL)0.01 / (d1 > d2 ? d1 : d2), (REAL)(1.0 / 5.0)); /* order + 1 = 5 */
+  else h1 = (REAL)det_root5((double)((REAL)0.01 / (d1 > d2 ? d1 : d2))); /* ** (1 / (order + 1)) */
   const REAL h = ((REAL)100 * h0 < h1) ? (REAL)100 * h0 : h1;
   return (double)h;
 }
@@ -182,7 +182,7 @@ static inline REAL SFX(kdot)(const REAL k[MAXD][7], int d, const REAL *bd, int n
 
 /* one _adaptive_step; returns 0 ok, else status code */
 static int SFX(adaptive_step)(const ctx_t *c, SFX(rkstate) *s, REAL rtol, REAL atol, int64_t *nfe,
-                              int *accepted) {
+                              int *accepted, double *ratio_out) {
   const int D = c->D;
   const double t0 = s->t1, dt = s->dt;
   const double t1 = t0 + dt;
@@ -218,6 +218,7 @@ static int SFX(adaptive_step)(const ctx_t *c, SFX(rkstate) *s, REAL rtol, REAL a
   const REAL ratio = SFX(r_abs)(SFX(rms)(tmp, D));
   const int acc = ratio <= (REAL)1;
   *accepted = acc;
+  *ratio_out = (double)ratio;
 
   /* _optimal_step_size, fp64 */
   double dt_next;
@@ -225,7 +226,7 @@ static int SFX(adaptive_step)(const ctx_t *c, SFX(rkstate) *s, REAL rtol, REAL a
   else {
     const double dfactor = (ratio < (REAL)1) ? 1.0 : 0.2;
     const double er = (double)ratio;
-    double fac = 0.9 / pow(er, 0.2);
+    double fac = 0.9 / det_root5(er);
     if (!(fac > dfactor)) fac = dfactor; /* torch.max(x, dfactor) */
     if (!(fac < 10.0)) fac = 10.0;       /* torch.min(ifactor, .) */
     if (isnan(er)) fac = NAN;
@@ -282,11 +283,12 @@ static int SFX(solve)(const ctx_t *c, const double *y0d, const double *t_eval, i
       if (nacc + nrej >= max_steps) { status = STATUS_MAX_STEPS; break; }
       int acc = 0;
       const double t_before = s.t1, dt_before = s.dt;
-      status = SFX(adaptive_step)(c, &s, rtol, atol, &nfe, &acc);
+      double ratio_d = 0.0;
+      status = SFX(adaptive_step)(c, &s, rtol, atol, &nfe, &acc, &ratio_d);
       if (status != STATUS_OK) break;
       if (step_log && nacc + nrej < step_log_cap) {
-        double *row = step_log + 3 * (nacc + nrej);
-        row[0] = t_before; row[1] = dt_before; row[2] = (double)acc;
+        double *row = step_log + 4 * (nacc + nrej);
+        row[0] = t_before; row[1] = dt_before; row[2] = ratio_d; row[3] = (double)acc;
       }
       if (acc) ++nacc; else ++nrej;
     }

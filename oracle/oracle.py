@@ -81,7 +81,7 @@ def solve(model, params, prot_v, y0, t_eval, *, weights=None, mlp_layers=0, mlp_
     y = np.empty((B, Nt, D), dtype=np.float64)
     status = np.zeros(B, dtype=np.int32)
     stats = np.zeros((B, 4), dtype=np.int64)
-    slog = np.zeros((step_log_cap, 3), dtype=np.float64) if step_log_cap else None
+    slog = np.zeros((step_log_cap, 4), dtype=np.float64) if step_log_cap else None
     rc = lib().oracle_dopri5_batch(C.byref(d), _p(weights), _p(params), _p(prot_v), _p(prot_t), _p(prot_of_traj),
                                    _p(y0), _p(t_eval), _p(y), _p(status), _p(stats), _p(slog),
                                    C.c_int64(step_log_cap), C.c_int(nthreads))
