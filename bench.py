@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Headline benchmark: trajectories/s of the batched dopri5 + NN-f (arch s00) solve on MI355X.
+
+Workload (BASELINE.json configs[1]): NN-f, architecture s00 (5 x 200 hidden, the reference's trained s1
+weights from tests/golden), B = 4096 trajectories per GPU, each on its own synthetic sine-wave protocol
+(0.1 ms sampling, 10 s => N_p = N_t = 100 001, "100k steps"), fp64 solver state, rtol 1e-7 / atol 1e-9,
+y0 = [0, 1].  A "step" = one solve of the whole batch (one kernel launch) + the fused current-trace
+epilogue + the loss reduction; with N > 1 GPUs every rank solves its own B trajectories (weak scaling,
+no data-path collective) and the scalar loss is all-reduced over RCCL.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--nt NT] [--no-cpu-baseline]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# MI355X peaks, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_FP32_TFLOPS = 157.3  # fp32 MFMA (v_mfma_f32_16x16x4_f32) == fp32 vector peak
+PEAK_HBM_GBS = 8000.0
+
+P_HH = np.array([1.12592345582957387e-01, 8.26751134920666146e+01, 3.38768033864048357e-02,
+                 4.67106147665183542e+01, 8.47769667061995875e+01, 2.04001345352499328e+01,
+                 1.02860743916105211e+01, 2.78201179336874098e+01]) * 1e-3  # train-s1.py:139-146 / :211-214
+MLP_L, MLP_N = 5, 200  # architectures/s00.py
+F_MLP = 2 * (MLP_L * MLP_N * MLP_N + 3 * MLP_N)  # 401 200 FLOP per RHS evaluation
+F_RHS_OTHER = 150  # HH rate terms + RK stage combination per evaluation
+
+
+def load_weights():
+    p = os.path.join(ROOT, "tests", "golden", "weights_s1.f32")
+    if os.path.exists(p):
+        return np.fromfile(p, dtype="<f4"), "reference s1 state dict (tests/golden)"
+    rng = np.random.default_rng(0)  # nn.init.normal_(std=0.1), zero bias: train-s1.py:202-205
+    n = 2 * MLP_N + MLP_N + MLP_L * (MLP_N * MLP_N + MLP_N) + MLP_N + 1
+    w = rng.normal(0, 0.1, n).astype(np.float32)
+    return w, "random init N(0, 0.1^2)"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=4096, help="trajectories per GPU")
+    ap.add_argument("--nt", type=int, default=100001, help="protocol samples = output samples")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="trajectories timed on the host (0 = auto)")
+    ap.add_argument("--tile-waves", type=int, default=0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the integrator has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+
+    ion = importlib.import_module("neural-ode-ion-channels_amd")
+    capi, protocols = ion.capi, importlib.import_module("neural-ode-ion-channels_amd.protocols")
+
+    B, Nt = args.batch, args.nt
+    weights, wsrc = load_weights()
+    packed = torch.from_numpy(capi.mlp_pack(weights, MLP_L, MLP_N)).to(dev)
+    first = rank * B  # global trajectory index of this rank's shard
+    prot_v = protocols.sinewave(protocols.sinewave_scales(first, B), n_samples=Nt, dt=0.1, xp=torch, device=dev)
+    params = torch.from_numpy(np.tile(P_HH, (B, 1))).to(dev)
+    y0 = torch.tensor([[0.0, 1.0]], dtype=torch.float64, device=dev).repeat(B, 1).contiguous()
+    t_eval = torch.arange(Nt, dtype=torch.float64, device=dev) * 0.1
+    i_ref = torch.zeros((B, Nt), dtype=torch.float64, device=dev)  # synthetic "data" current
+    out = {}
+
+    def step():
+        r = capi.dopri5(capi.MODEL_NNF, params, prot_v, y0, t_eval, mlp_packed=packed, mlp_layers=MLP_L,
+                        mlp_width=MLP_N, prot_t0=0.0, prot_dt=0.1, current=True, obs_g=1.0, obs_e=-86.0,
+                        tile_waves=args.tile_waves, out=out)
+        out.update({k: r[k] for k in ("y", "i", "status", "stats")})
+        part = torch.stack([(r["i"] - i_ref).abs().sum(), torch.tensor(float(B * Nt), dtype=torch.float64, device=dev)])
+        if dist is not None:
+            dist.all_reduce(part)  # the path's only collective: 16 bytes
+        return r, part[0] / part[1]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()  # same stream as the kernel launch (torch's current stream)
+        r = capi.dopri5(capi.MODEL_NNF, params, prot_v, y0, t_eval, mlp_packed=packed, mlp_layers=MLP_L,
+                        mlp_width=MLP_N, prot_t0=0.0, prot_dt=0.1, current=True, obs_g=1.0, obs_e=-86.0,
+                        tile_waves=args.tile_waves, out=out)
+        ev[k][1].record()
+        part = torch.stack([(r["i"] - i_ref).abs().sum(), torch.tensor(float(B * Nt), dtype=torch.float64, device=dev)])
+        if dist is not None:
+            dist.all_reduce(part)
+        loss = part[0] / part[1]
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    stats = r["stats"].cpu().numpy()
+    status = r["status"].cpu().numpy()
+    nfe = stats[:, 2].astype(np.float64)
+    n_ok = int((status == 0).sum())
+    value = world * B * args.steps / elapsed
+
+    # algorithmic work of ONE launch: FLOPs = sum_traj NFE * (F_mlp + ~150);
+    # bytes = N_p*8 (protocol) + N_t*D*8 (states) + N_t*8 (current trace) per trajectory + weights once
+    flops = float(nfe.sum()) * (F_MLP + F_RHS_OTHER)
+    bytes_traj = Nt * 8 + Nt * 2 * 8 + Nt * 8 + 2 * 8 + 64
+    bytes_launch = B * bytes_traj + weights.size * 4
+    tflops = flops / (kern_ms * 1e-3) / 1e12
+    gbs = bytes_launch / (kern_ms * 1e-3) / 1e9
+
+    res = {
+        "metric": "trajectories/sec (sinewave protocol, 100k steps)",
+        "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": f"synthetic sinewave protocols; {wsrc}",
+        "config": {"workload": "configs[1]: NN-f (arch s00) batched synthetic sinewave trajectories, fp64 state, "
+                               "N_p = N_t = %d, rtol 1e-7 atol 1e-9" % Nt,
+                   "trajectories_per_gpu": B, "global_batch": world * B, "parallelism": f"traj-shard x{world}",
+                   "kernel": capi.kernel_name(r["desc"]), "geometry": capi.launch_geometry(r["desc"]),
+                   "mean_nfe": float(nfe.mean()), "mean_accepted": float(stats[:, 0].mean()),
+                   "mean_rejected": float(stats[:, 1].mean()), "trajectories_ok": n_ok, "loss": float(loss.item())},
+        "roofline": {"bound": "mfma", "achieved": tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                     "frac": tflops / PEAK_FP32_TFLOPS, "traffic": None,
+                     "kernel_ms": kern_ms, "flop_per_launch": flops,
+                     "note": "s00 is fp32-FMA bound (SURVEY.md finding 5): 401 200 FLOP per RHS evaluation on the "
+                             "fp32 MFMA (dense peak = fp32 vector peak 157.3 TFLOP/s)"},
+        "roofline_hbm": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": gbs / PEAK_HBM_GBS, "bytes_per_trajectory": bytes_traj},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(prot_v, weights, Nt, args.cpu_sample, out)
+    if rank == 0:
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(prot_v, weights, Nt, n_sample, gpu_out):
+    """The CPU oracle (a port of the reference path, oracle/) on the first trajectories of the same workload,
+    all host cores (OpenMP over trajectories).  Also used as a live parity check of the benchmark run."""
+    from oracle import oracle
+    oracle.build()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    n = n_sample or max(cores, 8)
+    pv = prot_v[:n].cpu().numpy()
+    te = np.arange(Nt, dtype=np.float64) * 0.1
+    t0 = time.perf_counter()
+    o = oracle.solve(oracle.MODEL_NNF, np.tile(P_HH, (n, 1)), pv, [0.0, 1.0], te, weights=weights,
+                     mlp_layers=MLP_L, mlp_width=MLP_N, prot_t0=0.0, prot_dt=0.1, nthreads=cores)
+    dt = time.perf_counter() - t0
+    g = gpu_out["y"][:n].cpu().numpy()
+    err = float(np.linalg.norm(g - o["y"]) / np.linalg.norm(o["y"]))
+    return {"value": n / dt, "unit": "trajectories/s", "cores": cores, "kind": "port",
+            "sample": f"first {n} trajectories of the same batch, oracle/liboracle.so (C, AVX2 fp32 fmaf chain), "
+                      f"{dt:.1f} s wall", "rel_l2_gpu_vs_oracle": err}
+
+
+if __name__ == "__main__":
+    main()

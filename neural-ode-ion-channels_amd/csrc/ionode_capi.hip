@@ -22,7 +22,8 @@ struct Plan {
   size_t lds = 0;
 };
 
-const ionode::Variant *find_variant(int model, int f32, int G, int RT) {
+// NT < 0: any.  Closed-form kernels are registered with NT == 0.
+const ionode::Variant *find_variant(int model, int f32, int G, int NT) {
   using namespace ionode;
   typedef const Variant *(*TabFn)(int *);
   static const TabFn tabs[] = {variants_closed, variants_nnf_f64, variants_nnf_f32, variants_nnd_f64, variants_nnd_f32};
@@ -30,7 +31,7 @@ const ionode::Variant *find_variant(int model, int f32, int G, int RT) {
     int n = 0;
     const Variant *t = tf(&n);
     for (int i = 0; i < n; ++i)
-      if (t[i].model == model && t[i].f32 == f32 && t[i].G == G && t[i].RT == RT) return &t[i];
+      if (t[i].model == model && t[i].f32 == f32 && (G == 0 || t[i].G == G) && t[i].NT == NT) return &t[i];
   }
   return nullptr;
 }
@@ -46,26 +47,23 @@ int make_plan(const ionode_desc *d, Plan *pl) {
   if (!(d->rtol > 0) || !(d->atol >= 0) || !(d->prot_dt > 0)) { set_err("rtol/atol/prot_dt must be positive"); return IONODE_ERR_ARG; }
   const int f32 = d->state_f32 ? 1 : 0;
   if (!mlp) {
-    pl->v = find_variant(d->model, f32, 1, 1);
+    pl->v = find_variant(d->model, f32, 1, 0);
     pl->grid = (unsigned)((d->n_traj + 63) / 64);
     pl->block = 64;
     pl->lds = 0;
   } else {
     if (d->mlp_width < 1 || d->mlp_layers < 0) { set_err("bad MLP shape"); return IONODE_ERR_ARG; }
     const int NP = np_of(d->mlp_width), NT = NP / 16;
-    int G = d->tile_waves;
-    if (G == 0) G = (NT == 1) ? 1 : 4;
-    if (G != 1 && G != 4) { set_err("tile_waves must be 0, 1 or 4"); return IONODE_ERR_UNSUPPORTED; }
-    const int need = (NT + G - 1) / G;
-    int RT = 0;
-    for (int c : {1, 2, 4, 8}) {
-      if (c >= need && find_variant(d->model, f32, G, c)) { RT = c; break; }
+    if (d->tile_waves != 0 && d->tile_waves != 1 && d->tile_waves != 4) { set_err("tile_waves must be 0, 1 or 4"); return IONODE_ERR_UNSUPPORTED; }
+    pl->v = find_variant(d->model, f32, d->tile_waves, NT);
+    if (!pl->v) {
+      set_err("MLP width outside the compiled kernel variants: N must pad to 16, 112, 208 or 512 "
+              "(architectures s00-s11: N = 10, 100, 200, 500)");
+      return IONODE_ERR_UNSUPPORTED;
     }
-    if (!RT) { set_err("MLP width outside the compiled kernel variants (N <= 512 with 4 waves, N <= 16 with 1)"); return IONODE_ERR_UNSUPPORTED; }
-    pl->v = find_variant(d->model, f32, G, RT);
     pl->grid = (unsigned)((d->n_traj + 15) / 16);
-    pl->block = 64u * G;
-    pl->lds = ((size_t)2 * NT * 64 + NP) * 16;
+    pl->block = 64u * pl->v->G;
+    pl->lds = ((size_t)2 * NT * 64 + NP) * 16 + ((size_t)d->mlp_layers * NP + NP + 4) * 4;
   }
   if (!pl->v) { set_err("no kernel variant compiled for this descriptor"); return IONODE_ERR_UNSUPPORTED; }
   return IONODE_OK;
@@ -82,7 +80,7 @@ const char *ionode_last_error(void) { return g_err; }
 size_t ionode_mlp_packed_floats(int32_t L, int32_t N) {
   if (L < 0 || N < 1) return 0;
   const size_t NP = (size_t)np_of(N);
-  return 4 * NP + (size_t)L * (NP * NP + NP) + NP + 4;
+  return 4 * NP + (size_t)L * (NP * NP + NP) + NP + 4 + 256;  // + a 1 KiB zero block (dummy row tiles)
 }
 
 int ionode_mlp_pack(const float *w, int32_t L, int32_t N, float *out) {

@@ -28,6 +28,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/ionode.h"
 
 namespace ionode {
@@ -185,117 +187,170 @@ __device__ __forceinline__ bool protocol_v(const KArgs &a, const double *__restr
 __device__ __forceinline__ float lrelu(float x) { return x > 0.0f ? x : x * 0.01f; }
 
 // ---------------------------------------------------------------------------------------------
-// Stage MLP of one 16-trajectory tile on the fp32 MFMA.  Called by all G wavefronts of the
-// workgroup in uniform control flow.  Returns net([x0, x1]) for the lane's trajectory.
-//   image layout (ionode_mlp_pack):  [NP][4] {b0,w00,w01,0} | L x { A[rt][kt][lane][4], bias[NP] } | wl[NP], bl
-//   canonical order: acc = bias; for kt: for r: for q: acc = fmaf(W[row][16kt+4q+r], h[16kt+4q+r], acc)
+// Stage MLP of one 16-trajectory tile on the fp32 MFMA.  All G wavefronts of the workgroup call
+// eval() together in uniform control flow; it returns net([x0, x1]) for the lane's trajectory.
+//
+//   image (ionode_mlp_pack):  [NP][4] {b0,w00,w01,0} | L x { A[rt][kt][lane][4], bias[NP] } | wl[NP], bl
+//   canonical order          hidden: acc = bias; for kt: for r: for q: acc = fmaf(W[row][k], h[k], acc), k = 16kt+4q+r
+//                            last:   part_q = 0; for kt: for r: part_q = fmaf(wl[k], h[k], part_q);
+//                                    out = ((part_0 + part_1) + (part_2 + part_3)) + bl
+//
+// Weight streaming: the A fragments of the hidden layers are the only global traffic of the MLP.
+// They are consumed from a register ring that is refilled PD k-tiles ahead (PD == NT: a whole layer
+// ahead), so an L2 round trip (~1-2 us under load) hides behind >= PD*RT*4 MFMAs instead of stalling
+// every k-tile.  With L == 1 and PD == NT the layer simply stays resident in registers.
+// Small vectors (layer-0 rows, biases, last-layer weights) live in LDS for the kernel's lifetime.
 // ---------------------------------------------------------------------------------------------
-template <int G, int RT>
-__device__ __forceinline__ float mlp_tile_eval(const KArgs &a, float x0, float x1, f32x4 *__restrict__ Hs,
-                                               const f32x4 *__restrict__ W0s, int wave, int lane) {
-  const int NP = a.NP, NT = a.NT, L = a.L;
-  const int q = lane >> 4;
-  const int tstride = NT * 64;
+template <int G, int RT, int NT, int PD>
+struct MlpTile {
+  static_assert(NT % PD == 0, "ring depth must divide the k-tile count");
+  static constexpr int NP = 16 * NT;
+  f32x4 ring[PD][RT];
+  f32x4 *Hs;          // LDS [2][NT*64] activations, accumulator layout
+  const f32x4 *W0s;   // LDS [NP] {b0, w00, w01, 0}
+  const float *biasS; // LDS [L][NP]
+  const float *wlS;   // LDS [NP] + bl
+  const f32x4 *Aimg;  // global: hidden-layer fragments, + lane
+  size_t lstride4;    // f32x4 per hidden layer in the image
+  // Every wavefront runs RT row tiles so the MFMA stream is branch-free; a tile index past NT (13 = 4+3+3+3)
+  // streams the image's 1 KiB zero block instead and its result is never stored.
+  size_t toff[RT];    // f32x4 offset of row tile i inside a layer (fragment kt = 0), or of the zero block
+  size_t tkt[RT];     // f32x4 stride per k-tile: 64, or 0 for the zero block
+  int L, wave, lane, nrt;
 
-  // layer 0: Linear(2, N) + LeakyReLU on the VALU, written in accumulator layout
-#pragma unroll
-  for (int i = 0; i < RT; ++i) {
-    const int rt = wave + i * G;
-    if (rt < NT) {
-      f32x4 h;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const f32x4 w = W0s[16 * rt + 4 * q + r];
-        h[r] = lrelu(fmaf(w[2], x1, fmaf(w[1], x0, w[0])));
-      }
-      Hs[rt * 64 + lane] = h;
-    }
+  static __host__ __device__ constexpr size_t lds_bytes(int L) {
+    return ((size_t)2 * NT * 64 + NP) * 16 + ((size_t)L * NP + NP + 4) * 4;
   }
-  if (G > 1) __syncthreads();
 
-  const size_t lstride = (size_t)NP * NP + NP;
-  for (int l = 0; l < L; ++l) {
-    const f32x4 *__restrict__ Hin = Hs + (l & 1) * tstride;
-    f32x4 *__restrict__ Hout = Hs + ((l + 1) & 1) * tstride;
-    const float *__restrict__ Wl = a.mlp + 4 * (size_t)NP + (size_t)l * lstride;
-    const float *__restrict__ bias = Wl + (size_t)NP * NP;
-    const f32x4 *__restrict__ Ap = reinterpret_cast<const f32x4 *>(Wl) + lane;
-
-    f32x4 acc[RT], a_nxt[RT];
+  __device__ __forceinline__ void init(const KArgs &a, unsigned char *smem, int wave_, int lane_) {
+    L = a.L; wave = wave_; lane = lane_;
+    nrt = (NT - wave + G - 1) / G;  // row tiles owned by this wavefront: rt = wave + i*G
+    Hs = reinterpret_cast<f32x4 *>(smem);
+    f32x4 *w0 = Hs + 2 * NT * 64;
+    float *bs = reinterpret_cast<float *>(w0 + NP);
+    float *ws = bs + (size_t)L * NP;
+    const size_t lstride = (size_t)NP * NP + NP;
+    const int tid = wave * 64 + lane;
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(a.mlp);
+    for (int i = tid; i < NP; i += 64 * G) w0[i] = src[i];
+    for (int i = tid; i < L * NP; i += 64 * G) bs[i] = a.mlp[4 * (size_t)NP + (size_t)(i / NP) * lstride + (size_t)NP * NP + (i % NP)];
+    const float *wl = a.mlp + 4 * (size_t)NP + (size_t)L * lstride;
+    for (int i = tid; i < NP + 4; i += 64 * G) ws[i] = wl[i];
+    W0s = w0; biasS = bs; wlS = ws;
+    Aimg = reinterpret_cast<const f32x4 *>(a.mlp + 4 * (size_t)NP) + lane;
+    lstride4 = lstride / 4;
+    const size_t zero4 = ((size_t)L * lstride + NP + 4) / 4;  // the zero block follows wl/bl
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
-      const int rt = wave + i * G;
-      if (rt < NT) {
-        acc[i] = *reinterpret_cast<const f32x4 *>(bias + 16 * rt + 4 * q);
-        a_nxt[i] = Ap[(size_t)(rt * NT) * 64];
-      } else {
-        acc[i] = f32x4{0, 0, 0, 0};
-        a_nxt[i] = f32x4{0, 0, 0, 0};
-      }
+      const bool real = i < nrt;
+      toff[i] = real ? (size_t)((wave + i * G) * NT) * 64 : zero4;
+      tkt[i] = real ? 64 : 0;
     }
-    for (int kt = 0; kt < NT; ++kt) {
-      f32x4 a_cur[RT];
+    // prime the ring with the first PD k-tiles of hidden layer 0
 #pragma unroll
-      for (int i = 0; i < RT; ++i) a_cur[i] = a_nxt[i];
-      if (kt + 1 < NT) {
+    for (int u = 0; u < PD; ++u)
 #pragma unroll
-        for (int i = 0; i < RT; ++i) {
-          const int rt = wave + i * G;
-          if (rt < NT) a_nxt[i] = Ap[(size_t)(rt * NT + kt + 1) * 64];
-        }
-      }
-      const f32x4 b = Hin[kt * 64 + lane];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int i = 0; i < RT; ++i) {
-          const int rt = wave + i * G;
-          if (rt < NT) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[i][r], b[r], acc[i], 0, 0, 0);
-        }
-      }
-    }
+      for (int i = 0; i < RT; ++i) ring[u][i] = Aimg[toff[i] + tkt[i] * u];
+    __syncthreads();
+  }
+
+  __device__ __forceinline__ float eval(float x0, float x1) {
+    const int q = lane >> 4;
+    constexpr int tstride = NT * 64;
+
+    // layer 0: Linear(2, N) + LeakyReLU on the VALU, written in accumulator layout
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
-      const int rt = wave + i * G;
-      if (rt < NT) {
+      if (i < nrt) {
+        const int rt = wave + i * G;
         f32x4 h;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) h[r] = lrelu(acc[i][r]);
-        Hout[rt * 64 + lane] = h;
+        for (int r = 0; r < 4; ++r) {
+          const f32x4 w = W0s[16 * rt + 4 * q + r];
+          h[r] = lrelu(fmaf(w[2], x1, fmaf(w[1], x0, w[0])));
+        }
+        Hs[rt * 64 + lane] = h;
       }
     }
     if (G > 1) __syncthreads();
-  }
 
-  // Linear(N, 1): one MFMA row tile whose only non-zero row is row 0 (lanes with lane&15 == 0
-  // carry the weights); every wavefront computes it redundantly from the shared activations.
-  const f32x4 *__restrict__ Hin = Hs + (L & 1) * tstride;
-  const float *__restrict__ wl = a.mlp + 4 * (size_t)NP + (size_t)L * lstride;
-  const bool row0 = (lane & 15) == 0;
-  f32x4 acc = {0, 0, 0, 0};
-  acc[0] = (q == 0) ? wl[NP] : 0.0f;
-  for (int kt = 0; kt < NT; ++kt) {
-    f32x4 w = *reinterpret_cast<const f32x4 *>(wl + 16 * kt + 4 * q);
-    if (!row0) w = f32x4{0, 0, 0, 0};
-    const f32x4 b = Hin[kt * 64 + lane];
+    for (int l = 0; l < L; ++l) {
+      const f32x4 *__restrict__ Hin = Hs + (l & 1) * tstride;
+      f32x4 *__restrict__ Hout = Hs + ((l + 1) & 1) * tstride;
+      const int ln = (l + 1 < L) ? l + 1 : 0;  // the ring runs cyclically over the hidden stack
+      const bool resident = (PD == NT) && (L == 1);
+      // zero-block tiles must not move with the layer: their layer stride is 0 too
+      const size_t lcur = (size_t)l * lstride4, lnext = (size_t)ln * lstride4;
+
+      f32x4 acc[RT];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], b[r], acc, 0, 0, 0);
+      for (int i = 0; i < RT; ++i) {
+        const int rt = (i < nrt) ? wave + i * G : 0;  // dummy tiles read a valid bias row; result discarded
+        acc[i] = *reinterpret_cast<const f32x4 *>(biasS + l * NP + 16 * rt + 4 * q);
+      }
+      for (int kt0 = 0; kt0 < NT; kt0 += PD) {
+        const bool same_layer = kt0 + PD < NT;
+        const size_t lref = same_layer ? lcur : lnext;
+        const int ktref = same_layer ? kt0 + PD : 0;
+#pragma unroll
+        for (int u = 0; u < PD; ++u) {
+          const f32x4 b = Hin[(kt0 + u) * 64 + lane];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+              acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[u][i][r], b[r], acc[i], 0, 0, 0);
+          }
+          if (!resident) {
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+              ring[u][i] = Aimg[(tkt[i] ? lref : 0) + toff[i] + tkt[i] * (ktref + u)];
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        if (i < nrt) {
+          f32x4 h;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h[r] = lrelu(acc[i][r]);
+          Hout[(wave + i * G) * 64 + lane] = h;
+        }
+      }
+      if (G > 1) __syncthreads();
+    }
+
+    // Linear(N, 1) on the VALU: four partial fmaf chains (one per lane group q), fixed combine tree
+    const f32x4 *__restrict__ Hin = Hs + (L & 1) * tstride;
+    float part = 0.0f;
+#pragma unroll 4
+    for (int kt = 0; kt < NT; ++kt) {
+      const f32x4 w = *reinterpret_cast<const f32x4 *>(wlS + 16 * kt + 4 * q);
+      const f32x4 h = Hin[kt * 64 + lane];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part = fmaf(w[r], h[r], part);
+    }
+    const float pair = part + __shfl_xor(part, 16);   // (p0 + p1) or (p2 + p3)
+    const float out = (pair + __shfl_xor(pair, 32)) + wlS[NP];
+    if (G > 1 && (L & 1) == 0) __syncthreads();  // next evaluation's layer 0 rewrites buffer 0
+    return out;
   }
-  const float out = __shfl(acc[0], lane & 15);
-  if (G > 1 && (L & 1) == 0) __syncthreads();  // next evaluation's layer 0 rewrites buffer 0
-  return out;
-}
+};
+
+// Closed-form models carry an empty stand-in so the integrator code is shared.
+struct NoMlp {
+  __device__ __forceinline__ float eval(float, float) { return 0.0f; }
+};
 
 // ---------------------------------------------------------------------------------------------
-// func.forward(t, y) of the reference, per lane (t already in the state dtype, as _PerturbFunc casts it)
+// func.forward(t, y) of the reference, per lane.  The protocol voltage at the stage time (and whether
+// the time was inside the protocol's range) is looked up by the caller, ahead of the stage.
 // ---------------------------------------------------------------------------------------------
-template <int MODEL, typename S, int G, int RT>
-__device__ __forceinline__ void rhs(const KArgs &a, const double *__restrict__ pv, const double *p, S t, const S *y,
-                                    S *f, f32x4 *Hs, const f32x4 *W0s, int wave, int lane) {
+template <int MODEL, typename S, typename MLP>
+__device__ __forceinline__ void rhs(const KArgs &a, const double *p, double v, bool inrange, const S *y, S *f,
+                                    MLP &mlp) {
   using MT = ModelTraits<MODEL>;
   constexpr bool F32 = sizeof(S) == 4;
-  double v;
-  const bool inrange = protocol_v(a, pv, (double)t, v);
 
   if constexpr (MODEL == IONODE_MODEL_MARKOV6) {
     if (F32 && !inrange) {
@@ -340,7 +395,7 @@ __device__ __forceinline__ void rhs(const KArgs &a, const double *__restrict__ p
     if constexpr (MT::MLP) {
       const float vf = (float)a.v_oob;
       const float nv = oob32 ? vf / 100.0f : (float)(v / 100.0);  // v / self.vrange, then .float()
-      net = mlp_tile_eval<G, RT>(a, nv, (float)av, Hs, W0s, wave, lane) / 1000.0f;  // / self.netscale
+      net = mlp.eval(nv, (float)av) / 1000.0f;                     // / self.netscale
     }
 
     if (oob32) {
@@ -403,7 +458,7 @@ template <typename S, int D> __device__ __forceinline__ void store_state(S *dst,
 // ---------------------------------------------------------------------------------------------
 // The integrator.  One workgroup = one tile of TPW trajectories (G wavefronts for MLP models).
 // ---------------------------------------------------------------------------------------------
-template <int MODEL, typename S, int G, int RT>
+template <int MODEL, typename S, int G, int RT, int NT, int PD>
 __global__ void __launch_bounds__(64 * G) ionode_dopri5_kernel(const KArgs a) {
   using MT = ModelTraits<MODEL>;
   using R = Real<S>;
@@ -412,22 +467,17 @@ __global__ void __launch_bounds__(64 * G) ionode_dopri5_kernel(const KArgs a) {
   static_assert(MT::MLP || G == 1, "closed-form models use one wavefront per tile");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  f32x4 *Hs = reinterpret_cast<f32x4 *>(smem);
-  f32x4 *W0s = Hs + 2 * a.NT * 64;
 
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps per-wave tile guards scalar
   const int j = lane % TPW;
   const bool primary = (lane < TPW) && (wave == 0);  // the replica that writes per-trajectory scalars
   const int traj_raw = blockIdx.x * TPW + j;
   const bool valid = traj_raw < a.B;
   const int traj = valid ? traj_raw : a.B - 1;
 
-  if constexpr (MT::MLP) {
-    const f32x4 *src = reinterpret_cast<const f32x4 *>(a.mlp);
-    for (int i = threadIdx.x; i < a.NP; i += 64 * G) W0s[i] = src[i];
-    __syncthreads();
-  }
+  typename std::conditional<MT::MLP, MlpTile<G, (RT > 0 ? RT : 1), (NT > 0 ? NT : 1), (PD > 0 ? PD : 1)>, NoMlp>::type mlp;
+  if constexpr (MT::MLP) mlp.init(a, smem, wave, lane);
 
   double p[NPAR];
 #pragma unroll
@@ -445,7 +495,11 @@ __global__ void __launch_bounds__(64 * G) ionode_dopri5_kernel(const KArgs a) {
   for (int d = 0; d < D; ++d) y[d] = reinterpret_cast<const S *>(a.y0)[(size_t)traj * D + d];
 
   double t = a.t_eval[0];
-  rhs<MODEL, S, G, RT>(a, pv, p, (S)t, y, f, Hs, W0s, wave, lane);  // f0 = func(t[0], y0)
+  {
+    double v0;
+    const bool in0 = protocol_v(a, pv, (double)(S)t, v0);
+    rhs<MODEL, S>(a, p, v0, in0, y, f, mlp);  // f0 = func(t[0], y0)
+  }
 
   // _select_initial_step (order argument 4), all in the state dtype
   double dt;
@@ -465,7 +519,11 @@ __global__ void __launch_bounds__(64 * G) ionode_dopri5_kernel(const KArgs a) {
     else h0 = (S)0.01 * d0 / d1;
 #pragma unroll
     for (int d = 0; d < D; ++d) y1[d] = y[d] + h0 * f[d];
-    rhs<MODEL, S, G, RT>(a, pv, p, t0s + h0, y1, f1, Hs, W0s, wave, lane);
+    {
+      double v1;
+      const bool in1 = protocol_v(a, pv, (double)(t0s + h0), v1);
+      rhs<MODEL, S>(a, p, v1, in1, y1, f1, mlp);
+    }
 #pragma unroll
     for (int d = 0; d < D; ++d) tmp[d] = (f1[d] - f[d]) / scale[d];
     const S d2 = rms_norm<S, D>(tmp) / h0;
@@ -540,9 +598,16 @@ __global__ void __launch_bounds__(64 * G) ionode_dopri5_kernel(const KArgs a) {
     S k[7][D], yi[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) k[0][d] = f[d];
+    // stage voltages: pure functions of (t0, dt), so all protocol loads are issued ahead of the stages
+    double vst[5];
+    bool inst[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const S ti = (i >= 4) ? R::prev_(t1s) : t0s + (S)kAlpha[i] * dts;  // alpha == 1: Perturb.PREV (stages 4 and 5)
+      inst[i] = protocol_v(a, pv, (double)ti, vst[i]);
+    }
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      const S ti = (i >= 4) ? R::prev_(t1s) : t0s + (S)kAlpha[i] * dts;  // alpha == 1: Perturb.PREV
       S bd[6];
 #pragma unroll
       for (int jx = 0; jx <= i; ++jx) bd[jx] = (S)kBeta[i][jx] * dts;
@@ -553,7 +618,7 @@ __global__ void __launch_bounds__(64 * G) ionode_dopri5_kernel(const KArgs a) {
         for (int jx = 1; jx <= i; ++jx) s = s + k[jx][d] * bd[jx];
         yi[d] = y[d] + s;
       }
-      rhs<MODEL, S, G, RT>(a, pv, p, ti, yi, k[i + 1], Hs, W0s, wave, lane);
+      rhs<MODEL, S>(a, p, vst[i < 4 ? i : 4], inst[i < 4 ? i : 4], yi, k[i + 1], mlp);
     }
     // y1 = y_5 (c_sol == beta[5] + [0]); error estimate; _compute_error_ratio
     S tmp[D];

@@ -7,14 +7,14 @@ namespace ionode {
 using LaunchFn = hipError_t (*)(const KArgs &, unsigned grid, size_t lds, hipStream_t);
 
 struct Variant {
-  int model, f32, G, RT;
+  int model, f32, G, RT, NT, PD;  // NT = k-tiles (16*NT = padded MLP width), PD = weight-ring depth
   LaunchFn fn;
   const char *name;  // as rocprofv3 --kernel-trace prints it
 };
 
-template <int MODEL, typename S, int G, int RT>
+template <int MODEL, typename S, int G, int RT, int NT, int PD>
 hipError_t launch(const KArgs &a, unsigned grid, size_t lds, hipStream_t s) {
-  auto kern = ionode_dopri5_kernel<MODEL, S, G, RT>;
+  auto kern = ionode_dopri5_kernel<MODEL, S, G, RT, NT, PD>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -24,8 +24,15 @@ hipError_t launch(const KArgs &a, unsigned grid, size_t lds, hipStream_t s) {
   return hipGetLastError();
 }
 
-#define IONODE_VARIANT(MODEL, S, F32, G, RT) \
-  Variant { MODEL, F32, G, RT, &launch<MODEL, S, G, RT>, "ionode_dopri5_kernel<" #MODEL ", " #S ", " #G ", " #RT ">" }
+#define IONODE_VARIANT(MODEL, S, F32, G, RT, NT, PD)           \
+  Variant {                                                   \
+    MODEL, F32, G, RT, NT, PD, &launch<MODEL, S, G, RT, NT, PD>, \
+        "ionode_dopri5_kernel<" #MODEL ", " #S ", " #G ", " #RT ", " #NT ", " #PD ">" \
+  }
+// the MLP shapes of the reference's architectures/s00-s11.py: N = 10, 100, 200, 500
+#define IONODE_MLP_VARIANTS(MODEL, S, F32)                                                      \
+  IONODE_VARIANT(MODEL, S, F32, 1, 1, 1, 1), IONODE_VARIANT(MODEL, S, F32, 4, 2, 7, 7),         \
+      IONODE_VARIANT(MODEL, S, F32, 4, 4, 13, 13), IONODE_VARIANT(MODEL, S, F32, 4, 8, 32, 4)
 
 // one table per translation unit (they compile in parallel)
 const Variant *variants_closed(int *n);

@@ -28,7 +28,9 @@
  *     observable in the reference (it is whatever the CPU BLAS did); the oracle fixes it as
  *     an fmaf chain seeded with the bias, over k in the order
  *         for tile in 0..NP/16-1: for r in 0..3: for q in 0..3: k = 16*tile + 4*q + r
- *     with the width zero-padded to NP = 16*ceil(N/16)  (DESIGN.md "canonical MLP order").
+ *     with the width zero-padded to NP = 16*ceil(N/16); the final Linear(N, 1) is four such chains
+ *     (one per q, seeded with 0) combined as ((p0 + p1) + (p2 + p3)) + bias
+ *     (DESIGN.md "canonical MLP order").
  */
 
 #ifndef REAL
