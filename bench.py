@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="trajectories timed on the host (0 = auto)")
     ap.add_argument("--tile-waves", type=int, default=0)
+    ap.add_argument("--stamps", action="store_true", help="diagnostic build (-DIONODE_STAMPS): print phase shares")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -85,6 +86,15 @@ def main():
     t_eval = torch.arange(Nt, dtype=torch.float64, device=dev) * 0.1
     i_ref = torch.zeros((B, Nt), dtype=torch.float64, device=dev)  # synthetic "data" current
     out = {}
+    if args.stamps:
+        slog = torch.zeros((16, 4), dtype=torch.float64, device=dev)
+        capi.dopri5(capi.MODEL_NNF, params, prot_v, y0, t_eval, mlp_packed=packed, mlp_layers=MLP_L, mlp_width=MLP_N,
+                    prot_t0=0.0, prot_dt=0.1, current=True, tile_waves=args.tile_waves, step_log=slog)
+        torch.cuda.synchronize()
+        t = slog.cpu().numpy().reshape(-1)[:16]
+        names = ["outside-mlp", "layer0", "barriers", "hidden-mfma", "lrelu+store", "last-layer", "rk-stage/err", "interp+emit"]
+        tot = t[:8].sum()
+        print("STAMPS (wave 0 of block 0, cycles):", {n: (int(v), round(v / tot, 3)) for n, v in zip(names, t[:8])}, file=sys.stderr)
 
     def step():
         r = capi.dopri5(capi.MODEL_NNF, params, prot_v, y0, t_eval, mlp_packed=packed, mlp_layers=MLP_L,

@@ -2,8 +2,8 @@
 #include "ionode_launch.hpp"
 namespace ionode {
 static const Variant kTab[] = {
-    IONODE_VARIANT(0, double, 0, 1, 0, 0, 0), IONODE_VARIANT(0, float, 1, 1, 0, 0, 0),
-    IONODE_VARIANT(1, double, 0, 1, 0, 0, 0), IONODE_VARIANT(1, float, 1, 1, 0, 0, 0),
+    IONODE_VARIANT(0, double, 0, 1, 0, 0, 0, 0), IONODE_VARIANT(0, float, 1, 1, 0, 0, 0, 0),
+    IONODE_VARIANT(1, double, 0, 1, 0, 0, 0, 0), IONODE_VARIANT(1, float, 1, 1, 0, 0, 0, 0),
 };
 const Variant *variants_closed(int *n) { *n = sizeof(kTab) / sizeof(kTab[0]); return kTab; }
 }  // namespace ionode

@@ -135,6 +135,25 @@ template <> struct Real<double> {
   static __device__ __forceinline__ double prev_(double x) { return nextafter(x, x - 1.0); }
 };
 
+// Diagnostic build only (make EXTRA=-DIONODE_STAMPS): s_memtime phase stamps of workgroup 0 / wavefront 0, summed
+// in SGPR-side 64-bit counters and written to step_log[0..15] at kernel end (no stamp executes in the real build).
+#ifdef IONODE_STAMPS
+struct Stamps {
+  unsigned long long acc[16];
+  unsigned long long last;
+};
+__device__ __forceinline__ unsigned long long stamp_now() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define STAMP_DECL Stamps stamps_; for (int i_ = 0; i_ < 16; ++i_) stamps_.acc[i_] = 0; stamps_.last = stamp_now();
+#define STAMP(st, slot) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = stamp_now(); (st).acc[slot] += n_ - (st).last; (st).last = n_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(st, slot) do { } while (0)
+#endif
+
 template <int MODEL> struct ModelTraits {
   static constexpr int D = (MODEL == IONODE_MODEL_MARKOV6) ? 6 : 2;
   static constexpr int NPAR = (MODEL == IONODE_MODEL_MARKOV6) ? 12 : 8;
@@ -184,7 +203,8 @@ __device__ __forceinline__ bool protocol_v(const KArgs &a, const double *__restr
   return true;
 }
 
-__device__ __forceinline__ float lrelu(float x) { return x > 0.0f ? x : x * 0.01f; }
+// nn.LeakyReLU(0.01): x > 0 ? x : 0.01*x  ==  max(x, 0.01*x) for every input (incl. +-0, NaN): 2 VALU ops
+__device__ __forceinline__ float lrelu(float x) { return fmaxf(x, x * 0.01f); }
 
 // ---------------------------------------------------------------------------------------------
 // Stage MLP of one 16-trajectory tile on the fp32 MFMA.  All G wavefronts of the workgroup call
@@ -201,11 +221,21 @@ __device__ __forceinline__ float lrelu(float x) { return x > 0.0f ? x : x * 0.01
 // every k-tile.  With L == 1 and PD == NT the layer simply stays resident in registers.
 // Small vectors (layer-0 rows, biases, last-layer weights) live in LDS for the kernel's lifetime.
 // ---------------------------------------------------------------------------------------------
-template <int G, int RT, int NT, int PD>
+//
+// TAIL (only with PD == NT): hipcc's waitcnt pass loses the age of loads across the layer loop's back edge and
+// drains ALL outstanding loads (vmcnt(0)) at the first MFMA of every layer.  To make that drain free, the last
+// TAIL k-tiles of a layer do not go through the ring: they are loaded at the start of the SAME layer (behind the
+// drain point) into their own registers, so the youngest ring refill is TAIL k-tiles (>= TAIL*RT*4 MFMAs) old
+// when the next layer drains.  Register cost is unchanged: (NT - TAIL) ring slots + TAIL tail slots.
+template <int G, int RT, int NT, int PD, int TAIL = 0>
 struct MlpTile {
   static_assert(NT % PD == 0, "ring depth must divide the k-tile count");
+  static_assert(TAIL == 0 || PD == NT, "the tail scheme is for the full-layer-ahead ring");
+  static_assert(TAIL < NT, "tail must leave at least one ring slot");
   static constexpr int NP = 16 * NT;
-  f32x4 ring[PD][RT];
+  static constexpr int RING = PD - TAIL;  // ring slots u = 0..RING-1 hold k-tile u (+ kt0 in the blocked scheme)
+  f32x4 ring[RING][RT];
+  f32x4 tail[TAIL > 0 ? TAIL : 1][RT];
   f32x4 *Hs;          // LDS [2][NT*64] activations, accumulator layout
   const f32x4 *W0s;   // LDS [NP] {b0, w00, w01, 0}
   const float *biasS; // LDS [L][NP]
@@ -217,6 +247,12 @@ struct MlpTile {
   size_t toff[RT];    // f32x4 offset of row tile i inside a layer (fragment kt = 0), or of the zero block
   size_t tkt[RT];     // f32x4 stride per k-tile: 64, or 0 for the zero block
   int L, wave, lane, nrt;
+#ifdef IONODE_STAMPS
+  Stamps *sp;
+#define MSTAMP(slot) STAMP(*sp, slot)
+#else
+#define MSTAMP(slot) do { } while (0)
+#endif
 
   static __host__ __device__ constexpr size_t lds_bytes(int L) {
     return ((size_t)2 * NT * 64 + NP) * 16 + ((size_t)L * NP + NP + 4) * 4;
@@ -246,17 +282,22 @@ struct MlpTile {
       toff[i] = real ? (size_t)((wave + i * G) * NT) * 64 : zero4;
       tkt[i] = real ? 64 : 0;
     }
-    // prime the ring with the first PD k-tiles of hidden layer 0
+    // prime the ring with the first k-tiles of hidden layer 0 (L == 1: the whole layer stays resident)
 #pragma unroll
-    for (int u = 0; u < PD; ++u)
+    for (int u = 0; u < RING; ++u)
 #pragma unroll
       for (int i = 0; i < RT; ++i) ring[u][i] = Aimg[toff[i] + tkt[i] * u];
+#pragma unroll
+    for (int u = 0; u < (TAIL > 0 ? TAIL : 1); ++u)
+#pragma unroll
+      for (int i = 0; i < RT; ++i) tail[u][i] = f32x4{0, 0, 0, 0};
     __syncthreads();
   }
 
   __device__ __forceinline__ float eval(float x0, float x1) {
     const int q = lane >> 4;
     constexpr int tstride = NT * 64;
+    MSTAMP(0);  // slot 0: everything outside the MLP (RK scalar work, emission)
 
     // layer 0: Linear(2, N) + LeakyReLU on the VALU, written in accumulator layout
 #pragma unroll
@@ -272,13 +313,16 @@ struct MlpTile {
         Hs[rt * 64 + lane] = h;
       }
     }
+    MSTAMP(1);  // slot 1: layer 0
     if (G > 1) __syncthreads();
+    MSTAMP(2);  // slot 2: barriers
 
     for (int l = 0; l < L; ++l) {
       const f32x4 *__restrict__ Hin = Hs + (l & 1) * tstride;
       f32x4 *__restrict__ Hout = Hs + ((l + 1) & 1) * tstride;
       const int ln = (l + 1 < L) ? l + 1 : 0;  // the ring runs cyclically over the hidden stack
-      const bool resident = (PD == NT) && (L == 1);
+      // (L == 1 simply re-streams the same layer: a runtime 'resident' branch around the refills would make
+      // hipcc's wait-count pass lose the age of the loads and drain them all at every use)
       // zero-block tiles must not move with the layer: their layer stride is 0 too
       const size_t lcur = (size_t)l * lstride4, lnext = (size_t)ln * lstride4;
 
@@ -288,26 +332,59 @@ struct MlpTile {
         const int rt = (i < nrt) ? wave + i * G : 0;  // dummy tiles read a valid bias row; result discarded
         acc[i] = *reinterpret_cast<const f32x4 *>(biasS + l * NP + 16 * rt + 4 * q);
       }
-      for (int kt0 = 0; kt0 < NT; kt0 += PD) {
-        const bool same_layer = kt0 + PD < NT;
-        const size_t lref = same_layer ? lcur : lnext;
-        const int ktref = same_layer ? kt0 + PD : 0;
+      if constexpr (TAIL > 0) {
+        // ring + tail: k-tiles 0..RING-1 from the ring (refilled for the next layer right after use),
+        // k-tiles RING..NT-1 from the tail (loaded behind the first MFMAs of this layer)
+        f32x4 b_nxt = Hin[lane];
 #pragma unroll
-        for (int u = 0; u < PD; ++u) {
-          const f32x4 b = Hin[(kt0 + u) * 64 + lane];
+        for (int u = 0; u < NT; ++u) {
+          const f32x4 b = b_nxt;
+          if (u + 1 < NT) b_nxt = Hin[(u + 1) * 64 + lane];  // LDS read one k-tile ahead: its latency hides behind 16 MFMAs
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
 #pragma unroll
             for (int i = 0; i < RT; ++i)
-              acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[u][i][r], b[r], acc[i], 0, 0, 0);
+              acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(u < RING ? ring[u][i][r] : tail[u - RING][i][r], b[r],
+                                                            acc[i], 0, 0, 0);
           }
-          if (!resident) {
+          if (u < RING) {
+#pragma unroll
+            for (int i = 0; i < RT; ++i) ring[u][i] = Aimg[(tkt[i] ? lnext : 0) + toff[i] + tkt[i] * u];
+          }
+          if (u == 0) {
+#pragma unroll
+            for (int v = 0; v < TAIL; ++v)
+#pragma unroll
+              for (int i = 0; i < RT; ++i) tail[v][i] = Aimg[(tkt[i] ? lcur : 0) + toff[i] + tkt[i] * (RING + v)];
+          }
+          // pin the refills here: left alone, the machine scheduler sinks every load of this (branch-free)
+          // layer body to its end / right before its use, which turns the ring back into a stall per k-tile
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+        for (int kt0 = 0; kt0 < NT; kt0 += PD) {
+          const bool same_layer = kt0 + PD < NT;
+          const size_t lref = same_layer ? lcur : lnext;
+          const int ktref = same_layer ? kt0 + PD : 0;
+          f32x4 b_nxt = Hin[kt0 * 64 + lane];
+#pragma unroll
+          for (int u = 0; u < PD; ++u) {
+            const f32x4 b = b_nxt;
+            if (u + 1 < PD) b_nxt = Hin[(kt0 + u + 1) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+              for (int i = 0; i < RT; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[u][i][r], b[r], acc[i], 0, 0, 0);
+            }
 #pragma unroll
             for (int i = 0; i < RT; ++i)
               ring[u][i] = Aimg[(tkt[i] ? lref : 0) + toff[i] + tkt[i] * (ktref + u)];
+            __builtin_amdgcn_sched_barrier(0);  // keep each refill behind its own k-tile's MFMAs
           }
         }
       }
+      MSTAMP(3);  // slot 3: hidden-layer MFMA loops (incl. bias load, B reads, refills)
 #pragma unroll
       for (int i = 0; i < RT; ++i) {
         if (i < nrt) {
@@ -317,7 +394,9 @@ struct MlpTile {
           Hout[(wave + i * G) * 64 + lane] = h;
         }
       }
+      MSTAMP(4);  // slot 4: LeakyReLU + activation store
       if (G > 1) __syncthreads();
+      MSTAMP(2);
     }
 
     // Linear(N, 1) on the VALU: four partial fmaf chains (one per lane group q), fixed combine tree
@@ -333,6 +412,7 @@ struct MlpTile {
     const float pair = part + __shfl_xor(part, 16);   // (p0 + p1) or (p2 + p3)
     const float out = (pair + __shfl_xor(pair, 32)) + wlS[NP];
     if (G > 1 && (L & 1) == 0) __syncthreads();  // next evaluation's layer 0 rewrites buffer 0
+    MSTAMP(5);  // slot 5: last layer
     return out;
   }
 };
@@ -458,7 +538,7 @@ template <typename S, int D> __device__ __forceinline__ void store_state(S *dst,
 // ---------------------------------------------------------------------------------------------
 // The integrator.  One workgroup = one tile of TPW trajectories (G wavefronts for MLP models).
 // ---------------------------------------------------------------------------------------------
-template <int MODEL, typename S, int G, int RT, int NT, int PD>
+template <int MODEL, typename S, int G, int RT, int NT, int PD, int TAIL>
 __global__ void __launch_bounds__(64 * G) ionode_dopri5_kernel(const KArgs a) {
   using MT = ModelTraits<MODEL>;
   using R = Real<S>;
@@ -476,8 +556,12 @@ __global__ void __launch_bounds__(64 * G) ionode_dopri5_kernel(const KArgs a) {
   const bool valid = traj_raw < a.B;
   const int traj = valid ? traj_raw : a.B - 1;
 
-  typename std::conditional<MT::MLP, MlpTile<G, (RT > 0 ? RT : 1), (NT > 0 ? NT : 1), (PD > 0 ? PD : 1)>, NoMlp>::type mlp;
+  typename std::conditional<MT::MLP, MlpTile<G, (RT > 0 ? RT : 1), (NT > 0 ? NT : 1), (PD > 0 ? PD : 1), TAIL>, NoMlp>::type mlp;
   if constexpr (MT::MLP) mlp.init(a, smem, wave, lane);
+  STAMP_DECL
+#ifdef IONODE_STAMPS
+  if constexpr (MT::MLP) mlp.sp = &stamps_;
+#endif
 
   double p[NPAR];
 #pragma unroll
@@ -652,11 +736,14 @@ __global__ void __launch_bounds__(64 * G) ionode_dopri5_kernel(const KArgs a) {
       dt_next = dt * fac;
     }
 
+    STAMP(stamps_, 6);  // slot 6: stage assembly + error control (scalar RK work outside the MLP)
     const bool acc_now = active && accept;
+#ifndef IONODE_STAMPS
     if (a.step_log != nullptr && active && primary && traj_raw == 0 && (int64_t)nacc + nrej < a.step_log_cap) {
       double *row = a.step_log + 4 * ((int64_t)nacc + nrej);
       row[0] = t0; row[1] = dt; row[2] = (double)ratio; row[3] = accept ? 1.0 : 0.0;
     }
+#endif
     if (active) { if (accept) ++nacc; else ++nrej; }
 
     // ---- _interp_fit + cooperative dense output ----
@@ -742,6 +829,7 @@ __global__ void __launch_bounds__(64 * G) ionode_dopri5_kernel(const KArgs a) {
       }
     }
 
+    STAMP(stamps_, 7);  // slot 7: interpolant fit + cooperative dense output
     // ---- advance the RK state ----
     if (acc_now) {
 #pragma unroll
@@ -752,6 +840,11 @@ __global__ void __launch_bounds__(64 * G) ionode_dopri5_kernel(const KArgs a) {
     if (active || acc_now) dt = dt_next;
   }
 
+#ifdef IONODE_STAMPS
+  STAMP(stamps_, 0);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && a.step_log != nullptr && a.step_log_cap >= 4)
+    for (int i_ = 0; i_ < 16; ++i_) a.step_log[i_] = (double)stamps_.acc[i_];
+#endif
   if (valid && primary) {
     a.status[traj] = status;
     if (a.stats) {

@@ -12,9 +12,9 @@ struct Variant {
   const char *name;  // as rocprofv3 --kernel-trace prints it
 };
 
-template <int MODEL, typename S, int G, int RT, int NT, int PD>
+template <int MODEL, typename S, int G, int RT, int NT, int PD, int TAIL>
 hipError_t launch(const KArgs &a, unsigned grid, size_t lds, hipStream_t s) {
-  auto kern = ionode_dopri5_kernel<MODEL, S, G, RT, NT, PD>;
+  auto kern = ionode_dopri5_kernel<MODEL, S, G, RT, NT, PD, TAIL>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -24,15 +24,19 @@ hipError_t launch(const KArgs &a, unsigned grid, size_t lds, hipStream_t s) {
   return hipGetLastError();
 }
 
-#define IONODE_VARIANT(MODEL, S, F32, G, RT, NT, PD)           \
-  Variant {                                                   \
-    MODEL, F32, G, RT, NT, PD, &launch<MODEL, S, G, RT, NT, PD>, \
-        "ionode_dopri5_kernel<" #MODEL ", " #S ", " #G ", " #RT ", " #NT ", " #PD ">" \
+#define IONODE_VARIANT(MODEL, S, F32, G, RT, NT, PD, TAIL) IONODE_VARIANT_(MODEL, S, F32, G, RT, NT, PD, TAIL)
+#define IONODE_VARIANT_(MODEL, S, F32, G, RT, NT, PD, TAIL)                                   \
+  Variant {                                                                                   \
+    MODEL, F32, G, RT, NT, PD, &launch<MODEL, S, G, RT, NT, PD, TAIL>,                          \
+        "ionode_dopri5_kernel<" #MODEL ", " #S ", " #G ", " #RT ", " #NT ", " #PD ", " #TAIL ">" \
   }
+#ifndef IONODE_TAIL13
+#define IONODE_TAIL13 0
+#endif
 // the MLP shapes of the reference's architectures/s00-s11.py: N = 10, 100, 200, 500
 #define IONODE_MLP_VARIANTS(MODEL, S, F32)                                                      \
-  IONODE_VARIANT(MODEL, S, F32, 1, 1, 1, 1), IONODE_VARIANT(MODEL, S, F32, 4, 2, 7, 7),         \
-      IONODE_VARIANT(MODEL, S, F32, 4, 4, 13, 13), IONODE_VARIANT(MODEL, S, F32, 4, 8, 32, 4)
+  IONODE_VARIANT(MODEL, S, F32, 1, 1, 1, 1, 0), IONODE_VARIANT(MODEL, S, F32, 4, 2, 7, 7, 0),        \
+      IONODE_VARIANT(MODEL, S, F32, 4, 4, 13, 13, IONODE_TAIL13), IONODE_VARIANT(MODEL, S, F32, 4, 8, 32, 4, 0)
 
 // one table per translation unit (they compile in parallel)
 const Variant *variants_closed(int *n);
