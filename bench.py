@@ -93,8 +93,9 @@ def main():
         torch.cuda.synchronize()
         t = slog.cpu().numpy().reshape(-1)[:16]
         names = ["outside-mlp", "layer0", "barriers", "hidden-mfma", "lrelu+store", "last-layer", "rk-stage/err", "interp+emit"]
-        tot = t[:8].sum()
-        print("STAMPS (wave 0 of block 0, cycles):", {n: (int(v), round(v / tot, 3)) for n, v in zip(names, t[:8])}, file=sys.stderr)
+        names += ["layer-prologue", "ktile-0", "ktile-last"]
+        tot = t[:11].sum()
+        print("STAMPS (wave 0 of block 0, cycles):", {n: (int(v), round(v / tot, 3)) for n, v in zip(names, t[:11])}, file=sys.stderr)
 
     def step():
         r = capi.dopri5(capi.MODEL_NNF, params, prot_v, y0, t_eval, mlp_packed=packed, mlp_layers=MLP_L,

@@ -77,14 +77,25 @@ int32_t ionode_abi_version(void) { return IONODE_ABI_VERSION; }
 
 const char *ionode_last_error(void) { return g_err; }
 
+// (G, RT) of the kernel variant that serves width N: the fragment stream is laid out per wavefront.
+static bool tile_shape(int N, int *G, int *RT) {
+  const ionode::Variant *v = find_variant(IONODE_MODEL_NNF, 0, 0, np_of(N) / 16);
+  if (!v) return false;
+  *G = v->G; *RT = v->RT;
+  return true;
+}
+
 size_t ionode_mlp_packed_floats(int32_t L, int32_t N) {
-  if (L < 0 || N < 1) return 0;
-  const size_t NP = (size_t)np_of(N);
-  return 4 * NP + (size_t)L * (NP * NP + NP) + NP + 4 + 256;  // + a 1 KiB zero block (dummy row tiles)
+  int G, RT;
+  if (L < 0 || N < 1 || !tile_shape(N, &G, &RT)) return 0;
+  const size_t NP = (size_t)np_of(N), NT = NP / 16;
+  return 4 * NP + (size_t)L * ((size_t)G * NT * RT * 256 + NP) + NP + 4;
 }
 
 int ionode_mlp_pack(const float *w, int32_t L, int32_t N, float *out) {
+  int G, RT;
   if (!w || !out || L < 0 || N < 1) { set_err("ionode_mlp_pack: bad argument"); return IONODE_ERR_ARG; }
+  if (!tile_shape(N, &G, &RT)) { set_err("ionode_mlp_pack: MLP width outside the compiled kernel variants"); return IONODE_ERR_UNSUPPORTED; }
   const int NP = np_of(N), NT = NP / 16;
   memset(out, 0, ionode_mlp_packed_floats(L, N) * sizeof(float));
   // layer 0: rows {b0, w00, w01, 0}
@@ -96,24 +107,27 @@ int ionode_mlp_pack(const float *w, int32_t L, int32_t N, float *out) {
   }
   const float *src = b0 + N;
   float *dst = out + 4 * (size_t)NP;
+  const size_t frag_floats = (size_t)G * NT * RT * 256;
   for (int l = 0; l < L; ++l) {
     const float *W = src, *b = src + (size_t)N * N;
-    // A fragments of v_mfma_f32_16x16x4_f32: lane = 16q + m holds row 16rt + m, k = 16kt + 4q + r
-    for (int rt = 0; rt < NT; ++rt)
+    // A operand of v_mfma_f32_16x16x4_f32: lane = 16q + m supplies row 16*rt + m, k = 16*kt + 4*q + r.
+    // Stream order: wavefront wv | k-tile kt | element e = r*RT + i (row tile rt = wv + i*G) | lane; 4 elements
+    // per float4, so the MFMAs of one k-step read one float4 (RT = 4).  Row tiles past NT are zero.
+    for (int wv = 0; wv < G; ++wv)
       for (int kt = 0; kt < NT; ++kt)
-        for (int lane = 0; lane < 64; ++lane) {
-          const int m = lane & 15, q = lane >> 4;
-          const int row = 16 * rt + m;
-          for (int r = 0; r < 4; ++r) {
-            const int k = 16 * kt + 4 * q + r;
-            const float val = (row < N && k < N) ? W[(size_t)row * N + k] : 0.0f;
-            dst[(((size_t)rt * NT + kt) * 64 + lane) * 4 + r] = val;
+        for (int e = 0; e < 4 * RT; ++e) {
+          const int r = e / RT, i = e % RT, rt = wv + i * G;
+          for (int lane = 0; lane < 64; ++lane) {
+            const int m = lane & 15, q = lane >> 4;
+            const int row = 16 * rt + m, k = 16 * kt + 4 * q + r;
+            const float val = (rt < NT && row < N && k < N) ? W[(size_t)row * N + k] : 0.0f;
+            dst[((((size_t)wv * NT + kt) * RT + e / 4) * 64 + lane) * 4 + e % 4] = val;
           }
         }
-    float *bias = dst + (size_t)NP * NP;
+    float *bias = dst + frag_floats;
     for (int r = 0; r < N; ++r) bias[r] = b[r];
     src += (size_t)N * N + N;
-    dst += (size_t)NP * NP + NP;
+    dst += frag_floats + NP;
   }
   for (int k = 0; k < N; ++k) dst[k] = src[k];
   dst[NP] = src[N];

@@ -210,7 +210,7 @@ __device__ __forceinline__ float lrelu(float x) { return fmaxf(x, x * 0.01f); }
 // Stage MLP of one 16-trajectory tile on the fp32 MFMA.  All G wavefronts of the workgroup call
 // eval() together in uniform control flow; it returns net([x0, x1]) for the lane's trajectory.
 //
-//   image (ionode_mlp_pack):  [NP][4] {b0,w00,w01,0} | L x { A[rt][kt][lane][4], bias[NP] } | wl[NP], bl
+//   image (ionode_mlp_pack):  [NP][4] {b0,w00,w01,0} | L x { A[wave][kt][r*RT+i][lane] (4 per float4), bias[NP] } | wl[NP], bl
 //   canonical order          hidden: acc = bias; for kt: for r: for q: acc = fmaf(W[row][k], h[k], acc), k = 16kt+4q+r
 //                            last:   part_q = 0; for kt: for r: part_q = fmaf(wl[k], h[k], part_q);
 //                                    out = ((part_0 + part_1) + (part_2 + part_3)) + bl
@@ -230,22 +230,19 @@ __device__ __forceinline__ float lrelu(float x) { return fmaxf(x, x * 0.01f); }
 template <int G, int RT, int NT, int PD, int TAIL = 0>
 struct MlpTile {
   static_assert(NT % PD == 0, "ring depth must divide the k-tile count");
-  static_assert(TAIL == 0 || PD == NT, "the tail scheme is for the full-layer-ahead ring");
-  static_assert(TAIL < NT, "tail must leave at least one ring slot");
+  static_assert(TAIL == 0, "tail scheme retired: the refills are interleaved with the MFMAs instead");
+  static_assert(RT == 1 || RT == 2 || RT == 4 || RT == 8, "row tiles per wavefront");
   static constexpr int NP = 16 * NT;
-  static constexpr int RING = PD - TAIL;  // ring slots u = 0..RING-1 hold k-tile u (+ kt0 in the blocked scheme)
-  f32x4 ring[RING][RT];
-  f32x4 tail[TAIL > 0 ? TAIL : 1][RT];
-  f32x4 *Hs;          // LDS [2][NT*64] activations, accumulator layout
+  // ring[u][j]: float4 j of k-tile slot u.  A k-tile of one wavefront is 4*RT floats per lane, element
+  // e = r*RT + i (k-step r, row tile i) -> float4 e/4, component e%4: the four (or RT) MFMAs of one k-step
+  // read ONE float4, which is refilled right behind them -- one 1 KiB load per 4 MFMAs, evenly spread.
+  f32x4 ring[PD][RT];
+  f32x4 *Hs;          // LDS [2][NT*64] activations (pre-LeakyReLU for hidden layers), accumulator layout
   const f32x4 *W0s;   // LDS [NP] {b0, w00, w01, 0}
   const float *biasS; // LDS [L][NP]
   const float *wlS;   // LDS [NP] + bl
-  const f32x4 *Aimg;  // global: hidden-layer fragments, + lane
+  const f32x4 *Aw;    // global: this wavefront's fragment stream of hidden layer 0, + lane
   size_t lstride4;    // f32x4 per hidden layer in the image
-  // Every wavefront runs RT row tiles so the MFMA stream is branch-free; a tile index past NT (13 = 4+3+3+3)
-  // streams the image's 1 KiB zero block instead and its result is never stored.
-  size_t toff[RT];    // f32x4 offset of row tile i inside a layer (fragment kt = 0), or of the zero block
-  size_t tkt[RT];     // f32x4 stride per k-tile: 64, or 0 for the zero block
   int L, wave, lane, nrt;
 #ifdef IONODE_STAMPS
   Stamps *sp;
@@ -254,43 +251,30 @@ struct MlpTile {
 #define MSTAMP(slot) do { } while (0)
 #endif
 
-  static __host__ __device__ constexpr size_t lds_bytes(int L) {
-    return ((size_t)2 * NT * 64 + NP) * 16 + ((size_t)L * NP + NP + 4) * 4;
-  }
+  static __host__ __device__ constexpr size_t layer_floats() { return (size_t)G * NT * RT * 256 + NP; }
 
   __device__ __forceinline__ void init(const KArgs &a, unsigned char *smem, int wave_, int lane_) {
     L = a.L; wave = wave_; lane = lane_;
-    nrt = (NT - wave + G - 1) / G;  // row tiles owned by this wavefront: rt = wave + i*G
+    nrt = (NT - wave + G - 1) / G;  // real row tiles of this wavefront: rt = wave + i*G (the rest are zero-padded)
     Hs = reinterpret_cast<f32x4 *>(smem);
     f32x4 *w0 = Hs + 2 * NT * 64;
     float *bs = reinterpret_cast<float *>(w0 + NP);
     float *ws = bs + (size_t)L * NP;
-    const size_t lstride = (size_t)NP * NP + NP;
+    constexpr size_t lstride = layer_floats();
     const int tid = wave * 64 + lane;
     const f32x4 *src = reinterpret_cast<const f32x4 *>(a.mlp);
     for (int i = tid; i < NP; i += 64 * G) w0[i] = src[i];
-    for (int i = tid; i < L * NP; i += 64 * G) bs[i] = a.mlp[4 * (size_t)NP + (size_t)(i / NP) * lstride + (size_t)NP * NP + (i % NP)];
+    for (int i = tid; i < L * NP; i += 64 * G) bs[i] = a.mlp[4 * (size_t)NP + (size_t)(i / NP) * lstride + (lstride - NP) + (i % NP)];
     const float *wl = a.mlp + 4 * (size_t)NP + (size_t)L * lstride;
     for (int i = tid; i < NP + 4; i += 64 * G) ws[i] = wl[i];
     W0s = w0; biasS = bs; wlS = ws;
-    Aimg = reinterpret_cast<const f32x4 *>(a.mlp + 4 * (size_t)NP) + lane;
+    Aw = reinterpret_cast<const f32x4 *>(a.mlp + 4 * (size_t)NP) + (size_t)wave * NT * RT * 64 + lane;
     lstride4 = lstride / 4;
-    const size_t zero4 = ((size_t)L * lstride + NP + 4) / 4;  // the zero block follows wl/bl
+    // prime the ring with the first PD k-tiles of hidden layer 0
 #pragma unroll
-    for (int i = 0; i < RT; ++i) {
-      const bool real = i < nrt;
-      toff[i] = real ? (size_t)((wave + i * G) * NT) * 64 : zero4;
-      tkt[i] = real ? 64 : 0;
-    }
-    // prime the ring with the first k-tiles of hidden layer 0 (L == 1: the whole layer stays resident)
+    for (int u = 0; u < PD; ++u)
 #pragma unroll
-    for (int u = 0; u < RING; ++u)
-#pragma unroll
-      for (int i = 0; i < RT; ++i) ring[u][i] = Aimg[toff[i] + tkt[i] * u];
-#pragma unroll
-    for (int u = 0; u < (TAIL > 0 ? TAIL : 1); ++u)
-#pragma unroll
-      for (int i = 0; i < RT; ++i) tail[u][i] = f32x4{0, 0, 0, 0};
+      for (int j = 0; j < RT; ++j) ring[u][j] = Aw[(size_t)(u * RT + j) * 64];
     __syncthreads();
   }
 
@@ -323,68 +307,44 @@ struct MlpTile {
       const int ln = (l + 1 < L) ? l + 1 : 0;  // the ring runs cyclically over the hidden stack
       // (L == 1 simply re-streams the same layer: a runtime 'resident' branch around the refills would make
       // hipcc's wait-count pass lose the age of the loads and drain them all at every use)
-      // zero-block tiles must not move with the layer: their layer stride is 0 too
-      const size_t lcur = (size_t)l * lstride4, lnext = (size_t)ln * lstride4;
+      const f32x4 *__restrict__ Acur = Aw + (size_t)l * lstride4;
+      const f32x4 *__restrict__ Anext = Aw + (size_t)ln * lstride4;
 
       f32x4 acc[RT];
 #pragma unroll
       for (int i = 0; i < RT; ++i) {
-        const int rt = (i < nrt) ? wave + i * G : 0;  // dummy tiles read a valid bias row; result discarded
+        const int rt = (i < nrt) ? wave + i * G : 0;  // padded tiles read a valid bias row; result discarded
         acc[i] = *reinterpret_cast<const f32x4 *>(biasS + l * NP + 16 * rt + 4 * q);
       }
-      if constexpr (TAIL > 0) {
-        // ring + tail: k-tiles 0..RING-1 from the ring (refilled for the next layer right after use),
-        // k-tiles RING..NT-1 from the tail (loaded behind the first MFMAs of this layer)
-        f32x4 b_nxt = Hin[lane];
+      for (int kt0 = 0; kt0 < NT; kt0 += PD) {
+        const bool same_layer = kt0 + PD < NT;
+        const f32x4 *__restrict__ Aref = same_layer ? Acur + (size_t)(kt0 + PD) * RT * 64 : Anext;
+        f32x4 b_nxt = Hin[kt0 * 64 + lane];
+        MSTAMP(8);  // slot 8: layer prologue (bias, first B read)
 #pragma unroll
-        for (int u = 0; u < NT; ++u) {
+        for (int u = 0; u < PD; ++u) {
+          if (u == 1) MSTAMP(9);       // slot 9: first k-tile
+          if (u == PD - 1) MSTAMP(3);  // slot 3: k-tiles 1..PD-2
           const f32x4 b = b_nxt;
-          if (u + 1 < NT) b_nxt = Hin[(u + 1) * 64 + lane];  // LDS read one k-tile ahead: its latency hides behind 16 MFMAs
+          if (u + 1 < PD) b_nxt = Hin[(kt0 + u + 1) * 64 + lane];  // LDS read one k-tile ahead
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
 #pragma unroll
-            for (int i = 0; i < RT; ++i)
-              acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(u < RING ? ring[u][i][r] : tail[u - RING][i][r], b[r],
-                                                            acc[i], 0, 0, 0);
-          }
-          if (u < RING) {
-#pragma unroll
-            for (int i = 0; i < RT; ++i) ring[u][i] = Aimg[(tkt[i] ? lnext : 0) + toff[i] + tkt[i] * u];
-          }
-          if (u == 0) {
-#pragma unroll
-            for (int v = 0; v < TAIL; ++v)
-#pragma unroll
-              for (int i = 0; i < RT; ++i) tail[v][i] = Aimg[(tkt[i] ? lcur : 0) + toff[i] + tkt[i] * (RING + v)];
-          }
-          // pin the refills here: left alone, the machine scheduler sinks every load of this (branch-free)
-          // layer body to its end / right before its use, which turns the ring back into a stall per k-tile
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      } else {
-        for (int kt0 = 0; kt0 < NT; kt0 += PD) {
-          const bool same_layer = kt0 + PD < NT;
-          const size_t lref = same_layer ? lcur : lnext;
-          const int ktref = same_layer ? kt0 + PD : 0;
-          f32x4 b_nxt = Hin[kt0 * 64 + lane];
-#pragma unroll
-          for (int u = 0; u < PD; ++u) {
-            const f32x4 b = b_nxt;
-            if (u + 1 < PD) b_nxt = Hin[(kt0 + u + 1) * 64 + lane];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-#pragma unroll
-              for (int i = 0; i < RT; ++i)
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[u][i][r], b[r], acc[i], 0, 0, 0);
+            for (int i = 0; i < RT; ++i) {
+              constexpr int dummy = 0; (void)dummy;
+              const int e = r * RT + i;
+              acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[u][e / 4][e % 4], b[r], acc[i], 0, 0, 0);
             }
+            // refill every float4 whose last reader was this k-step; pinned here so the machine scheduler can
+            // neither sink the loads to the end of the layer nor bunch them into one MFMA-free gap
 #pragma unroll
-            for (int i = 0; i < RT; ++i)
-              ring[u][i] = Aimg[(tkt[i] ? lref : 0) + toff[i] + tkt[i] * (ktref + u)];
-            __builtin_amdgcn_sched_barrier(0);  // keep each refill behind its own k-tile's MFMAs
+            for (int j = 0; j < RT; ++j)
+              if ((4 * j + 3) / RT == r) ring[u][j] = Aref[(size_t)(u * RT + j) * 64];
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
       }
-      MSTAMP(3);  // slot 3: hidden-layer MFMA loops (incl. bias load, B reads, refills)
+      MSTAMP(10);  // slot 10: last k-tile
 #pragma unroll
       for (int i = 0; i < RT; ++i) {
         if (i < nrt) {
