@@ -241,8 +241,12 @@ struct MlpTile {
   const f32x4 *W0s;   // LDS [NP] {b0, w00, w01, 0}
   const float *biasS; // LDS [L][NP]
   const float *wlS;   // LDS [NP] + bl
-  const f32x4 *Aw;    // global: this wavefront's fragment stream of hidden layer 0, + lane
-  size_t lstride4;    // f32x4 per hidden layer in the image
+  // weight stream addressing: buffer loads (128-bit SRSRC in SGPRs + ONE 32-bit VGPR offset per lane + scalar
+  // offset), so a refill moves half the address data of a 64-bit global_load through the issue port
+  __amdgpu_buffer_rsrc_t rsrc;
+  unsigned voff;      // per lane: byte offset of (this wavefront's stream, lane) inside a hidden layer
+  unsigned hid0;      // byte offset of hidden layer 0 in the image
+  unsigned lbytes;    // bytes per hidden layer in the image
   int L, wave, lane, nrt;
 #ifdef IONODE_STAMPS
   Stamps *sp;
@@ -268,14 +272,24 @@ struct MlpTile {
     const float *wl = a.mlp + 4 * (size_t)NP + (size_t)L * lstride;
     for (int i = tid; i < NP + 4; i += 64 * G) ws[i] = wl[i];
     W0s = w0; biasS = bs; wlS = ws;
-    Aw = reinterpret_cast<const f32x4 *>(a.mlp + 4 * (size_t)NP) + (size_t)wave * NT * RT * 64 + lane;
-    lstride4 = lstride / 4;
+    const size_t img_bytes = (4 * (size_t)NP + (size_t)L * lstride + NP + 4) * 4;
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.mlp), 0, (int)img_bytes, 0x00020000);
+    voff = (unsigned)(wave * NT * RT * 1024 + lane * 16);
+    hid0 = (unsigned)(4 * NP * 4);
+    lbytes = (unsigned)(lstride * 4);
     // prime the ring with the first PD k-tiles of hidden layer 0
 #pragma unroll
     for (int u = 0; u < PD; ++u)
 #pragma unroll
-      for (int j = 0; j < RT; ++j) ring[u][j] = Aw[(size_t)(u * RT + j) * 64];
+      for (int j = 0; j < RT; ++j) ring[u][j] = frag(hid0, u * RT + j);
     __syncthreads();
+  }
+
+  // one 1 KiB fragment (64 lanes x float4): k-tile-slot index n = kt*RT + j of the layer at byte offset `lbase`
+  __device__ __forceinline__ f32x4 frag(unsigned lbase, int n) const {
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, lbase + (unsigned)n * 1024u, 0);
+    return __builtin_bit_cast(f32x4, v);
   }
 
   __device__ __forceinline__ float eval(float x0, float x1) {
@@ -307,8 +321,7 @@ struct MlpTile {
       const int ln = (l + 1 < L) ? l + 1 : 0;  // the ring runs cyclically over the hidden stack
       // (L == 1 simply re-streams the same layer: a runtime 'resident' branch around the refills would make
       // hipcc's wait-count pass lose the age of the loads and drain them all at every use)
-      const f32x4 *__restrict__ Acur = Aw + (size_t)l * lstride4;
-      const f32x4 *__restrict__ Anext = Aw + (size_t)ln * lstride4;
+      const unsigned lcur = hid0 + (unsigned)l * lbytes, lnext = hid0 + (unsigned)ln * lbytes;
 
       f32x4 acc[RT];
 #pragma unroll
@@ -318,7 +331,7 @@ struct MlpTile {
       }
       for (int kt0 = 0; kt0 < NT; kt0 += PD) {
         const bool same_layer = kt0 + PD < NT;
-        const f32x4 *__restrict__ Aref = same_layer ? Acur + (size_t)(kt0 + PD) * RT * 64 : Anext;
+        const unsigned lref = same_layer ? lcur + (unsigned)(kt0 + PD) * RT * 1024u : lnext;
         f32x4 b_nxt = Hin[kt0 * 64 + lane];
         MSTAMP(8);  // slot 8: layer prologue (bias, first B read)
 #pragma unroll
@@ -337,9 +350,11 @@ struct MlpTile {
             }
             // refill every float4 whose last reader was this k-step; pinned here so the machine scheduler can
             // neither sink the loads to the end of the layer nor bunch them into one MFMA-free gap
+#ifndef IONODE_EXPERIMENT_NO_REFILL  // timing experiment only: results are wrong for L > 1
 #pragma unroll
             for (int j = 0; j < RT; ++j)
-              if ((4 * j + 3) / RT == r) ring[u][j] = Aref[(size_t)(u * RT + j) * 64];
+              if ((4 * j + 3) / RT == r) ring[u][j] = frag(lref, u * RT + j);
+#endif
             __builtin_amdgcn_sched_barrier(0);
           }
         }
