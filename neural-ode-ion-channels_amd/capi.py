@@ -10,7 +10,8 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libionode.so")
+# IONODE_LIB: dev override to A/B kernel builds (tools/ab_build.sh); the default is the in-tree library
+LIB_PATH = os.environ.get("IONODE_LIB") or os.path.join(_HERE, "libionode.so")
 
 MODEL_HH2, MODEL_MARKOV6, MODEL_NNF, MODEL_NND = 0, 1, 2, 3
 STATUS_OK, STATUS_DT_UNDERFLOW, STATUS_NONFINITE, STATUS_MAX_STEPS = 0, 1, 2, 3

@@ -63,7 +63,8 @@ int make_plan(const ionode_desc *d, Plan *pl) {
     }
     pl->grid = (unsigned)((d->n_traj + 15) / 16);
     pl->block = 64u * pl->v->G;
-    pl->lds = ((size_t)2 * NT * 64 + NP) * 16 + ((size_t)d->mlp_layers * NP + NP + 4) * 4;
+    const int Gv = pl->v->G, Rv = NT - Gv * (NT / Gv);  // remainder row tiles: K-split partial sums in LDS
+    pl->lds = ((size_t)2 * NT * 64 + (size_t)2 * Rv * Gv * 64 + NP) * 16 + ((size_t)d->mlp_layers * NP + NP + 4) * 4;
   }
   if (!pl->v) { set_err("no kernel variant compiled for this descriptor"); return IONODE_ERR_UNSUPPORTED; }
   return IONODE_OK;
@@ -111,16 +112,19 @@ int ionode_mlp_pack(const float *w, int32_t L, int32_t N, float *out) {
   for (int l = 0; l < L; ++l) {
     const float *W = src, *b = src + (size_t)N * N;
     // A operand of v_mfma_f32_16x16x4_f32: lane = 16q + m supplies row 16*rt + m, k = 16*kt + 4*q + r.
-    // Stream order: wavefront wv | k-tile kt | element e = r*RT + i (row tile rt = wv + i*G) | lane; 4 elements
-    // per float4, so the MFMAs of one k-step read one float4 (RT = 4).  Row tiles past NT are zero.
+    // Stream order: wavefront wv | k-tile kt | element e = r*RT + i | lane; 4 elements per float4.  Slot i < F is
+    // the full row tile wv + i*G; slot F + j is remainder tile G*F + j, present only in wv's K-slice (kt % G == wv).
+    const int F = NT / G;
     for (int wv = 0; wv < G; ++wv)
       for (int kt = 0; kt < NT; ++kt)
         for (int e = 0; e < 4 * RT; ++e) {
-          const int r = e / RT, i = e % RT, rt = wv + i * G;
+          const int r = e / RT, i = e % RT;
+          const int rt = (i < F) ? wv + i * G : G * F + (i - F);
+          const bool present = (i < F) || (kt % G == wv);
           for (int lane = 0; lane < 64; ++lane) {
             const int m = lane & 15, q = lane >> 4;
             const int row = 16 * rt + m, k = 16 * kt + 4 * q + r;
-            const float val = (rt < NT && row < N && k < N) ? W[(size_t)row * N + k] : 0.0f;
+            const float val = (present && rt < NT && row < N && k < N) ? W[(size_t)row * N + k] : 0.0f;
             dst[((((size_t)wv * NT + kt) * RT + e / 4) * 64 + lane) * 4 + e % 4] = val;
           }
         }

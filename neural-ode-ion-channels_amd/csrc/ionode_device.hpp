@@ -210,44 +210,50 @@ __device__ __forceinline__ float lrelu(float x) { return fmaxf(x, x * 0.01f); }
 // Stage MLP of one 16-trajectory tile on the fp32 MFMA.  All G wavefronts of the workgroup call
 // eval() together in uniform control flow; it returns net([x0, x1]) for the lane's trajectory.
 //
-//   image (ionode_mlp_pack):  [NP][4] {b0,w00,w01,0} | L x { A[wave][kt][r*RT+i][lane] (4 per float4), bias[NP] } | wl[NP], bl
-//   canonical order          hidden: acc = bias; for kt: for r: for q: acc = fmaf(W[row][k], h[k], acc), k = 16kt+4q+r
-//                            last:   part_q = 0; for kt: for r: part_q = fmaf(wl[k], h[k], part_q);
-//                                    out = ((part_0 + part_1) + (part_2 + part_3)) + bl
+// Work split.  A hidden layer is NT row tiles x NT k-tiles of 16x16x4 MFMAs (4 per tile pair).  Each of the G
+// wavefronts owns F = NT/G FULL row tiles (rt = w + i*G: all k-tiles) and a 1/G K-slice (k-tiles kt % G == w) of each
+// of the R = NT - G*F REMAINDER row tiles (rt = G*F + j).  For N = 200 (NT = 13, G = 4) that is 3*13 + 13/4 tile
+// products per wavefront instead of 4*13 on the critical wavefront.  The K-slices of a remainder tile are
+// partial sums; they meet in LDS and every wavefront folds them itself after the layer barrier.
 //
-// Weight streaming: the A fragments of the hidden layers are the only global traffic of the MLP.
-// They are consumed from a register ring that is refilled PD k-tiles ahead (PD == NT: a whole layer
-// ahead), so an L2 round trip (~1-2 us under load) hides behind >= PD*RT*4 MFMAs instead of stalling
-// every k-tile.  With L == 1 and PD == NT the layer simply stays resident in registers.
+// Canonical accumulation order (the oracle executes exactly this; DESIGN.md "canonical MLP order"):
+//   k index of (k-tile kt, k-step r, lane group q):  k = 16*kt + 4*q + r        (accumulator layout == B operand layout)
+//   full tile rows:       acc = bias; for kt = 0..NT-1: for r: for q: acc = fmaf(W[row][k], h[k], acc)
+//   remainder tile rows:  p_w = (w == 0 ? bias : 0); for kt with kt % G == w, ascending: for r: for q: p_w = fmaf(...)
+//                         acc = (p_0 + p_1) + (p_2 + p_3)                            (G = 4; G = 1 has no remainder)
+//   Linear(N, 1):         part_q = 0; for kt: for r: part_q = fmaf(wl[k], h[k], part_q);
+//                         out = ((part_0 + part_1) + (part_2 + part_3)) + bl
+//
+// Weight streaming.  The A fragments of the hidden layers are the only global traffic of the MLP.  Stream order
+// (ionode_mlp_pack): layer | wavefront w | k-tile kt | element e = r*RT + i | lane, 4 elements per float4, where
+// slot i < F is full tile w + i*G and slot F + j is remainder tile G*F + j (its K-slice for kt % G == w, zeros
+// elsewhere); RT = F + R.  They are consumed from a register ring refilled PD k-tiles ahead (PD == NT: a whole
+// layer ahead) with SRSRC buffer loads, one 1 KiB load behind every RT MFMAs, pinned with sched_barrier so the
+// machine scheduler neither sinks them to the end of the layer nor bunches them into an MFMA-free gap.
 // Small vectors (layer-0 rows, biases, last-layer weights) live in LDS for the kernel's lifetime.
 // ---------------------------------------------------------------------------------------------
-//
-// TAIL (only with PD == NT): hipcc's waitcnt pass loses the age of loads across the layer loop's back edge and
-// drains ALL outstanding loads (vmcnt(0)) at the first MFMA of every layer.  To make that drain free, the last
-// TAIL k-tiles of a layer do not go through the ring: they are loaded at the start of the SAME layer (behind the
-// drain point) into their own registers, so the youngest ring refill is TAIL k-tiles (>= TAIL*RT*4 MFMAs) old
-// when the next layer drains.  Register cost is unchanged: (NT - TAIL) ring slots + TAIL tail slots.
 template <int G, int RT, int NT, int PD, int TAIL = 0>
 struct MlpTile {
+  static constexpr int F = NT / G;       // full row tiles per wavefront
+  static constexpr int R = NT - G * F;   // remainder row tiles, K-split over the G wavefronts
+  static constexpr int NP = 16 * NT;
+  static constexpr int RP = (R > 0 ? R : 1);
   static_assert(NT % PD == 0, "ring depth must divide the k-tile count");
   static_assert(TAIL == 0, "tail scheme retired: the refills are interleaved with the MFMAs instead");
-  static_assert(RT == 1 || RT == 2 || RT == 4 || RT == 8, "row tiles per wavefront");
-  static constexpr int NP = 16 * NT;
-  // ring[u][j]: float4 j of k-tile slot u.  A k-tile of one wavefront is 4*RT floats per lane, element
-  // e = r*RT + i (k-step r, row tile i) -> float4 e/4, component e%4: the four (or RT) MFMAs of one k-step
-  // read ONE float4, which is refilled right behind them -- one 1 KiB load per 4 MFMAs, evenly spread.
+  static_assert(RT == F + R, "RT = full + remainder tile slots per wavefront");
+  static_assert((4 * RT) % 4 == 0 && (RT == 1 || RT == 2 || RT == 4 || RT == 8), "fragment = RT float4 per k-tile");
+  static_assert(R == 0 || G == 4, "the remainder combine tree is written for 4 wavefronts");
   f32x4 ring[PD][RT];
-  f32x4 *Hs;          // LDS [2][NT*64] activations (pre-LeakyReLU for hidden layers), accumulator layout
+  f32x4 *Hs;          // LDS [2][NT*64] activations after LeakyReLU, accumulator layout (full tiles only)
+  f32x4 *Ps;          // LDS [2][R][G][64] partial sums of the remainder tiles (pre-activation)
   const f32x4 *W0s;   // LDS [NP] {b0, w00, w01, 0}
   const float *biasS; // LDS [L][NP]
   const float *wlS;   // LDS [NP] + bl
-  // weight stream addressing: buffer loads (128-bit SRSRC in SGPRs + ONE 32-bit VGPR offset per lane + scalar
-  // offset), so a refill moves half the address data of a 64-bit global_load through the issue port
-  __amdgpu_buffer_rsrc_t rsrc;
+  __amdgpu_buffer_rsrc_t rsrc;  // weight image; one 32-bit VGPR offset per lane + scalar offset per load
   unsigned voff;      // per lane: byte offset of (this wavefront's stream, lane) inside a hidden layer
   unsigned hid0;      // byte offset of hidden layer 0 in the image
   unsigned lbytes;    // bytes per hidden layer in the image
-  int L, wave, lane, nrt;
+  int L, wave, lane;
 #ifdef IONODE_STAMPS
   Stamps *sp;
 #define MSTAMP(slot) STAMP(*sp, slot)
@@ -256,12 +262,15 @@ struct MlpTile {
 #endif
 
   static __host__ __device__ constexpr size_t layer_floats() { return (size_t)G * NT * RT * 256 + NP; }
+  static __host__ __device__ constexpr size_t lds_bytes(int L) {
+    return ((size_t)2 * NT * 64 + (size_t)2 * R * G * 64 + NP) * 16 + ((size_t)L * NP + NP + 4) * 4;
+  }
 
   __device__ __forceinline__ void init(const KArgs &a, unsigned char *smem, int wave_, int lane_) {
     L = a.L; wave = wave_; lane = lane_;
-    nrt = (NT - wave + G - 1) / G;  // real row tiles of this wavefront: rt = wave + i*G (the rest are zero-padded)
     Hs = reinterpret_cast<f32x4 *>(smem);
-    f32x4 *w0 = Hs + 2 * NT * 64;
+    Ps = Hs + 2 * NT * 64;
+    f32x4 *w0 = Ps + 2 * R * G * 64;
     float *bs = reinterpret_cast<float *>(w0 + NP);
     float *ws = bs + (size_t)L * NP;
     constexpr size_t lstride = layer_floats();
@@ -288,20 +297,34 @@ struct MlpTile {
   // one 1 KiB fragment (64 lanes x float4): k-tile-slot index n = kt*RT + j of the layer at byte offset `lbase`
   __device__ __forceinline__ f32x4 frag(unsigned lbase, int n) const {
     using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, lbase + (unsigned)n * 1024u, 0);
+    #ifndef IONODE_WEIGHT_AUX
+#define IONODE_WEIGHT_AUX 0
+#endif
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, lbase + (unsigned)n * 1024u, IONODE_WEIGHT_AUX);
     return __builtin_bit_cast(f32x4, v);
+  }
+
+  // activations of remainder tile j as a B operand / dot-product input: fold the G partial sums (fixed tree)
+  __device__ __forceinline__ f32x4 remainder_h(const f32x4 *__restrict__ Pin, int j) const {
+    const f32x4 p0 = Pin[(j * G + 0) * 64 + lane], p1 = Pin[(j * G + 1) * 64 + lane];
+    const f32x4 p2 = Pin[(j * G + 2) * 64 + lane], p3 = Pin[(j * G + 3) * 64 + lane];
+    f32x4 h;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h[r] = lrelu((p0[r] + p1[r]) + (p2[r] + p3[r]));
+    return h;
   }
 
   __device__ __forceinline__ float eval(float x0, float x1) {
     const int q = lane >> 4;
     constexpr int tstride = NT * 64;
+    constexpr int pstride = R * G * 64;
     MSTAMP(0);  // slot 0: everything outside the MLP (RK scalar work, emission)
 
-    // layer 0: Linear(2, N) + LeakyReLU on the VALU, written in accumulator layout
+    // layer 0: Linear(2, N) + LeakyReLU on the VALU, written in accumulator layout; row tile rt by wavefront rt % G
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
-      if (i < nrt) {
-        const int rt = wave + i * G;
+      const int rt = wave + i * G;
+      if (rt < NT) {
         f32x4 h;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -318,38 +341,56 @@ struct MlpTile {
     for (int l = 0; l < L; ++l) {
       const f32x4 *__restrict__ Hin = Hs + (l & 1) * tstride;
       f32x4 *__restrict__ Hout = Hs + ((l + 1) & 1) * tstride;
+      const f32x4 *__restrict__ Pin = Ps + (l & 1) * pstride;
+      f32x4 *__restrict__ Pout = Ps + ((l + 1) & 1) * pstride;
       const int ln = (l + 1 < L) ? l + 1 : 0;  // the ring runs cyclically over the hidden stack
       // (L == 1 simply re-streams the same layer: a runtime 'resident' branch around the refills would make
       // hipcc's wait-count pass lose the age of the loads and drain them all at every use)
       const unsigned lcur = hid0 + (unsigned)l * lbytes, lnext = hid0 + (unsigned)ln * lbytes;
 
-      f32x4 acc[RT];
+      // B operands of the remainder k-tiles: layer 0 wrote them as ordinary tiles, hidden layers as partial sums
+      f32x4 brem[RP];
 #pragma unroll
-      for (int i = 0; i < RT; ++i) {
-        const int rt = (i < nrt) ? wave + i * G : 0;  // padded tiles read a valid bias row; result discarded
-        acc[i] = *reinterpret_cast<const f32x4 *>(biasS + l * NP + 16 * rt + 4 * q);
+      for (int j = 0; j < R; ++j) brem[j] = (l == 0) ? Hin[(G * F + j) * 64 + lane] : remainder_h(Pin, j);
+
+      f32x4 acc[F > 0 ? F : 1], accr[RP];
+#pragma unroll
+      for (int i = 0; i < F; ++i)
+        acc[i] = *reinterpret_cast<const f32x4 *>(biasS + l * NP + 16 * (wave + i * G) + 4 * q);
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const f32x4 bz = *reinterpret_cast<const f32x4 *>(biasS + l * NP + 16 * (G * F + j) + 4 * q);
+        accr[j] = (wave == 0) ? bz : f32x4{0, 0, 0, 0};  // partial sum 0 carries the bias
       }
       for (int kt0 = 0; kt0 < NT; kt0 += PD) {
         const bool same_layer = kt0 + PD < NT;
         const unsigned lref = same_layer ? lcur + (unsigned)(kt0 + PD) * RT * 1024u : lnext;
         f32x4 b_nxt = Hin[kt0 * 64 + lane];
-        MSTAMP(8);  // slot 8: layer prologue (bias, first B read)
+        MSTAMP(8);  // slot 8: layer prologue (bias, remainder fold, first B read)
 #pragma unroll
         for (int u = 0; u < PD; ++u) {
           if (u == 1) MSTAMP(9);       // slot 9: first k-tile
           if (u == PD - 1) MSTAMP(3);  // slot 3: k-tiles 1..PD-2
-          const f32x4 b = b_nxt;
-          if (u + 1 < PD) b_nxt = Hin[(kt0 + u + 1) * 64 + lane];  // LDS read one k-tile ahead
+          // k-tile index kt0 + u; with R > 0 the scheme is PD == NT, so kt == u is static
+          f32x4 b = b_nxt;
+          if (R > 0 && u >= G * F) b = brem[(u - G * F) < R ? (u - G * F) : 0];
+          if (u + 1 < PD && (R == 0 || u + 1 < G * F)) b_nxt = Hin[(kt0 + u + 1) * 64 + lane];  // LDS read one k-tile ahead
+          const bool own = (R > 0) && ((u % G) == wave);  // this wavefront's K-slice of the remainder tiles
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
 #pragma unroll
-            for (int i = 0; i < RT; ++i) {
-              constexpr int dummy = 0; (void)dummy;
+            for (int i = 0; i < F; ++i) {
               const int e = r * RT + i;
               acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[u][e / 4][e % 4], b[r], acc[i], 0, 0, 0);
             }
-            // refill every float4 whose last reader was this k-step; pinned here so the machine scheduler can
-            // neither sink the loads to the end of the layer nor bunch them into one MFMA-free gap
+            if (own) {
+#pragma unroll
+              for (int j = 0; j < R; ++j) {
+                const int e = r * RT + F + j;
+                accr[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[u][e / 4][e % 4], b[r], accr[j], 0, 0, 0);
+              }
+            }
+            // refill every float4 whose last reader was this k-step; pinned here (see header comment)
 #ifndef IONODE_EXPERIMENT_NO_REFILL  // timing experiment only: results are wrong for L > 1
 #pragma unroll
             for (int j = 0; j < RT; ++j)
@@ -361,14 +402,14 @@ struct MlpTile {
       }
       MSTAMP(10);  // slot 10: last k-tile
 #pragma unroll
-      for (int i = 0; i < RT; ++i) {
-        if (i < nrt) {
-          f32x4 h;
+      for (int i = 0; i < F; ++i) {
+        f32x4 h;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) h[r] = lrelu(acc[i][r]);
-          Hout[(wave + i * G) * 64 + lane] = h;
-        }
+        for (int r = 0; r < 4; ++r) h[r] = lrelu(acc[i][r]);
+        Hout[(wave + i * G) * 64 + lane] = h;
       }
+#pragma unroll
+      for (int j = 0; j < R; ++j) Pout[(j * G + wave) * 64 + lane] = accr[j];
       MSTAMP(4);  // slot 4: LeakyReLU + activation store
       if (G > 1) __syncthreads();
       MSTAMP(2);
@@ -376,11 +417,14 @@ struct MlpTile {
 
     // Linear(N, 1) on the VALU: four partial fmaf chains (one per lane group q), fixed combine tree
     const f32x4 *__restrict__ Hin = Hs + (L & 1) * tstride;
+    const f32x4 *__restrict__ Pin = Ps + (L & 1) * pstride;
     float part = 0.0f;
-#pragma unroll 4
+#pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
       const f32x4 w = *reinterpret_cast<const f32x4 *>(wlS + 16 * kt + 4 * q);
-      const f32x4 h = Hin[kt * 64 + lane];
+      f32x4 h;
+      if (R > 0 && kt >= G * F && L > 0) h = remainder_h(Pin, kt - G * F);
+      else h = Hin[kt * 64 + lane];
 #pragma unroll
       for (int r = 0; r < 4; ++r) part = fmaf(w[r], h[r], part);
     }

@@ -35,7 +35,7 @@ hipError_t launch(const KArgs &a, unsigned grid, size_t lds, hipStream_t s) {
 #endif
 // the MLP shapes of the reference's architectures/s00-s11.py: N = 10, 100, 200, 500
 #define IONODE_MLP_VARIANTS(MODEL, S, F32)                                                      \
-  IONODE_VARIANT(MODEL, S, F32, 1, 1, 1, 1, 0), IONODE_VARIANT(MODEL, S, F32, 4, 2, 7, 7, 0),        \
+  IONODE_VARIANT(MODEL, S, F32, 1, 1, 1, 1, 0), IONODE_VARIANT(MODEL, S, F32, 4, 4, 7, 7, 0),        \
       IONODE_VARIANT(MODEL, S, F32, 4, 4, 13, 13, IONODE_TAIL13), IONODE_VARIANT(MODEL, S, F32, 4, 8, 32, 4, 0)
 
 // one table per translation unit (they compile in parallel)
