@@ -90,7 +90,7 @@ size_t ionode_mlp_packed_floats(int32_t L, int32_t N) {
   int G, RT;
   if (L < 0 || N < 1 || !tile_shape(N, &G, &RT)) return 0;
   const size_t NP = (size_t)np_of(N), NT = NP / 16;
-  return 4 * NP + (size_t)L * ((size_t)G * NT * RT * 256 + NP) + NP + 4;
+  return 4 * NP + (size_t)L * ((size_t)G * NT * RT * 256 + NP) + NP + 4 + 256;  // + 1 KiB zero block
 }
 
 int ionode_mlp_pack(const float *w, int32_t L, int32_t N, float *out) {
@@ -112,21 +112,25 @@ int ionode_mlp_pack(const float *w, int32_t L, int32_t N, float *out) {
   for (int l = 0; l < L; ++l) {
     const float *W = src, *b = src + (size_t)N * N;
     // A operand of v_mfma_f32_16x16x4_f32: lane = 16q + m supplies row 16*rt + m, k = 16*kt + 4*q + r.
-    // Stream order: wavefront wv | k-tile kt | element e = r*RT + i | lane; 4 elements per float4.  Slot i < F is
-    // the full row tile wv + i*G; slot F + j is remainder tile G*F + j, present only in wv's K-slice (kt % G == wv).
-    const int F = NT / G;
+    // Stream order: wavefront wv | k-tile kt | RT = F + R float4 fragments | lane.  Fragments 0..F-1: the full row
+    // tiles wv + i*G, k-step-major (element e = r*F + i -> fragment e/4, component e%4).  Fragment F + j: remainder
+    // tile G*F + j, component = k-step r, only in wv's K-slice (kt % G == wv); zeros elsewhere (never loaded).
+    const int F = NT / G, Rm = NT - G * F;
     for (int wv = 0; wv < G; ++wv)
       for (int kt = 0; kt < NT; ++kt)
-        for (int e = 0; e < 4 * RT; ++e) {
-          const int r = e / RT, i = e % RT;
-          const int rt = (i < F) ? wv + i * G : G * F + (i - F);
-          const bool present = (i < F) || (kt % G == wv);
-          for (int lane = 0; lane < 64; ++lane) {
-            const int m = lane & 15, q = lane >> 4;
+        for (int lane = 0; lane < 64; ++lane) {
+          const int m = lane & 15, q = lane >> 4;
+          float *frag0 = dst + ((((size_t)wv * NT + kt) * RT) * 64 + lane) * 4;
+          for (int e = 0; e < 4 * F; ++e) {
+            const int r = e / F, i = e % F, rt = wv + i * G;
             const int row = 16 * rt + m, k = 16 * kt + 4 * q + r;
-            const float val = (present && rt < NT && row < N && k < N) ? W[(size_t)row * N + k] : 0.0f;
-            dst[((((size_t)wv * NT + kt) * RT + e / 4) * 64 + lane) * 4 + e % 4] = val;
+            frag0[(size_t)(e / 4) * 256 + e % 4] = (row < N && k < N) ? W[(size_t)row * N + k] : 0.0f;
           }
+          for (int j = 0; j < Rm; ++j)
+            for (int r = 0; r < 4; ++r) {
+              const int row = 16 * (G * F + j) + m, k = 16 * kt + 4 * q + r;
+              frag0[(size_t)(F + j) * 256 + r] = (kt % G == wv && row < N && k < N) ? W[(size_t)row * N + k] : 0.0f;
+            }
         }
     float *bias = dst + frag_floats;
     for (int r = 0; r < N; ++r) bias[r] = b[r];

@@ -225,11 +225,15 @@ __device__ __forceinline__ float lrelu(float x) { return fmaxf(x, x * 0.01f); }
 //                         out = ((part_0 + part_1) + (part_2 + part_3)) + bl
 //
 // Weight streaming.  The A fragments of the hidden layers are the only global traffic of the MLP.  Stream order
-// (ionode_mlp_pack): layer | wavefront w | k-tile kt | element e = r*RT + i | lane, 4 elements per float4, where
-// slot i < F is full tile w + i*G and slot F + j is remainder tile G*F + j (its K-slice for kt % G == w, zeros
-// elsewhere); RT = F + R.  They are consumed from a register ring refilled PD k-tiles ahead (PD == NT: a whole
-// layer ahead) with SRSRC buffer loads, one 1 KiB load behind every RT MFMAs, pinned with sched_barrier so the
-// machine scheduler neither sinks them to the end of the layer nor bunches them into an MFMA-free gap.
+// (ionode_mlp_pack): layer | wavefront w | k-tile kt | RT = F + R float4 fragments | lane.  Fragments 0..F-1 hold
+// the full tiles k-step-major (element e = r*F + i -> float4 e/4, component e%4: the F MFMAs of a k-step read one
+// float4 when F = 4); fragment F + j holds remainder tile G*F + j (components = k-steps r) and exists only in
+// wavefront w's K-slice (kt % G == w): elsewhere the kernel points that load at the image's 1 KiB zero block,
+// which stays L1-resident, so the padding costs no L2 bandwidth.  Fragments are consumed from a register ring
+// refilled PD k-tiles ahead (PD == NT: a whole layer ahead) with SRSRC buffer loads issued right behind the last
+// MFMA that reads them, pinned with sched_barrier so the machine scheduler neither sinks them to the end of the
+// layer nor bunches them into an MFMA-free gap.  The kernel sits at the balance point of fp32-MFMA rate and per-CU
+// L2 streaming rate (about 28 B/clk/CU measured), so both the MFMA count and the streamed bytes matter.
 // Small vectors (layer-0 rows, biases, last-layer weights) live in LDS for the kernel's lifetime.
 // ---------------------------------------------------------------------------------------------
 template <int G, int RT, int NT, int PD, int TAIL = 0>
@@ -253,6 +257,7 @@ struct MlpTile {
   unsigned voff;      // per lane: byte offset of (this wavefront's stream, lane) inside a hidden layer
   unsigned hid0;      // byte offset of hidden layer 0 in the image
   unsigned lbytes;    // bytes per hidden layer in the image
+  unsigned zoff;      // soffset that makes voff address the zero block (wave-uniform)
   int L, wave, lane;
 #ifdef IONODE_STAMPS
   Stamps *sp;
@@ -281,26 +286,28 @@ struct MlpTile {
     const float *wl = a.mlp + 4 * (size_t)NP + (size_t)L * lstride;
     for (int i = tid; i < NP + 4; i += 64 * G) ws[i] = wl[i];
     W0s = w0; biasS = bs; wlS = ws;
-    const size_t img_bytes = (4 * (size_t)NP + (size_t)L * lstride + NP + 4) * 4;
+    const size_t zero_byte = (4 * (size_t)NP + (size_t)L * lstride + NP + 4) * 4;  // zero block follows wl / bl
+    const size_t img_bytes = zero_byte + 1024;
     rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.mlp), 0, (int)img_bytes, 0x00020000);
     voff = (unsigned)(wave * NT * RT * 1024 + lane * 16);
     hid0 = (unsigned)(4 * NP * 4);
     lbytes = (unsigned)(lstride * 4);
+    zoff = (unsigned)zero_byte - (unsigned)(wave * NT * RT * 1024);
     // prime the ring with the first PD k-tiles of hidden layer 0
 #pragma unroll
     for (int u = 0; u < PD; ++u)
 #pragma unroll
-      for (int j = 0; j < RT; ++j) ring[u][j] = frag(hid0, u * RT + j);
+      for (int j = 0; j < RT; ++j) ring[u][j] = frag(hid0, u, j);
     __syncthreads();
   }
 
-  // one 1 KiB fragment (64 lanes x float4): k-tile-slot index n = kt*RT + j of the layer at byte offset `lbase`
-  __device__ __forceinline__ f32x4 frag(unsigned lbase, int n) const {
+  // one 1 KiB fragment (64 lanes x float4): fragment j of k-tile kt of the layer at byte offset `lbase`.
+  // A remainder fragment outside this wavefront's K-slice is never read by an MFMA: load the zero block instead.
+  __device__ __forceinline__ f32x4 frag(unsigned lbase, int kt, int j) const {
     using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
-    #ifndef IONODE_WEIGHT_AUX
-#define IONODE_WEIGHT_AUX 0
-#endif
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, lbase + (unsigned)n * 1024u, IONODE_WEIGHT_AUX);
+    unsigned soff = lbase + (unsigned)(kt * RT + j) * 1024u;
+    if (R > 0 && j >= F && (kt % G) != wave) soff = zoff;
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
     return __builtin_bit_cast(f32x4, v);
   }
 
@@ -364,6 +371,7 @@ struct MlpTile {
       }
       for (int kt0 = 0; kt0 < NT; kt0 += PD) {
         const bool same_layer = kt0 + PD < NT;
+        // (frag() needs the true k-tile index for the K-slice test; with R > 0 the scheme is PD == NT, kt0 == 0)
         const unsigned lref = same_layer ? lcur + (unsigned)(kt0 + PD) * RT * 1024u : lnext;
         f32x4 b_nxt = Hin[kt0 * 64 + lane];
         MSTAMP(8);  // slot 8: layer prologue (bias, remainder fold, first B read)
@@ -380,21 +388,23 @@ struct MlpTile {
           for (int r = 0; r < 4; ++r) {
 #pragma unroll
             for (int i = 0; i < F; ++i) {
-              const int e = r * RT + i;
+              const int e = r * F + i;
               acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[u][e / 4][e % 4], b[r], acc[i], 0, 0, 0);
             }
             if (own) {
 #pragma unroll
-              for (int j = 0; j < R; ++j) {
-                const int e = r * RT + F + j;
-                accr[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[u][e / 4][e % 4], b[r], accr[j], 0, 0, 0);
-              }
+              for (int j = 0; j < R; ++j)
+                accr[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[u][F + j][r], b[r], accr[j], 0, 0, 0);
             }
-            // refill every float4 whose last reader was this k-step; pinned here (see header comment)
+            // refill every fragment whose last reader was this k-step; pinned here (see header comment)
 #ifndef IONODE_EXPERIMENT_NO_REFILL  // timing experiment only: results are wrong for L > 1
 #pragma unroll
-            for (int j = 0; j < RT; ++j)
-              if ((4 * j + 3) / RT == r) ring[u][j] = frag(lref, u * RT + j);
+            for (int j = 0; j < F; ++j)
+              if ((4 * j + 3) / F == r) ring[u][j] = frag(lref, u, j);
+            if (r == 3) {
+#pragma unroll
+              for (int j = 0; j < R; ++j) ring[u][F + j] = frag(lref, u, F + j);
+            }
 #endif
             __builtin_amdgcn_sched_barrier(0);
           }
