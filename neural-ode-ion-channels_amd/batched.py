@@ -1,0 +1,102 @@
+"""Batched host API over the C ABI: numpy / torch in, torch (device) out.
+
+`solve()` is what the drop-in `odeint` wraps for one trajectory and what sweeps / benchmarks call directly for
+B trajectories (per-trajectory rate parameters, per-trajectory or shared protocols, shared MLP weights).
+"""
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import capi
+
+_packed_cache = {}
+
+
+def _dev(device=None):
+    if not torch.cuda.is_available():
+        raise capi.IonodeError("no HIP device visible: the integrator has no CPU fallback")
+    if device is None:
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device(device)
+
+
+def _to(x, dtype, dev):
+    if x is None:
+        return None
+    if isinstance(x, torch.Tensor):
+        return x.to(device=dev, dtype=dtype).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(x))).to(device=dev, dtype=dtype).contiguous()
+
+
+def packed_weights(weights, mlp_layers, mlp_width, dev, key=None):
+    """Device-resident MFMA-order image of a flat fp32 state dict; cached per (key, device)."""
+    ck = (key, mlp_layers, mlp_width, str(dev)) if key is not None else None
+    if ck is not None and ck in _packed_cache:
+        return _packed_cache[ck]
+    if isinstance(weights, torch.Tensor):
+        weights = weights.detach().cpu().numpy()
+    img = torch.from_numpy(capi.mlp_pack(weights, mlp_layers, mlp_width)).to(dev)
+    if ck is not None:
+        if len(_packed_cache) > 16:
+            _packed_cache.clear()
+        _packed_cache[ck] = img
+    return img
+
+
+@dataclass
+class Solution:
+    y: torch.Tensor                 # [B, Nt, D] state dtype, on device
+    i: Optional[torch.Tensor]       # [B, Nt] fp64 current trace or None
+    status: torch.Tensor            # [B] int32
+    stats: Optional[torch.Tensor]   # [B, 4] int64: accepted, rejected, nfe, status
+    kernel: str
+
+    def raise_on_failure(self):
+        st = self.status.cpu().numpy()
+        bad = np.nonzero(st)[0]
+        if bad.size:
+            b = int(bad[0])
+            # torchdiffeq raises AssertionError with these messages
+            raise AssertionError(f"{capi.STATUS_TEXT[int(st[b])]} (trajectory {b}; {bad.size} of {st.size} failed)")
+
+
+def solve(model, params, prot_v, y0, t_eval, *, weights=None, mlp_layers=0, mlp_width=0, weights_key=None,
+          prot_t=None, prot_t0=0.0, prot_dt=1.0, prot_of_traj=None, state_dtype=None, rtol=1e-7, atol=1e-9,
+          v_oob=-80.0, max_steps=0, current=False, obs_g=1.0, obs_e=-86.0, obs_open_state_only=False,
+          tile_waves=0, device=None, step_log=None) -> Solution:
+    """Integrate B trajectories on the GPU (asynchronous on the current stream).
+
+    params [B, 8|12] (or [8|12] -> B = 1), prot_v [P, Np] (or [Np]), y0 [B, D] / [D] (broadcast over B),
+    t_eval [Nt].  state_dtype: torch.float32 (reference-compatible) or torch.float64; default = y0's dtype if it
+    is a floating torch tensor, else float64.
+    """
+    dev = _dev(device)
+    params_t = _to(params, torch.float64, dev)
+    if params_t.dim() == 1:
+        params_t = params_t[None, :].contiguous()
+    B = params_t.shape[0]
+    prot_v_t = _to(prot_v, torch.float64, dev)
+    if prot_v_t.dim() == 1:
+        prot_v_t = prot_v_t[None, :].contiguous()
+    if state_dtype is None:
+        state_dtype = y0.dtype if isinstance(y0, torch.Tensor) and y0.dtype in (torch.float32, torch.float64) else torch.float64
+    y0_t = _to(y0, state_dtype, dev)
+    if y0_t.dim() == 1:
+        y0_t = y0_t[None, :]
+    if y0_t.shape[0] != B:
+        y0_t = y0_t.expand(B, y0_t.shape[1])
+    y0_t = y0_t.contiguous()
+    t_eval_t = _to(t_eval, torch.float64, dev)
+    packed = None
+    if model in (capi.MODEL_NNF, capi.MODEL_NND):
+        if weights is None:
+            raise capi.IonodeError("NN models need `weights` (flat fp32 state dict)")
+        packed = packed_weights(weights, mlp_layers, mlp_width, dev, key=weights_key)
+    r = capi.dopri5(model, params_t, prot_v_t, y0_t, t_eval_t, mlp_packed=packed, mlp_layers=mlp_layers,
+                    mlp_width=mlp_width, prot_t=_to(prot_t, torch.float64, dev), prot_t0=prot_t0, prot_dt=prot_dt,
+                    prot_of_traj=_to(prot_of_traj, torch.int32, dev), rtol=rtol, atol=atol, v_oob=v_oob,
+                    max_steps=max_steps, current=current, obs_g=obs_g, obs_e=obs_e,
+                    obs_open_state_only=obs_open_state_only, tile_waves=tile_waves, step_log=step_log)
+    return Solution(y=r["y"], i=r["i"], status=r["status"], stats=r["stats"], kernel=capi.kernel_name(r["desc"]))

@@ -1,0 +1,71 @@
+"""Drop-in `odeint(func, y0, t)` with torchdiffeq's call signature (the reference's hot-path boundary).
+
+    from torchdiffeq import odeint            # train-s1.py:29-32 -> resolves to the shim at the repo root
+    pred_y = odeint(func, true_y0, prediction_t)                       # train-s1.py:327
+    o = odeint(self._ode, self._y0_torch, t, method='dopri5')          # train-d0.py:428
+
+Returns a tensor of shape (len(t), *y0.shape), dtype y0.dtype, on y0.device, as torchdiffeq does.  The reference's
+RHS modules (rhs.py) are integrated by the fused HIP kernel.  `func` is read at call time: the protocol set by
+`set_fixed_form_voltage_protocol` between calls and the current weights are picked up on every call.
+
+Failures raise AssertionError with torchdiffeq's messages ('underflow in dt', 'non-finite values in state `y`',
+'max_num_steps exceeded').  There is no CPU fallback for recognised modules: without a HIP device the call raises.
+Modules that are not one of the reference's families raise UnrecognisedRhs unless the caller opts into the
+generic torch stepper with options={'allow_generic': True} (same algorithm, `func.forward` called from Python).
+"""
+import warnings
+
+import numpy as np
+import torch
+
+from . import batched, capi, rhs
+from .generic import generic_dopri5
+
+_KNOWN_OPTIONS = {"allow_generic", "explicit_protocol", "max_num_steps", "tile_waves",
+                  # torchdiffeq 0.1.x-era keys the reference passes in train-d0.py:436; 0.2.x warns and ignores them
+                  "grid_points", "eps"}
+
+
+def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, event_fn=None):
+    if event_fn is not None:
+        raise NotImplementedError("event handling is not part of the reference's path")
+    if method not in (None, "dopri5"):
+        raise NotImplementedError(f"method={method!r}: the reference only ever runs dopri5 (SURVEY.md section 5)")
+    if not isinstance(y0, torch.Tensor) or not isinstance(t, torch.Tensor):
+        raise TypeError("y0 and t must be torch tensors")
+    if t.dim() != 1 or t.numel() < 1:
+        raise ValueError("t must be a 1-D tensor")
+    options = dict(options or {})
+    unknown = set(options) - _KNOWN_OPTIONS
+    if unknown:
+        warnings.warn(f"odeint: unexpected options {sorted(unknown)} ignored")
+    if "grid_points" in options or "eps" in options:
+        warnings.warn("odeint: 'grid_points'/'eps' are torchdiffeq 0.1.x options; ignored (0.2.1 ignores them too)")
+    if y0.dtype not in (torch.float32, torch.float64):
+        raise TypeError("y0 must be float32 or float64")
+
+    try:
+        spec = rhs.recognise(func, y0, force_explicit_protocol=bool(options.get("explicit_protocol", False)))
+    except rhs.UnrecognisedRhs as e:
+        if options.get("allow_generic", False):
+            return generic_dopri5(func, y0, t, rtol=rtol, atol=atol, max_steps=options.get("max_num_steps", 2**31 - 1))
+        raise rhs.UnrecognisedRhs(
+            f"odeint: func is not one of the reference's RHS families ({e}); pass options={{'allow_generic': True}} "
+            "to integrate it with the generic torch stepper") from None
+
+    sol = batched.solve(spec.model, spec.params, spec.prot_v, y0.reshape(1, -1), t.detach().to(torch.float64),
+                        weights=spec.weights, mlp_layers=spec.mlp_layers, mlp_width=spec.mlp_width,
+                        weights_key=spec.weights_key, prot_t=spec.prot_t, prot_t0=spec.prot_t0, prot_dt=spec.prot_dt,
+                        state_dtype=y0.dtype, rtol=float(rtol), atol=float(atol),
+                        max_steps=int(options.get("max_num_steps", 0)), tile_waves=int(options.get("tile_waves", 0)))
+    sol.raise_on_failure()
+    out = sol.y[0].reshape((t.numel(),) + tuple(y0.shape))
+    return out.to(y0.device)
+
+
+def odeint_adjoint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, event_fn=None,
+                   adjoint_rtol=None, adjoint_atol=None, adjoint_method=None, adjoint_options=None, adjoint_params=None):
+    """The reference's --adjoint flag only switches this import (train-s1.py:29-32); every call site runs under
+    torch.no_grad() and never differentiates through the solve (SURVEY.md finding 3).  Forward values are identical
+    to odeint; the result carries no autograd graph."""
+    return odeint(func, y0, t, rtol=rtol, atol=atol, method=method, options=options, event_fn=event_fn)

@@ -1,0 +1,138 @@
+"""-m gpu: shape coverage and edge cases through the C ABI, each against the oracle bit for bit; plus
+size-independent properties at BASELINE.json's full sizes (N_p = N_t = 100 001)."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+import kat_cases as K
+from gpu_util import run_gpu
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_weights(L, N, seed):
+    rng = np.random.default_rng(seed)
+    n = 2 * N + N + L * (N * N + N) + N + 1
+    return (rng.normal(0, 0.1, n)).astype(np.float32)
+
+
+def _same(g, o):
+    assert np.array_equal(g["status"], o["status"])
+    assert np.array_equal(g["stats"], o["stats"])
+    assert np.array_equal(g["y"], o["y"], equal_nan=True)
+
+
+@pytest.mark.parametrize("L,N", [(5, 10), (1, 10), (10, 10), (1, 100), (5, 100), (1, 200), (10, 200), (1, 500)])
+@pytest.mark.parametrize("model", [K.MODEL_NNF, K.MODEL_NND])
+def test_architectures_s00_to_s11(ion, gpu, oracle, L, N, model):
+    """Every (n_layers, n_nodes) of architectures/s00-s11.py except the two 500-wide deep ones (s06, s08: same kernel
+    as s07, only slower on the oracle): random-init weights N(0, 0.1^2) as train-s1.py:202-205."""
+    if model == K.MODEL_NND and (L, N) not in ((5, 10), (1, 100), (10, 200)):
+        pytest.skip("NN-d shares the MLP path; three shapes suffice")
+    w = _rand_weights(L, N, 100 * L + N)
+    pv = np.stack([K.atau(30)[1], K.atau(300)[1]])
+    te = K.atau(30)[2][:1501]
+    B = 18
+    params = np.tile(K.P_HH, (B, 1)) * np.random.default_rng(3).uniform(0.9, 1.1, (B, 8))
+    kw = dict(prot_t0=0.0, prot_dt=1.0, prot_of_traj=(np.arange(B) % 2).astype(np.int32), max_steps=4000)
+    g = run_gpu(ion, gpu, model, params, pv, K.NN_Y0, te, weights=w, L=L, N=N, **kw)
+    o = oracle.solve(model, params, pv, K.NN_Y0, te, weights=w, mlp_layers=L, mlp_width=N, **kw)
+    _same(g, o)
+
+
+@pytest.mark.parametrize("B", [1, 15, 16, 17, 63, 64, 65, 130])
+def test_ragged_batches(ion, gpu, oracle, B):
+    """Batch sizes around the tile sizes (16 trajectories per MLP tile, 64 per closed-form wavefront)."""
+    rng = np.random.default_rng(B)
+    pv = K.deactivation(-90)[1][None, :]
+    te = K.deactivation(0)[2][:1001]
+    params = K.P_HH[None, :] * rng.uniform(0.8, 1.2, (B, 8))
+    kw = dict(prot_t0=0.0, prot_dt=1.0)
+    _same(run_gpu(ion, gpu, K.MODEL_HH2, params, pv, [0.0, 1.0], te, **kw),
+          oracle.solve(K.MODEL_HH2, params, pv, [0.0, 1.0], te, **kw))
+    if B <= 65:
+        w = K.load_weights("s2")
+        te2 = te[:301]
+        _same(run_gpu(ion, gpu, K.MODEL_NND, params, pv, K.NN_Y0, te2, weights=w, L=5, N=200, **kw),
+              oracle.solve(K.MODEL_NND, params, pv, K.NN_Y0, te2, weights=w, mlp_layers=5, mlp_width=200, **kw))
+
+
+def test_single_output_time_and_irregular_output_grid(ion, gpu, oracle):
+    pv = K.activation(0)[1]
+    kw = dict(prot_t0=0.0, prot_dt=1.0)
+    g = run_gpu(ion, gpu, K.MODEL_HH2, K.P_HH, pv, [0.0, 1.0], [5.0], **kw)
+    assert g["status"][0] == 0 and np.array_equal(g["y"][0, 0], [0.0, 1.0]) and g["stats"][0, 2] == 2
+    te = np.sort(np.random.default_rng(0).uniform(0, 7999, 700))
+    te[0] = 0.0
+    _same(run_gpu(ion, gpu, K.MODEL_HH2, K.P_HH, pv, [0.0, 1.0], te, **kw),
+          oracle.solve(K.MODEL_HH2, K.P_HH, pv, [0.0, 1.0], te, **kw))
+
+
+def test_output_times_beyond_the_protocol_use_the_hold_voltage(ion, gpu, oracle):
+    """t past the protocol's last sample: the reference's RHS substitutes -80 mV (train-s1.py:234-237)."""
+    pv = K.atau(100)[1][:3001]
+    te = np.linspace(0.0, 4000.0, 401)
+    for f32 in (False, True):
+        kw = dict(prot_t0=0.0, prot_dt=1.0)
+        _same(run_gpu(ion, gpu, K.MODEL_HH2, K.P_HH, pv, [0.0, 1.0], te, f32=f32, **kw),
+              oracle.solve(K.MODEL_HH2, K.P_HH, pv, [0.0, 1.0], te, state_f32=f32, **kw))
+
+
+def test_failed_trajectories_do_not_disturb_their_tile(ion, gpu, oracle):
+    """NaN start, max-steps and healthy trajectories in the same tile: status codes, NaN tails, neighbours intact."""
+    B = 20
+    params = np.tile(K.P_HH, (B, 1))
+    y0 = np.tile([0.0, 1.0], (B, 1))
+    y0[3, 0] = np.nan
+    y0[17, 1] = np.inf
+    pv = K.activation(40)[1]
+    te = K.activation(0)[2][:2001]
+    w = K.load_weights("s1")
+    kw = dict(prot_t0=0.0, prot_dt=1.0, max_steps=150)
+    g = run_gpu(ion, gpu, K.MODEL_NNF, params, pv, y0, te, weights=w, L=5, N=200, **kw)
+    o = oracle.solve(K.MODEL_NNF, params, pv, y0, te, weights=w, mlp_layers=5, mlp_width=200, **kw)
+    _same(g, o)
+    assert set(np.unique(g["status"])) >= {1, 3} and np.isnan(g["y"][3, 1:]).all()
+
+
+@pytest.mark.parametrize("model,y0,open_only", [(K.MODEL_HH2, [0.0, 1.0], False), (K.MODEL_MARKOV6, [0, 1.0, 0, 0, 0, 0], True)])
+def test_fused_current_epilogue(ion, gpu, oracle, model, y0, open_only):
+    """i = g * gate * (V(t_k) - E) fused into the dense-output store (train-s1.py:328, train-r1.py:274, train-d1.py:299)."""
+    pt, pv, te = K.ap2hz()
+    p = K.P_HH if model == K.MODEL_HH2 else K.P_M6
+    g_, e_ = 0.133898199260611944 * 1.2, float(np.float32(-88.4 - 5))  # train-r1.py:43-47
+    for f32 in (False, True):
+        g = run_gpu(ion, gpu, model, p, pv, y0, te, f32=f32, prot_t=pt, current=True, obs_g=g_, obs_e=e_,
+                    obs_open_state_only=open_only)
+        o = oracle.solve(model, p, pv, y0, te, prot_t=pt, state_f32=f32)
+        v, _ = oracle.protocol_v(pv, te, prot_t=pt)
+        want = oracle.current(o["y"][0], v, g=g_, e_rev=e_, open_state_only=open_only, state_f32=f32)
+        assert np.array_equal(g["y"], o["y"]) and np.array_equal(g["i"][0], want)
+
+
+def test_full_size_properties(ion, gpu, oracle):
+    """BASELINE sizes (N_p = N_t = 100 001, 0.1 ms): properties that do not need a full-size oracle run.
+    (1) tile composition does not matter: any trajectory gives the same bits alone, in another slot, or in a
+        different batch;  (2) steps are never clipped to output times, so a 10x coarser output grid returns exactly
+        the matching samples;  (3) the current trace equals g*a*r*(V - E) recomputed from the returned states;
+    (4) a spot check of 3 trajectories against the oracle at full size."""
+    P = importlib.import_module("neural-ode-ion-channels_amd.protocols")
+    B, Nt = 40, 100001
+    pv = P.sinewave(P.sinewave_scales(0, B), n_samples=Nt)
+    te = np.arange(Nt) * 0.1
+    w = K.load_weights("s1")
+    params = np.tile(K.P_HH, (B, 1))
+    kw = dict(prot_t0=0.0, prot_dt=0.1)
+    g = run_gpu(ion, gpu, K.MODEL_NNF, params, pv, K.NN_Y0, te, weights=w, L=5, N=200, current=True, **kw)
+    assert (g["status"] == 0).all()
+    perm = np.random.default_rng(0).permutation(B)[:23]
+    g2 = run_gpu(ion, gpu, K.MODEL_NNF, params[perm], pv[perm], K.NN_Y0, te, weights=w, L=5, N=200, **kw)
+    assert np.array_equal(g2["y"], g["y"][perm]) and np.array_equal(g2["stats"], g["stats"][perm])
+    g3 = run_gpu(ion, gpu, K.MODEL_NNF, params[:5], pv[:5], K.NN_Y0, te[::10], weights=w, L=5, N=200, **kw)
+    assert np.array_equal(g3["y"], g["y"][:5, ::10]) and np.array_equal(g3["stats"], g["stats"][:5])
+    v = np.stack([oracle.protocol_v(pv[b], te, prot_t0=0.0, prot_dt=0.1)[0] for b in range(4)])
+    assert np.array_equal(g["i"][:4], (g["y"][:4, :, 0] * g["y"][:4, :, 1]) * (v + 86.0))
+    o = oracle.solve(K.MODEL_NNF, params[:3], pv[:3], K.NN_Y0, te, weights=w, mlp_layers=5, mlp_width=200, nthreads=3, **kw)
+    assert np.array_equal(g["y"][:3], o["y"]) and np.array_equal(g["stats"][:3], o["stats"])
