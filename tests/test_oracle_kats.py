@@ -123,3 +123,27 @@ def test_batch_is_trajectory_independent(oracle):
     for b in range(6):
         r1 = oracle.solve(K.MODEL_HH2, params[b], pv[pot[b]], [0.0, 1.0], te, prot_t0=0.0, prot_dt=1.0)
         assert np.array_equal(r1["y"][0], rb["y"][b]) and np.array_equal(r1["stats"][0], rb["stats"][b])
+
+
+def test_deterministic_exp_and_fifth_root_accuracy(oracle):
+    """det_exp / det_root5 (shared operation sequences of oracle and kernels): within 1 ulp of
+    libm's exp and within 2 ulp of the exact fifth root over the ranges the path uses (and well beyond)."""
+    import ctypes
+    import math
+    from decimal import Decimal, getcontext
+
+    lib = oracle.lib()
+    lib.det_exp.restype = ctypes.c_double
+    lib.det_exp.argtypes = [ctypes.c_double]
+    lib.det_root5.restype = ctypes.c_double
+    lib.det_root5.argtypes = [ctypes.c_double]
+    rng = np.random.default_rng(0)
+    for x in np.concatenate([rng.uniform(-20, 20, 20000), rng.uniform(-700, 700, 2000), [0.0, -0.0, 1e-300]]):
+        a, b = lib.det_exp(float(x)), math.exp(float(x))
+        assert abs(a - b) <= np.spacing(b), x
+    assert lib.det_exp(710.0) == math.inf and lib.det_exp(-746.0) == 0.0 and math.isnan(lib.det_exp(math.nan))
+    getcontext().prec = 40
+    for x in 10.0 ** rng.uniform(-14, 14, 1500):
+        a = lib.det_root5(float(x))
+        exact = Decimal(float(x)) ** (Decimal(1) / Decimal(5))
+        assert abs(Decimal(a) - exact) <= 2 * Decimal(float(np.spacing(a))), x
