@@ -158,7 +158,9 @@ def main():
                                "N_p = N_t = %d, rtol 1e-7 atol 1e-9" % Nt,
                    "trajectories_per_gpu": B, "global_batch": world * B, "parallelism": f"traj-shard x{world}",
                    "kernel": capi.kernel_name(r["desc"]), "geometry": capi.launch_geometry(r["desc"]),
-                   "mean_nfe": float(nfe.mean()), "mean_accepted": float(stats[:, 0].mean()),
+                   "mean_nfe": float(nfe.mean()), "max_nfe": float(nfe.max()),
+                   "us_per_rhs_eval_slowest_tile": kern_ms * 1e3 / float(nfe.max()),
+                   "mean_accepted": float(stats[:, 0].mean()),
                    "mean_rejected": float(stats[:, 1].mean()), "trajectories_ok": n_ok, "loss": float(loss.item())},
         "roofline": {"bound": "mfma", "achieved": tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                      "frac": tflops / PEAK_FP32_TFLOPS, "traffic": None,

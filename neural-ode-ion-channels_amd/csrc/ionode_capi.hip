@@ -64,7 +64,7 @@ int make_plan(const ionode_desc *d, Plan *pl) {
     pl->grid = (unsigned)((d->n_traj + 15) / 16);
     pl->block = 64u * pl->v->G;
     const int Gv = pl->v->G, Rv = NT - Gv * (NT / Gv);  // remainder row tiles: K-split partial sums in LDS
-    pl->lds = ((size_t)2 * NT * 64 + (size_t)2 * Rv * Gv * 64 + NP) * 16 + ((size_t)d->mlp_layers * NP + NP + 4) * 4;
+    pl->lds = ((size_t)2 * NT * 64 + (size_t)3 * Rv * Gv * 64 + NP) * 16 + ((size_t)d->mlp_layers * NP + NP + 4) * 4;
   }
   if (!pl->v) { set_err("no kernel variant compiled for this descriptor"); return IONODE_ERR_UNSUPPORTED; }
   return IONODE_OK;
@@ -86,11 +86,17 @@ static bool tile_shape(int N, int *G, int *RT) {
   return true;
 }
 
+// 1 KiB fragments per wavefront per hidden layer: F per step, + R on the steps s % G == 0 (K-slices of the remainder tiles)
+static size_t frags_per_wave(int NT, int G) {
+  const int F = NT / G, R = NT - G * F, NOWN = (NT + G - 1) / G;
+  return (size_t)NT * F + (size_t)NOWN * R;
+}
+
 size_t ionode_mlp_packed_floats(int32_t L, int32_t N) {
   int G, RT;
   if (L < 0 || N < 1 || !tile_shape(N, &G, &RT)) return 0;
   const size_t NP = (size_t)np_of(N), NT = NP / 16;
-  return 4 * NP + (size_t)L * ((size_t)G * NT * RT * 256 + NP) + NP + 4 + 256;  // + 1 KiB zero block
+  return 4 * NP + (size_t)L * ((size_t)G * frags_per_wave((int)NT, G) * 256 + NP) + NP + 4;
 }
 
 int ionode_mlp_pack(const float *w, int32_t L, int32_t N, float *out) {
@@ -108,30 +114,37 @@ int ionode_mlp_pack(const float *w, int32_t L, int32_t N, float *out) {
   }
   const float *src = b0 + N;
   float *dst = out + 4 * (size_t)NP;
-  const size_t frag_floats = (size_t)G * NT * RT * 256;
+  const int F = NT / G, Rm = NT - G * F;
+  const size_t FR = frags_per_wave(NT, G);
+  const size_t frag_floats = (size_t)G * FR * 256;
   for (int l = 0; l < L; ++l) {
     const float *W = src, *b = src + (size_t)N * N;
     // A operand of v_mfma_f32_16x16x4_f32: lane = 16q + m supplies row 16*rt + m, k = 16*kt + 4*q + r.
-    // Stream order: wavefront wv | k-tile kt | RT = F + R float4 fragments | lane.  Fragments 0..F-1: the full row
-    // tiles wv + i*G, k-step-major (element e = r*F + i -> fragment e/4, component e%4).  Fragment F + j: remainder
-    // tile G*F + j, component = k-step r, only in wv's K-slice (kt % G == wv); zeros elsewhere (never loaded).
-    const int F = NT / G, Rm = NT - G * F;
-    for (int wv = 0; wv < G; ++wv)
-      for (int kt = 0; kt < NT; ++kt)
+    // Stream order: wavefront wv | step s, k-tile kt = (s + wv) mod NT | fragments | lane.  F fragments hold the full
+    // row tiles wv + i*G k-step-major (element e = r*F + i -> fragment e/4, component e%4); steps with s % G == 0 add
+    // one fragment per remainder tile G*F + j (component = k-step r), zero when the step wraps (s + wv >= NT).
+    for (int wv = 0; wv < G; ++wv) {
+      size_t pos = 0;  // fragment index inside this wavefront's layer stream
+      for (int st = 0; st < NT; ++st) {
+        const int kt = (st + wv) % NT;
         for (int lane = 0; lane < 64; ++lane) {
           const int m = lane & 15, q = lane >> 4;
-          float *frag0 = dst + ((((size_t)wv * NT + kt) * RT) * 64 + lane) * 4;
+          float *f0 = dst + (((size_t)wv * FR + pos) * 64 + lane) * 4;
           for (int e = 0; e < 4 * F; ++e) {
             const int r = e / F, i = e % F, rt = wv + i * G;
             const int row = 16 * rt + m, k = 16 * kt + 4 * q + r;
-            frag0[(size_t)(e / 4) * 256 + e % 4] = (row < N && k < N) ? W[(size_t)row * N + k] : 0.0f;
+            f0[(size_t)(e / 4) * 256 + e % 4] = (row < N && k < N) ? W[(size_t)row * N + k] : 0.0f;
           }
-          for (int j = 0; j < Rm; ++j)
-            for (int r = 0; r < 4; ++r) {
-              const int row = 16 * (G * F + j) + m, k = 16 * kt + 4 * q + r;
-              frag0[(size_t)(F + j) * 256 + r] = (kt % G == wv && row < N && k < N) ? W[(size_t)row * N + k] : 0.0f;
-            }
+          if (Rm > 0 && st % G == 0)
+            for (int j = 0; j < Rm; ++j)
+              for (int r = 0; r < 4; ++r) {
+                const int row = 16 * (G * F + j) + m, k = 16 * kt + 4 * q + r;
+                f0[(size_t)(F + j) * 256 + r] = (st + wv < NT && row < N && k < N) ? W[(size_t)row * N + k] : 0.0f;
+              }
         }
+        pos += F + ((Rm > 0 && st % G == 0) ? Rm : 0);
+      }
+    }
     float *bias = dst + frag_floats;
     for (int r = 0; r < N; ++r) bias[r] = b[r];
     src += (size_t)N * N + N;

@@ -215,21 +215,23 @@ __device__ __forceinline__ float lrelu(float x) { return fmaxf(x, x * 0.01f); }
 // of the R = NT - G*F REMAINDER row tiles (rt = G*F + j).  For N = 200 (NT = 13, G = 4) that is 3*13 + 13/4 tile
 // products per wavefront instead of 4*13 on the critical wavefront.  The K-slices of a remainder tile are
 // partial sums; they meet in LDS and every wavefront folds them itself after the layer barrier.
+// Wavefront w walks the k-tiles in the rotated order kt = (s + w) mod NT, s = 0..NT-1, so that "this step carries my
+// K-slice" is the compile-time predicate s % G == 0 (plus s + w < NT on the last such step) instead of a branch per
+// k-step, and the weight stream of a wavefront has a static shape.
 //
 // Canonical accumulation order (the oracle executes exactly this; DESIGN.md "canonical MLP order"):
 //   k index of (k-tile kt, k-step r, lane group q):  k = 16*kt + 4*q + r        (accumulator layout == B operand layout)
-//   full tile rows:       acc = bias; for kt = 0..NT-1: for r: for q: acc = fmaf(W[row][k], h[k], acc)
+//   full tile rows:       acc = bias; for s = 0..NT-1, kt = (s + rt % G) mod NT: for r: for q: acc = fmaf(W[row][k], h[k], acc)
 //   remainder tile rows:  p_w = (w == 0 ? bias : 0); for kt with kt % G == w, ascending: for r: for q: p_w = fmaf(...)
 //                         acc = (p_0 + p_1) + (p_2 + p_3)                            (G = 4; G = 1 has no remainder)
 //   Linear(N, 1):         part_q = 0; for kt: for r: part_q = fmaf(wl[k], h[k], part_q);
 //                         out = ((part_0 + part_1) + (part_2 + part_3)) + bl
 //
 // Weight streaming.  The A fragments of the hidden layers are the only global traffic of the MLP.  Stream order
-// (ionode_mlp_pack): layer | wavefront w | k-tile kt | RT = F + R float4 fragments | lane.  Fragments 0..F-1 hold
-// the full tiles k-step-major (element e = r*F + i -> float4 e/4, component e%4: the F MFMAs of a k-step read one
-// float4 when F = 4); fragment F + j holds remainder tile G*F + j (components = k-steps r) and exists only in
-// wavefront w's K-slice (kt % G == w): elsewhere the kernel points that load at the image's 1 KiB zero block,
-// which stays L1-resident, so the padding costs no L2 bandwidth.  Fragments are consumed from a register ring
+// (ionode_mlp_pack): layer | wavefront w | step s (k-tile (s + w) mod NT) | fragments | lane.  Every step has F
+// fragments holding the full tiles k-step-major (element e = r*F + i -> float4 e/4, component e%4); steps with
+// s % G == 0 carry R more, one per remainder tile (components = k-steps r; zeros when s + w >= NT).
+// Fragments are consumed from a register ring
 // refilled PD k-tiles ahead (PD == NT: a whole layer ahead) with SRSRC buffer loads issued right behind the last
 // MFMA that reads them, pinned with sched_barrier so the machine scheduler neither sinks them to the end of the
 // layer nor bunches them into an MFMA-free gap.  The kernel sits at the balance point of fp32-MFMA rate and per-CU
@@ -247,9 +249,14 @@ struct MlpTile {
   static_assert(RT == F + R, "RT = full + remainder tile slots per wavefront");
   static_assert((4 * RT) % 4 == 0 && (RT == 1 || RT == 2 || RT == 4 || RT == 8), "fragment = RT float4 per k-tile");
   static_assert(R == 0 || G == 4, "the remainder combine tree is written for 4 wavefronts");
-  f32x4 ring[PD][RT];
+  static constexpr int NOWN = (NT + G - 1) / G;      // steps s = 0, G, 2G, ... carry a K-slice of the remainder tiles
+  static constexpr int FRAGS = NT * F + NOWN * R;    // 1 KiB fragments per wavefront per layer
+  // ring slot of step u (blocked scheme: step kt0 + u): F full fragments (+ R remainder fragments when owned)
+  f32x4 ring[PD][F > 0 ? F : 1];
+  f32x4 rrem[R > 0 ? (PD + G - 1) / G : 1][RP];
   f32x4 *Hs;          // LDS [2][NT*64] activations after LeakyReLU, accumulator layout (full tiles only)
   f32x4 *Ps;          // LDS [2][R][G][64] partial sums of the remainder tiles (pre-activation)
+  f32x4 *Hp;          // LDS [G][R][64] this wavefront's own folded copy of the remainder activations
   const f32x4 *W0s;   // LDS [NP] {b0, w00, w01, 0}
   const float *biasS; // LDS [L][NP]
   const float *wlS;   // LDS [NP] + bl
@@ -257,7 +264,6 @@ struct MlpTile {
   unsigned voff;      // per lane: byte offset of (this wavefront's stream, lane) inside a hidden layer
   unsigned hid0;      // byte offset of hidden layer 0 in the image
   unsigned lbytes;    // bytes per hidden layer in the image
-  unsigned zoff;      // soffset that makes voff address the zero block (wave-uniform)
   int L, wave, lane;
 #ifdef IONODE_STAMPS
   Stamps *sp;
@@ -266,16 +272,19 @@ struct MlpTile {
 #define MSTAMP(slot) do { } while (0)
 #endif
 
-  static __host__ __device__ constexpr size_t layer_floats() { return (size_t)G * NT * RT * 256 + NP; }
+  static __host__ __device__ constexpr size_t layer_floats() { return (size_t)G * FRAGS * 256 + NP; }
+  // index of step s's first fragment in a wavefront's layer stream
+  static __host__ __device__ constexpr int step_base(int s) { return s * F + R * ((s + G - 1) / G); }
   static __host__ __device__ constexpr size_t lds_bytes(int L) {
-    return ((size_t)2 * NT * 64 + (size_t)2 * R * G * 64 + NP) * 16 + ((size_t)L * NP + NP + 4) * 4;
+    return ((size_t)2 * NT * 64 + (size_t)3 * R * G * 64 + NP) * 16 + ((size_t)L * NP + NP + 4) * 4;
   }
 
   __device__ __forceinline__ void init(const KArgs &a, unsigned char *smem, int wave_, int lane_) {
     L = a.L; wave = wave_; lane = lane_;
     Hs = reinterpret_cast<f32x4 *>(smem);
     Ps = Hs + 2 * NT * 64;
-    f32x4 *w0 = Ps + 2 * R * G * 64;
+    Hp = Ps + 2 * R * G * 64 + wave_ * R * 64;
+    f32x4 *w0 = Ps + 3 * R * G * 64;
     float *bs = reinterpret_cast<float *>(w0 + NP);
     float *ws = bs + (size_t)L * NP;
     constexpr size_t lstride = layer_floats();
@@ -286,28 +295,28 @@ struct MlpTile {
     const float *wl = a.mlp + 4 * (size_t)NP + (size_t)L * lstride;
     for (int i = tid; i < NP + 4; i += 64 * G) ws[i] = wl[i];
     W0s = w0; biasS = bs; wlS = ws;
-    const size_t zero_byte = (4 * (size_t)NP + (size_t)L * lstride + NP + 4) * 4;  // zero block follows wl / bl
-    const size_t img_bytes = zero_byte + 1024;
+    const size_t img_bytes = (4 * (size_t)NP + (size_t)L * lstride + NP + 4) * 4;
     rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.mlp), 0, (int)img_bytes, 0x00020000);
-    voff = (unsigned)(wave * NT * RT * 1024 + lane * 16);
+    voff = (unsigned)(wave * FRAGS * 1024 + lane * 16);
     hid0 = (unsigned)(4 * NP * 4);
     lbytes = (unsigned)(lstride * 4);
-    zoff = (unsigned)zero_byte - (unsigned)(wave * NT * RT * 1024);
-    // prime the ring with the first PD k-tiles of hidden layer 0
+    // prime the ring with the first PD steps of hidden layer 0
 #pragma unroll
-    for (int u = 0; u < PD; ++u)
+    for (int u = 0; u < PD; ++u) {
 #pragma unroll
-      for (int j = 0; j < RT; ++j) ring[u][j] = frag(hid0, u, j);
+      for (int j = 0; j < F; ++j) ring[u][j] = frag(hid0, step_base(u) + j);
+      if (R > 0 && u % G == 0) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) rrem[u / G][j] = frag(hid0, step_base(u) + F + j);
+      }
+    }
     __syncthreads();
   }
 
-  // one 1 KiB fragment (64 lanes x float4): fragment j of k-tile kt of the layer at byte offset `lbase`.
-  // A remainder fragment outside this wavefront's K-slice is never read by an MFMA: load the zero block instead.
-  __device__ __forceinline__ f32x4 frag(unsigned lbase, int kt, int j) const {
+  // one 1 KiB fragment (64 lanes x float4): fragment n of this wavefront's stream of the layer at byte offset `lbase`
+  __device__ __forceinline__ f32x4 frag(unsigned lbase, int n) const {
     using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
-    unsigned soff = lbase + (unsigned)(kt * RT + j) * 1024u;
-    if (R > 0 && j >= F && (kt % G) != wave) soff = zoff;
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, lbase + (unsigned)n * 1024u, 0);
     return __builtin_bit_cast(f32x4, v);
   }
 
@@ -355,10 +364,15 @@ struct MlpTile {
       // hipcc's wait-count pass lose the age of the loads and drain them all at every use)
       const unsigned lcur = hid0 + (unsigned)l * lbytes, lnext = hid0 + (unsigned)ln * lbytes;
 
-      // B operands of the remainder k-tiles: layer 0 wrote them as ordinary tiles, hidden layers as partial sums
-      f32x4 brem[RP];
+      // B operands of the remainder k-tiles: layer 0 wrote them as ordinary tiles; hidden layers leave partial sums,
+      // which every wavefront folds into its OWN LDS slot (no barrier: written and read by the same wavefront).
+      // The fold is needed first at step G*F - wave; when that is late enough it runs behind the MFMAs of step 0.
+      constexpr bool LAZY_FOLD = (R > 0) && (G * F - (G - 1) >= 3);
+      const f32x4 *__restrict__ Hrem = (l == 0) ? Hin + G * F * 64 : Hp;  // [R][64] either way
+      if (R > 0 && !LAZY_FOLD && l > 0) {
 #pragma unroll
-      for (int j = 0; j < R; ++j) brem[j] = (l == 0) ? Hin[(G * F + j) * 64 + lane] : remainder_h(Pin, j);
+        for (int j = 0; j < R; ++j) Hp[j * 64 + lane] = remainder_h(Pin, j);
+      }
 
       f32x4 acc[F > 0 ? F : 1], accr[RP];
 #pragma unroll
@@ -370,20 +384,29 @@ struct MlpTile {
         accr[j] = (wave == 0) ? bz : f32x4{0, 0, 0, 0};  // partial sum 0 carries the bias
       }
       for (int kt0 = 0; kt0 < NT; kt0 += PD) {
+        static_assert(R == 0 || PD == NT, "remainder tiles need the full-layer ring (static step index)");
         const bool same_layer = kt0 + PD < NT;
-        // (frag() needs the true k-tile index for the K-slice test; with R > 0 the scheme is PD == NT, kt0 == 0)
-        const unsigned lref = same_layer ? lcur + (unsigned)(kt0 + PD) * RT * 1024u : lnext;
-        f32x4 b_nxt = Hin[kt0 * 64 + lane];
-        MSTAMP(8);  // slot 8: layer prologue (bias, remainder fold, first B read)
+        // stream position of the refills issued in this block: same layer, PD steps ahead, or the next layer's start
+        const unsigned lref = same_layer ? lcur + (unsigned)step_base(kt0 + PD) * 1024u : lnext;
+        int kt = kt0 + wave;  // this wavefront's k-tile at step kt0 + u: (kt0 + u + wave) mod NT
+        if (kt >= NT) kt -= NT;
+        f32x4 b_nxt = (R > 0 && kt >= G * F) ? Hrem[(kt - G * F) * 64 + lane] : Hin[kt * 64 + lane];
+        MSTAMP(8);  // slot 8: layer prologue (bias, first B read)
 #pragma unroll
         for (int u = 0; u < PD; ++u) {
           if (u == 1) MSTAMP(9);       // slot 9: first k-tile
           if (u == PD - 1) MSTAMP(3);  // slot 3: k-tiles 1..PD-2
-          // k-tile index kt0 + u; with R > 0 the scheme is PD == NT, so kt == u is static
-          f32x4 b = b_nxt;
-          if (R > 0 && u >= G * F) b = brem[(u - G * F) < R ? (u - G * F) : 0];
-          if (u + 1 < PD && (R == 0 || u + 1 < G * F)) b_nxt = Hin[(kt0 + u + 1) * 64 + lane];  // LDS read one k-tile ahead
-          const bool own = (R > 0) && ((u % G) == wave);  // this wavefront's K-slice of the remainder tiles
+          const f32x4 b = b_nxt;
+          int kt_n = kt + 1;
+          if (kt_n >= NT) kt_n -= NT;
+          // LDS read one step ahead; remainder k-tiles come from the folded copy (an address select, not a data select)
+#ifndef IONODE_EXPERIMENT_NO_BREAD  // timing experiment only
+          if (u + 1 < PD) b_nxt = (R > 0 && kt_n >= G * F) ? Hrem[(kt_n - G * F) * 64 + lane] : Hin[kt_n * 64 + lane];
+#endif
+          // K-slice ownership: static, except that the last owned step wraps past NT for the higher wavefronts
+          const bool own_static = (R > 0) && (u % G == 0);
+          const bool own_always = own_static && (u + G - 1 < NT);
+          const bool own = own_static && (own_always || (u + wave < NT));
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -391,23 +414,30 @@ struct MlpTile {
               const int e = r * F + i;
               acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[u][e / 4][e % 4], b[r], acc[i], 0, 0, 0);
             }
-            if (own) {
+            if (own_static) {
+              if (own) {
 #pragma unroll
-              for (int j = 0; j < R; ++j)
-                accr[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[u][F + j][r], b[r], accr[j], 0, 0, 0);
+                for (int j = 0; j < R; ++j)
+                  accr[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(rrem[u / G][j][r], b[r], accr[j], 0, 0, 0);
+              }
             }
             // refill every fragment whose last reader was this k-step; pinned here (see header comment)
 #ifndef IONODE_EXPERIMENT_NO_REFILL  // timing experiment only: results are wrong for L > 1
 #pragma unroll
             for (int j = 0; j < F; ++j)
-              if ((4 * j + 3) / F == r) ring[u][j] = frag(lref, u, j);
-            if (r == 3) {
+              if ((4 * j + 3) / F == r) ring[u][j] = frag(lref, step_base(u) + j);
+            if (own_static && r == 3) {
 #pragma unroll
-              for (int j = 0; j < R; ++j) ring[u][F + j] = frag(lref, u, F + j);
+              for (int j = 0; j < R; ++j) rrem[u / G][j] = frag(lref, step_base(u) + F + j);
             }
 #endif
+            if (LAZY_FOLD && u == 0 && r == 0 && l > 0) {
+#pragma unroll
+              for (int j = 0; j < R; ++j) Hp[j * 64 + lane] = remainder_h(Pin, j);
+            }
             __builtin_amdgcn_sched_barrier(0);
           }
+          kt = kt_n;
         }
       }
       MSTAMP(10);  // slot 10: last k-tile

@@ -27,9 +27,9 @@
  *   - the MLP is fp32 always (`.float()`, train-s1.py:245).  Its accumulation order is not
  *     observable in the reference (it is whatever the CPU BLAS did); the oracle fixes it as
  *     an fmaf chain seeded with the bias, over k in the order
- *         for tile in 0..NT-1: for r in 0..3: for q in 0..3: k = 16*tile + 4*q + r
- *     with the width zero-padded to NP = 16*NT, NT = ceil(N/16).  Rows of the last NT mod 4 row tiles
- *     (NT > 1) are instead four chains over the k-tiles tile % 4 == w (chain 0 seeded with the bias),
+ *         for s in 0..NT-1, tile = (s + rowtile % 4) mod NT: for r in 0..3: for q in 0..3: k = 16*tile + 4*q + r
+ *     with the width zero-padded to NP = 16*NT, NT = ceil(N/16) (no rotation when NT = 1).  Rows of the last
+ *     NT mod 4 row tiles are instead four chains over the k-tiles tile % 4 == w (chain 0 seeded with the bias),
  *     folded (p0 + p1) + (p2 + p3); the final Linear(N, 1) is four chains (one per q, seeded with 0)
  *     combined as ((p0 + p1) + (p2 + p3)) + bias   (DESIGN.md "canonical MLP order").
  */
