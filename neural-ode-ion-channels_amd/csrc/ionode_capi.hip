@@ -64,7 +64,7 @@ int make_plan(const ionode_desc *d, Plan *pl) {
     pl->grid = (unsigned)((d->n_traj + 15) / 16);
     pl->block = 64u * pl->v->G;
     const int Gv = pl->v->G, Rv = NT - Gv * (NT / Gv);  // remainder row tiles: K-split partial sums in LDS
-    pl->lds = ((size_t)2 * NT * 64 + (size_t)3 * Rv * Gv * 64 + NP) * 16 + ((size_t)d->mlp_layers * NP + NP + 4) * 4;
+    pl->lds = ((size_t)2 * (NT + Gv - 1) * 64 + (size_t)2 * Rv * Gv * 64 + NP) * 16 + ((size_t)d->mlp_layers * NP + NP + 4) * 4;
   }
   if (!pl->v) { set_err("no kernel variant compiled for this descriptor"); return IONODE_ERR_UNSUPPORTED; }
   return IONODE_OK;

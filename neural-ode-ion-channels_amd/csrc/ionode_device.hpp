@@ -244,6 +244,7 @@ struct MlpTile {
   static constexpr int R = NT - G * F;   // remainder row tiles, K-split over the G wavefronts
   static constexpr int NP = 16 * NT;
   static constexpr int RP = (R > 0 ? R : 1);
+  static constexpr int HT = NT + G - 1;  // activation slots per buffer (see Hs)
   static_assert(NT % PD == 0, "ring depth must divide the k-tile count");
   static_assert(TAIL == 0, "tail scheme retired: the refills are interleaved with the MFMAs instead");
   static_assert(RT == F + R, "RT = full + remainder tile slots per wavefront");
@@ -254,9 +255,12 @@ struct MlpTile {
   // ring slot of step u (blocked scheme: step kt0 + u): F full fragments (+ R remainder fragments when owned)
   f32x4 ring[PD][F > 0 ? F : 1];
   f32x4 rrem[R > 0 ? (PD + G - 1) / G : 1][RP];
-  f32x4 *Hs;          // LDS [2][NT*64] activations after LeakyReLU, accumulator layout (full tiles only)
+  // LDS [2][HT*64] activations after LeakyReLU, accumulator layout.  HT = NT + G - 1 slots: tiles 0..G-2 are stored
+  // twice (slot kt and kt + NT) so that wavefront w reads its rotated sequence kt = (s + w) mod NT at the linear
+  // address base_w + s -- an immediate offset, no per-step address arithmetic.  Remainder-tile slots are filled by
+  // every wavefront itself (identical bits) when it folds the partial sums.
+  f32x4 *Hs;
   f32x4 *Ps;          // LDS [2][R][G][64] partial sums of the remainder tiles (pre-activation)
-  f32x4 *Hp;          // LDS [G][R][64] this wavefront's own folded copy of the remainder activations
   const f32x4 *W0s;   // LDS [NP] {b0, w00, w01, 0}
   const float *biasS; // LDS [L][NP]
   const float *wlS;   // LDS [NP] + bl
@@ -276,15 +280,14 @@ struct MlpTile {
   // index of step s's first fragment in a wavefront's layer stream
   static __host__ __device__ constexpr int step_base(int s) { return s * F + R * ((s + G - 1) / G); }
   static __host__ __device__ constexpr size_t lds_bytes(int L) {
-    return ((size_t)2 * NT * 64 + (size_t)3 * R * G * 64 + NP) * 16 + ((size_t)L * NP + NP + 4) * 4;
+    return ((size_t)2 * HT * 64 + (size_t)2 * R * G * 64 + NP) * 16 + ((size_t)L * NP + NP + 4) * 4;
   }
 
   __device__ __forceinline__ void init(const KArgs &a, unsigned char *smem, int wave_, int lane_) {
     L = a.L; wave = wave_; lane = lane_;
     Hs = reinterpret_cast<f32x4 *>(smem);
-    Ps = Hs + 2 * NT * 64;
-    Hp = Ps + 2 * R * G * 64 + wave_ * R * 64;
-    f32x4 *w0 = Ps + 3 * R * G * 64;
+    Ps = Hs + 2 * HT * 64;
+    f32x4 *w0 = Ps + 2 * R * G * 64;
     float *bs = reinterpret_cast<float *>(w0 + NP);
     float *ws = bs + (size_t)L * NP;
     constexpr size_t lstride = layer_floats();
@@ -332,7 +335,7 @@ struct MlpTile {
 
   __device__ __forceinline__ float eval(float x0, float x1) {
     const int q = lane >> 4;
-    constexpr int tstride = NT * 64;
+    constexpr int tstride = HT * 64;
     constexpr int pstride = R * G * 64;
     MSTAMP(0);  // slot 0: everything outside the MLP (RK scalar work, emission)
 
@@ -348,6 +351,7 @@ struct MlpTile {
           h[r] = lrelu(fmaf(w[2], x1, fmaf(w[1], x0, w[0])));
         }
         Hs[rt * 64 + lane] = h;
+        if (rt < G - 1) Hs[(rt + NT) * 64 + lane] = h;
       }
     }
     MSTAMP(1);  // slot 1: layer 0
@@ -355,7 +359,7 @@ struct MlpTile {
     MSTAMP(2);  // slot 2: barriers
 
     for (int l = 0; l < L; ++l) {
-      const f32x4 *__restrict__ Hin = Hs + (l & 1) * tstride;
+      f32x4 *__restrict__ Hin = Hs + (l & 1) * tstride;
       f32x4 *__restrict__ Hout = Hs + ((l + 1) & 1) * tstride;
       const f32x4 *__restrict__ Pin = Ps + (l & 1) * pstride;
       f32x4 *__restrict__ Pout = Ps + ((l + 1) & 1) * pstride;
@@ -365,15 +369,14 @@ struct MlpTile {
       const unsigned lcur = hid0 + (unsigned)l * lbytes, lnext = hid0 + (unsigned)ln * lbytes;
 
       // B operands of the remainder k-tiles: layer 0 wrote them as ordinary tiles; hidden layers leave partial sums,
-      // which every wavefront folds into its OWN LDS slot (no barrier: written and read by the same wavefront).
-      // The fold is needed first at step G*F - wave; when that is late enough it runs behind the MFMAs of step 0.
+      // which every wavefront folds into the remainder slots of the input buffer itself (identical bits from all
+      // wavefronts; each reads after its own write, so no barrier).  The fold is needed first at step G*F - wave;
+      // when that is late enough it runs behind the MFMAs of step 0 instead of in the layer prologue.
       constexpr bool LAZY_FOLD = (R > 0) && (G * F - (G - 1) >= 3);
-      const f32x4 *__restrict__ Hrem = (l == 0) ? Hin + G * F * 64 : Hp;  // [R][64] either way
       if (R > 0 && !LAZY_FOLD && l > 0) {
 #pragma unroll
-        for (int j = 0; j < R; ++j) Hp[j * 64 + lane] = remainder_h(Pin, j);
+        for (int j = 0; j < R; ++j) Hin[(G * F + j) * 64 + lane] = remainder_h(Pin, j);
       }
-
       f32x4 acc[F > 0 ? F : 1], accr[RP];
 #pragma unroll
       for (int i = 0; i < F; ++i)
@@ -388,20 +391,17 @@ struct MlpTile {
         const bool same_layer = kt0 + PD < NT;
         // stream position of the refills issued in this block: same layer, PD steps ahead, or the next layer's start
         const unsigned lref = same_layer ? lcur + (unsigned)step_base(kt0 + PD) * 1024u : lnext;
-        int kt = kt0 + wave;  // this wavefront's k-tile at step kt0 + u: (kt0 + u + wave) mod NT
-        if (kt >= NT) kt -= NT;
-        f32x4 b_nxt = (R > 0 && kt >= G * F) ? Hrem[(kt - G * F) * 64 + lane] : Hin[kt * 64 + lane];
+        // this wavefront's k-tile at step kt0 + u is (kt0 + u + wave) mod NT = slot kt0 + u + wave of the buffer
+        const f32x4 *__restrict__ Bw = Hin + (kt0 + wave) * 64 + lane;
+        f32x4 b_nxt = Bw[0];
         MSTAMP(8);  // slot 8: layer prologue (bias, first B read)
 #pragma unroll
         for (int u = 0; u < PD; ++u) {
           if (u == 1) MSTAMP(9);       // slot 9: first k-tile
           if (u == PD - 1) MSTAMP(3);  // slot 3: k-tiles 1..PD-2
           const f32x4 b = b_nxt;
-          int kt_n = kt + 1;
-          if (kt_n >= NT) kt_n -= NT;
-          // LDS read one step ahead; remainder k-tiles come from the folded copy (an address select, not a data select)
 #ifndef IONODE_EXPERIMENT_NO_BREAD  // timing experiment only
-          if (u + 1 < PD) b_nxt = (R > 0 && kt_n >= G * F) ? Hrem[(kt_n - G * F) * 64 + lane] : Hin[kt_n * 64 + lane];
+          if (u + 1 < PD) b_nxt = Bw[(u + 1) * 64];  // LDS read one step ahead, immediate offset
 #endif
           // K-slice ownership: static, except that the last owned step wraps past NT for the higher wavefronts
           const bool own_static = (R > 0) && (u % G == 0);
@@ -433,11 +433,10 @@ struct MlpTile {
 #endif
             if (LAZY_FOLD && u == 0 && r == 0 && l > 0) {
 #pragma unroll
-              for (int j = 0; j < R; ++j) Hp[j * 64 + lane] = remainder_h(Pin, j);
+              for (int j = 0; j < R; ++j) Hin[(G * F + j) * 64 + lane] = remainder_h(Pin, j);
             }
             __builtin_amdgcn_sched_barrier(0);
           }
-          kt = kt_n;
         }
       }
       MSTAMP(10);  // slot 10: last k-tile
@@ -447,6 +446,7 @@ struct MlpTile {
 #pragma unroll
         for (int r = 0; r < 4; ++r) h[r] = lrelu(acc[i][r]);
         Hout[(wave + i * G) * 64 + lane] = h;
+        if (wave + i * G < G - 1) Hout[(wave + i * G + NT) * 64 + lane] = h;
       }
 #pragma unroll
       for (int j = 0; j < R; ++j) Pout[(j * G + wave) * 64 + lane] = accr[j];
