@@ -1,9 +1,12 @@
 // Closed-form RHS kernels: HH 2-state and 6-state Markov, fp32 and fp64 state.
 #include "ionode_launch.hpp"
 namespace ionode {
+// 4th parameter (RT slot) = trajectories per wavefront: 0 -> 64 (one per lane), 16 -> 16 (small batches)
 static const Variant kTab[] = {
-    IONODE_VARIANT(0, double, 0, 1, 0, 0, 0, 0), IONODE_VARIANT(0, float, 1, 1, 0, 0, 0, 0),
-    IONODE_VARIANT(1, double, 0, 1, 0, 0, 0, 0), IONODE_VARIANT(1, float, 1, 1, 0, 0, 0, 0),
+    IONODE_VARIANT(0, double, 0, 1, 0, 0, 0, 0),  IONODE_VARIANT(0, float, 1, 1, 0, 0, 0, 0),
+    IONODE_VARIANT(1, double, 0, 1, 0, 0, 0, 0),  IONODE_VARIANT(1, float, 1, 1, 0, 0, 0, 0),
+    IONODE_VARIANT(0, double, 0, 1, 16, 0, 0, 0), IONODE_VARIANT(0, float, 1, 1, 16, 0, 0, 0),
+    IONODE_VARIANT(1, double, 0, 1, 16, 0, 0, 0), IONODE_VARIANT(1, float, 1, 1, 16, 0, 0, 0),
 };
 const Variant *variants_closed(int *n) { *n = sizeof(kTab) / sizeof(kTab[0]); return kTab; }
 }  // namespace ionode

@@ -22,8 +22,8 @@ struct Plan {
   size_t lds = 0;
 };
 
-// NT < 0: any.  Closed-form kernels are registered with NT == 0.
-const ionode::Variant *find_variant(int model, int f32, int G, int NT) {
+// Closed-form kernels are registered with NT == 0 and RT = trajectories per wavefront (0 -> 64); rt < 0: any RT.
+const ionode::Variant *find_variant(int model, int f32, int G, int NT, int rt = -1) {
   using namespace ionode;
   typedef const Variant *(*TabFn)(int *);
   static const TabFn tabs[] = {variants_closed, variants_nnf_f64, variants_nnf_f32, variants_nnd_f64, variants_nnd_f32};
@@ -31,7 +31,8 @@ const ionode::Variant *find_variant(int model, int f32, int G, int NT) {
     int n = 0;
     const Variant *t = tf(&n);
     for (int i = 0; i < n; ++i)
-      if (t[i].model == model && t[i].f32 == f32 && (G == 0 || t[i].G == G) && t[i].NT == NT) return &t[i];
+      if (t[i].model == model && t[i].f32 == f32 && (G == 0 || t[i].G == G) && t[i].NT == NT && (rt < 0 || t[i].RT == rt))
+        return &t[i];
   }
   return nullptr;
 }
@@ -47,14 +48,17 @@ int make_plan(const ionode_desc *d, Plan *pl) {
   if (!(d->rtol > 0) || !(d->atol >= 0) || !(d->prot_dt > 0)) { set_err("rtol/atol/prot_dt must be positive"); return IONODE_ERR_ARG; }
   const int f32 = d->state_f32 ? 1 : 0;
   if (!mlp) {
-    pl->v = find_variant(d->model, f32, 1, 0);
-    pl->grid = (unsigned)((d->n_traj + 63) / 64);
+    // small batches: 16 trajectories per wavefront (4x the wavefronts); >= 2 wavefronts per SIMD at 64 per wavefront
+    // needs 131072 trajectories.  tile_waves = 64 / 16 forces a choice (tests).
+    const int tpw = (d->tile_waves == 64 || d->tile_waves == 16) ? d->tile_waves : (d->n_traj >= 131072 ? 64 : 16);
+    pl->v = find_variant(d->model, f32, 1, 0, tpw == 64 ? 0 : 16);
+    pl->grid = (unsigned)((d->n_traj + tpw - 1) / tpw);
     pl->block = 64;
     pl->lds = 0;
   } else {
     if (d->mlp_width < 1 || d->mlp_layers < 0) { set_err("bad MLP shape"); return IONODE_ERR_ARG; }
     const int NP = np_of(d->mlp_width), NT = NP / 16;
-    if (d->tile_waves != 0 && d->tile_waves != 1 && d->tile_waves != 4) { set_err("tile_waves must be 0, 1 or 4"); return IONODE_ERR_UNSUPPORTED; }
+    if (d->tile_waves != 0 && d->tile_waves != 1 && d->tile_waves != 4) { set_err("tile_waves must be 0, 1 or 4 for MLP models"); return IONODE_ERR_UNSUPPORTED; }
     pl->v = find_variant(d->model, f32, d->tile_waves, NT);
     if (!pl->v) {
       set_err("MLP width outside the compiled kernel variants: N must pad to 16, 112, 208 or 512 "

@@ -602,7 +602,9 @@ __global__ void __launch_bounds__(64 * G) ionode_dopri5_kernel(const KArgs a) {
   using MT = ModelTraits<MODEL>;
   using R = Real<S>;
   constexpr int D = MT::D, NPAR = MT::NPAR;
-  constexpr int TPW = MT::MLP ? 16 : 64;
+  // trajectories per wavefront: 16 for MLP tiles (MFMA column count); closed-form kernels: 64 (one per lane), or RT
+  // (16: lanes replicated 4x) for small batches, where 4x more wavefronts matter more than lane efficiency
+  constexpr int TPW = MT::MLP ? 16 : (RT > 0 ? RT : 64);
   static_assert(MT::MLP || G == 1, "closed-form models use one wavefront per tile");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

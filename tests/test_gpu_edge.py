@@ -50,8 +50,9 @@ def test_ragged_batches(ion, gpu, oracle, B):
     te = K.deactivation(0)[2][:1001]
     params = K.P_HH[None, :] * rng.uniform(0.8, 1.2, (B, 8))
     kw = dict(prot_t0=0.0, prot_dt=1.0)
-    _same(run_gpu(ion, gpu, K.MODEL_HH2, params, pv, [0.0, 1.0], te, **kw),
-          oracle.solve(K.MODEL_HH2, params, pv, [0.0, 1.0], te, **kw))
+    o = oracle.solve(K.MODEL_HH2, params, pv, [0.0, 1.0], te, **kw)
+    for tpw in (16, 64):  # both closed-form tile shapes
+        _same(run_gpu(ion, gpu, K.MODEL_HH2, params, pv, [0.0, 1.0], te, tile_waves=tpw, **kw), o)
     if B <= 65:
         w = K.load_weights("s2")
         te2 = te[:301]

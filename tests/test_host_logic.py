@@ -43,7 +43,10 @@ def test_dispatch_geometry_and_errors(ion):
     assert g["grid"] == 256 and g["block"] == 256 and g["tile_waves"] == 4 and g["lds_bytes"] < 160 * 1024
     assert "ionode_dopri5_kernel<2, double, 4" in capi.kernel_name(d)
     d.model = capi.MODEL_HH2
-    assert capi.launch_geometry(d) == {"grid": 64, "block": 64, "lds_bytes": 0, "tile_waves": 1}
+    assert capi.launch_geometry(d) == {"grid": 256, "block": 64, "lds_bytes": 0, "tile_waves": 1}  # 16 per wavefront
+    d.tile_waves = 64
+    assert capi.launch_geometry(d)["grid"] == 64
+    d.tile_waves = 0
     d.n_state = 6  # inconsistent with HH2
     with pytest.raises(capi.IonodeError):
         capi.launch_geometry(d)
