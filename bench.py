@@ -59,6 +59,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="trajectories timed on the host (0 = auto)")
     ap.add_argument("--tile-waves", type=int, default=0)
     ap.add_argument("--stamps", action="store_true", help="diagnostic build (-DIONODE_STAMPS): print phase shares")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="rehearsal of the N > 1 code path on a 1-GPU box: every rank uses cuda:0 (use with gloo)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -66,12 +69,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the integrator has no CPU fallback")
+    if args.rehearse_on_one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        else:
+            dist.init_process_group(args.dist_backend)
 
     ion = importlib.import_module("neural-ode-ion-channels_amd")
     capi, protocols = ion.capi, importlib.import_module("neural-ode-ion-channels_amd.protocols")
@@ -97,14 +105,23 @@ def main():
         tot = t[:11].sum()
         print("STAMPS (wave 0 of block 0, cycles):", {n: (int(v), round(v / tot, 3)) for n, v in zip(names, t[:11])}, file=sys.stderr)
 
+    def allreduce(x, op=None):
+        if dist is None:
+            return x
+        if args.dist_backend == "nccl":
+            dist.all_reduce(x) if op is None else dist.all_reduce(x, op=op)
+            return x
+        y = x.cpu()
+        dist.all_reduce(y) if op is None else dist.all_reduce(y, op=op)
+        return y.to(x.device)
+
     def step():
         r = capi.dopri5(capi.MODEL_NNF, params, prot_v, y0, t_eval, mlp_packed=packed, mlp_layers=MLP_L,
                         mlp_width=MLP_N, prot_t0=0.0, prot_dt=0.1, current=True, obs_g=1.0, obs_e=-86.0,
                         tile_waves=args.tile_waves, out=out)
         out.update({k: r[k] for k in ("y", "i", "status", "stats")})
         part = torch.stack([(r["i"] - i_ref).abs().sum(), torch.tensor(float(B * Nt), dtype=torch.float64, device=dev)])
-        if dist is not None:
-            dist.all_reduce(part)  # the path's only collective: 16 bytes
+        part = allreduce(part)  # the path's only collective: 16 bytes
         return r, part[0] / part[1]
 
     def barrier():
@@ -124,14 +141,13 @@ def main():
                         tile_waves=args.tile_waves, out=out)
         ev[k][1].record()
         part = torch.stack([(r["i"] - i_ref).abs().sum(), torch.tensor(float(B * Nt), dtype=torch.float64, device=dev)])
-        if dist is not None:
-            dist.all_reduce(part)
+        part = allreduce(part)
         loss = part[0] / part[1]
     barrier()
     t1 = time.perf_counter()
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     if dist is not None:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+        elapsed = allreduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
