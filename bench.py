@@ -187,6 +187,16 @@ def main():
                          "frac": gbs / PEAK_HBM_GBS, "bytes_per_trajectory": bytes_traj},
     }
 
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    if os.path.exists(pmc) and B == 4096 and Nt == 100001:
+        # HBM bytes per launch from the rocprofv3 --pmc passes of this same command (profiles/README.md): FETCH_SIZE is
+        # doubled (gfx950 counts 128-B requests as 64 B), WRITE_SIZE is exact; both are reported in KiB
+        try:
+            pj = json.load(open(pmc))
+            res["roofline_hbm"]["traffic"] = (2 * pj["r01_pmc2"]["FETCH_SIZE"] + pj["r01_pmc3"]["WRITE_SIZE"]) * 1024
+            res["roofline_hbm"]["traffic_source"] = "profiles/r01_pmc_summary.json (separate --pmc passes, not this run)"
+        except (KeyError, ValueError):
+            pass
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(prot_v, weights, Nt, args.cpu_sample, out)
     if rank == 0:
@@ -195,13 +205,25 @@ def main():
         dist.destroy_process_group()
 
 
+def usable_cores():
+    """Host cores this process may actually use: min(affinity mask, cgroup CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(prot_v, weights, Nt, n_sample, gpu_out):
     """The CPU oracle (a port of the reference path, oracle/) on the first trajectories of the same workload,
     all host cores (OpenMP over trajectories).  Also used as a live parity check of the benchmark run."""
     from oracle import oracle
     oracle.build()
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
-    n = n_sample or max(cores, 8)
+    cores = usable_cores()
+    n = n_sample or min(max(2 * cores, 16), 256)
     pv = prot_v[:n].cpu().numpy()
     te = np.arange(Nt, dtype=np.float64) * 0.1
     t0 = time.perf_counter()
