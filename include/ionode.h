@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define IONODE_ABI_VERSION 1
+#define IONODE_ABI_VERSION 2
 
 /* RHS families (func.forward variants of the reference) */
 #define IONODE_MODEL_HH2 0     /* 2-state Hodgkin-Huxley: Lambda, train-s1.py:134-177; candidate ODEFunc train-d0.py:321-374 */
@@ -78,6 +78,8 @@ typedef struct ionode_desc {
   double *step_log;    /* optional DEVICE buffer [step_log_cap][4] fp64: (t0, dt, error ratio, accepted) of every
                           step attempt of trajectory 0 -- the per-step trace parity tests compare; NULL = off */
   int64_t step_log_cap;
+  double t_eval_t0_hint; /* optional hint t_eval[k] ~ t0_hint + k*dt_hint (dt_hint <= 0: none).  Only a starting guess for */
+  double t_eval_dt_hint; /* the output cursor, verified against t_eval in the kernel: a wrong hint costs time, not results */
 } ionode_desc;
 
 /* Number of floats of the device-side weight image for an (L, N) MLP  Linear(2,N) + L x Linear(N,N) + Linear(N,1). */

@@ -65,7 +65,7 @@ class Solution:
 def solve(model, params, prot_v, y0, t_eval, *, weights=None, mlp_layers=0, mlp_width=0, weights_key=None,
           prot_t=None, prot_t0=0.0, prot_dt=1.0, prot_of_traj=None, state_dtype=None, rtol=1e-7, atol=1e-9,
           v_oob=-80.0, max_steps=0, current=False, obs_g=1.0, obs_e=-86.0, obs_open_state_only=False,
-          tile_waves=0, device=None, step_log=None) -> Solution:
+          tile_waves=0, device=None, step_log=None, t_eval_hint="auto") -> Solution:
     """Integrate B trajectories on the GPU (asynchronous on the current stream).
 
     params [B, 8|12] (or [8|12] -> B = 1), prot_v [P, Np] (or [Np]), y0 [B, D] / [D] (broadcast over B),
@@ -88,6 +88,14 @@ def solve(model, params, prot_v, y0, t_eval, *, weights=None, mlp_layers=0, mlp_
     if y0_t.shape[0] != B:
         y0_t = y0_t.expand(B, y0_t.shape[1])
     y0_t = y0_t.contiguous()
+    if isinstance(t_eval_hint, str) and t_eval_hint == "auto" and not (isinstance(t_eval, torch.Tensor) and t_eval.is_cuda):
+        # host-side grid: derive the output-cursor hint without touching the device
+        te = t_eval.detach().double().numpy() if isinstance(t_eval, torch.Tensor) else np.asarray(t_eval, dtype=np.float64)
+        t_eval_hint = None
+        if te.size > 1:
+            dth = (te[-1] - te[0]) / (te.size - 1)
+            if dth > 0 and np.max(np.abs(te - (te[0] + np.arange(te.size) * dth))) <= 0.5 * dth:
+                t_eval_hint = (float(te[0]), float(dth))
     t_eval_t = _to(t_eval, torch.float64, dev)
     packed = None
     if model in (capi.MODEL_NNF, capi.MODEL_NND):
@@ -98,5 +106,6 @@ def solve(model, params, prot_v, y0, t_eval, *, weights=None, mlp_layers=0, mlp_
                     mlp_width=mlp_width, prot_t=_to(prot_t, torch.float64, dev), prot_t0=prot_t0, prot_dt=prot_dt,
                     prot_of_traj=_to(prot_of_traj, torch.int32, dev), rtol=rtol, atol=atol, v_oob=v_oob,
                     max_steps=max_steps, current=current, obs_g=obs_g, obs_e=obs_e,
-                    obs_open_state_only=obs_open_state_only, tile_waves=tile_waves, step_log=step_log)
+                    obs_open_state_only=obs_open_state_only, tile_waves=tile_waves, step_log=step_log,
+                    t_eval_hint=t_eval_hint)
     return Solution(y=r["y"], i=r["i"], status=r["status"], stats=r["stats"], kernel=capi.kernel_name(r["desc"]))

@@ -197,6 +197,7 @@ int ionode_dopri5(const ionode_desc *d, const float *mlp_packed, const double *p
   a.prot_t0 = d->prot_t0; a.prot_dt = d->prot_dt; a.v_oob = d->v_oob; a.rtol = d->rtol; a.atol = d->atol;
   a.obs_g = d->obs_g; a.obs_e = d->obs_e; a.obs_open = d->obs_open_state_only;
   a.step_log = d->step_log; a.step_log_cap = d->step_log ? d->step_log_cap : 0;
+  a.te_t0 = d->t_eval_t0_hint; a.te_dt = (d->t_eval_dt_hint > 0.0 && d->n_out > 1) ? d->t_eval_dt_hint : 0.0;
   const hipError_t e = pl.v->fn(a, pl.grid, pl.lds, reinterpret_cast<hipStream_t>(stream));
   if (e != hipSuccess) { set_err("kernel launch failed: %s", hipGetErrorString(e)); return IONODE_ERR_LAUNCH; }
   return IONODE_OK;

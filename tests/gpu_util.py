@@ -13,6 +13,7 @@ def run_gpu(ion, dev, model, params, prot_v, y0, t_eval, *, weights=None, L=0, N
     packed = None
     if weights is not None:
         packed = torch.from_numpy(capi.mlp_pack(weights, L, N)).to(dev)
+    kw.setdefault("t_eval_hint", "auto")
     pt = kw.pop("prot_t", None)
     pot = kw.pop("prot_of_traj", None)
     r = capi.dopri5(

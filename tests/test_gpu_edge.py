@@ -71,6 +71,24 @@ def test_single_output_time_and_irregular_output_grid(ion, gpu, oracle):
           oracle.solve(K.MODEL_HH2, K.P_HH, pv, [0.0, 1.0], te, **kw))
 
 
+def test_output_grid_hint_is_only_a_guess(ion, gpu, oracle):
+    """The output-cursor hint is verified in the kernel: no hint (cooperative scan), the right hint and absurd hints
+    all return the oracle's bits; irregular grids work with any of them."""
+    pv = K.activation(20)[1]
+    te_u = K.activation(0)[2][:3001]
+    te_i = np.sort(np.random.default_rng(1).uniform(0, 2999, 400))
+    te_i[0] = 0.0
+    w = K.load_weights("s1")
+    for te in (te_u, te_i):
+        o = oracle.solve(K.MODEL_HH2, K.P_HH, pv, [0.0, 1.0], te, prot_t0=0.0, prot_dt=1.0)
+        on = oracle.solve(K.MODEL_NNF, np.tile(K.P_HH, (5, 1)), pv, K.NN_Y0, te[:801], weights=w, mlp_layers=5,
+                          mlp_width=200, prot_t0=0.0, prot_dt=1.0)
+        for hint in (None, "auto", (0.0, 1.0), (-500.0, 0.013), (100.0, 57.0)):
+            _same(run_gpu(ion, gpu, K.MODEL_HH2, K.P_HH, pv, [0.0, 1.0], te, prot_t0=0.0, prot_dt=1.0, t_eval_hint=hint), o)
+            _same(run_gpu(ion, gpu, K.MODEL_NNF, np.tile(K.P_HH, (5, 1)), pv, K.NN_Y0, te[:801], weights=w, L=5, N=200,
+                          prot_t0=0.0, prot_dt=1.0, t_eval_hint=hint), on)
+
+
 def test_output_times_beyond_the_protocol_use_the_hold_voltage(ion, gpu, oracle):
     """t past the protocol's last sample: the reference's RHS substitutes -80 mV (train-s1.py:234-237)."""
     pv = K.atau(100)[1][:3001]

@@ -49,7 +49,7 @@ ms = []
 for rep in range(a.reps + 1):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    r = ion.capi.dopri5(model, params, pv, y0t, te, prot_t0=0.0, prot_dt=0.1, prot_of_traj=pot, current=a.current, out=out)
+    r = ion.capi.dopri5(model, params, pv, y0t, te, prot_t0=0.0, prot_dt=0.1, prot_of_traj=pot, current=a.current, t_eval_hint=(0.0, 0.1), out=out)
     e1.record()
     torch.cuda.synchronize()
     out.update({k: r[k] for k in ("y", "i", "status", "stats")})
