@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--nt", type=int, default=100001, help="protocol samples = output samples")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="trajectories timed on the host (0 = auto)")
+    ap.add_argument("--no-python-baseline", action="store_true", help="skip the reference-structured Python leg")
     ap.add_argument("--tile-waves", type=int, default=0)
     ap.add_argument("--stamps", action="store_true", help="diagnostic build (-DIONODE_STAMPS): print phase shares")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal)")
@@ -199,6 +200,11 @@ def main():
             pass
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(prot_v, weights, Nt, args.cpu_sample, out)
+        if not args.no_python_baseline:
+            try:
+                res["cpu_baseline_python"] = python_reference_structured_baseline(ion, prot_v, weights, Nt, out)
+            except Exception as e:  # informational leg only
+                res["cpu_baseline_python"] = {"error": repr(e)}
     if rank == 0:
         print(json.dumps(res))
     if dist is not None:
@@ -223,7 +229,7 @@ def cpu_baseline(prot_v, weights, Nt, n_sample, gpu_out):
     from oracle import oracle
     oracle.build()
     cores = usable_cores()
-    n = n_sample or min(max(2 * cores, 16), 256)
+    n = n_sample or min(prot_v.shape[0], 32 * cores)  # ~10-20 s of host work
     pv = prot_v[:n].cpu().numpy()
     te = np.arange(Nt, dtype=np.float64) * 0.1
     t0 = time.perf_counter()
@@ -235,6 +241,68 @@ def cpu_baseline(prot_v, weights, Nt, n_sample, gpu_out):
     return {"value": n / dt, "unit": "trajectories/s", "cores": cores, "kind": "port",
             "sample": f"first {n} trajectories of the same batch, oracle/liboracle.so (C, AVX2 fp32 fmaf chain), "
                       f"{dt:.1f} s wall", "rel_l2_gpu_vs_oracle": err}
+
+
+def python_reference_structured_baseline(ion, prot_v, weights, Nt, gpu_out, budget_s=25.0):
+    """BASELINE.md 'Baseline A': the reference's cost structure -- a Python dopri5 (the package's opt-in generic
+    stepper) calling an nn.Module.forward shaped like train-s1.py:231-247 (SciPy interp1d on the host per RHS call +
+    fp32 nn.Sequential), one process, one thread.  torchdiffeq itself is not available here.  Bounded: integrates the
+    first trajectory of the batch over a prefix of the output grid that takes ~budget_s, and extrapolates linearly."""
+    import torch.nn as nn
+    from scipy.interpolate import interp1d
+
+    generic = importlib.import_module("neural-ode-ion-channels_amd.generic")
+    torch.set_num_threads(1)
+
+    class RefStyleNNf(nn.Module):
+        def __init__(self):
+            super().__init__()
+            layers = [nn.Linear(2, MLP_N), nn.LeakyReLU()]
+            for _ in range(MLP_L):
+                layers += [nn.Linear(MLP_N, MLP_N), nn.LeakyReLU()]
+            self.net = nn.Sequential(*layers, nn.Linear(MLP_N, 1))
+            off = 0
+            with torch.no_grad():
+                for m in self.net:
+                    if isinstance(m, nn.Linear):
+                        n = m.weight.numel()
+                        m.weight.copy_(torch.from_numpy(weights[off:off + n].reshape(m.weight.shape))); off += n
+                        m.bias.copy_(torch.from_numpy(weights[off:off + m.bias.numel()])); off += m.bias.numel()
+            self.p5, self.p6, self.p7, self.p8 = (float(x) for x in P_HH[4:8])
+
+        def set_protocol(self, t, v):
+            self._interp = interp1d(t, v)
+
+        def forward(self, t, y):
+            a, r = torch.unbind(y, dim=1)
+            try:
+                v = torch.from_numpy(self._interp([t.detach().numpy()]))
+            except ValueError:
+                v = torch.tensor([-80])
+            k3 = self.p5 * torch.exp(self.p6 * v)
+            k4 = self.p7 * torch.exp(-self.p8 * v)
+            drdt = -k3 * r + k4 * (1 - r)
+            dadt = self.net(torch.stack([(v / 100.0)[0], a[0]]).float()) / 1000.0
+            return torch.stack([dadt[0], drdt[0]]).reshape(1, -1)
+
+    f = RefStyleNNf().eval()
+    tp = np.arange(Nt, dtype=np.float64) * 0.1
+    f.set_protocol(tp, prot_v[0].cpu().numpy())
+    y0 = torch.tensor([[0.0, 1.0]], dtype=torch.float64)
+    n_probe = min(Nt, 2001)  # 200 ms of protocol to calibrate, then as much as the budget allows
+    t0 = time.perf_counter()
+    generic.generic_dopri5(f, y0, torch.from_numpy(tp[:n_probe]))
+    dt_probe = time.perf_counter() - t0
+    n = int(min(Nt, max(n_probe, n_probe * budget_s / max(dt_probe, 1e-3))))
+    t0 = time.perf_counter()
+    y = generic.generic_dopri5(f, y0, torch.from_numpy(tp[:n]))
+    dt = time.perf_counter() - t0
+    g = gpu_out["y"][0, :n].cpu().numpy()
+    err = float(np.linalg.norm(y[:, 0, :].numpy() - g) / np.linalg.norm(g))
+    return {"value": 1.0 / (dt * Nt / n), "unit": "trajectories/s", "cores": 1, "kind": "port",
+            "sample": f"trajectory 0, first {n} of {Nt} output samples in {dt:.1f} s, extrapolated linearly in samples; "
+                      "Python dopri5 + nn.Module.forward with host interp1d per RHS call (the reference's cost structure)",
+            "rel_l2_vs_gpu": err}
 
 
 if __name__ == "__main__":
