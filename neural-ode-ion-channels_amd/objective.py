@@ -1,0 +1,56 @@
+"""Batched candidate-model objective: the consumer of the batched solve that replaces the reference's
+PINTS `ForwardModel.simulate` + `SumOfSquaresError` + process pool (train-d0.py:377-439, :508-540).
+
+The reference evaluates ONE candidate at a time: for each protocol, `odeint(ODEFunc(p1..p4 = x), y0, t)`, current
+`o[:,0,0]*o[:,0,1]*(V+86)`, and a SIGALRM time limit that turns a stuck solve into an `inf` error vector
+(train-d0.py:426-438).  Here a whole CMA-ES population is one launch: C candidates x P protocols = C*P trajectories,
+per-trajectory rate parameters, the current trace fused into the dense output, failed solves -> inf.  With several GPUs
+the candidates are sharded contiguously and the per-candidate errors are all-gathered (the optimiser needs every
+candidate's value on every rank); a scalar loss needs only `distributed.allreduce_sum_count`.
+"""
+import numpy as np
+import torch
+
+from . import batched, capi, distributed
+
+
+def population_sum_of_squares(candidates, protocols_v, data_i, t_eval, *, base_params, free=(0, 1, 2, 3), prot_t0=0.0,
+                              prot_dt=0.1, y0=(0.0, 1.0), state_dtype=torch.float32, obs_g=1.0, obs_e=-86.0,
+                              max_steps=1_000_000, group=None, device=None):
+    """Sum-of-squares error of every candidate over all protocols (PINTS SumOfSquaresError on a multi-output problem).
+
+    candidates  [C, len(free)]  values of the free rate parameters (train-d0.py: p1..p4 -> free = (0, 1, 2, 3))
+    protocols_v [P, Np] mV;  data_i [P, Nt] measured currents;  t_eval [Nt] ms;  base_params [8]
+    Returns a [C] fp64 tensor on the device: inf where any of a candidate's solves failed (the reference's time-limit
+    rule).  Under torch.distributed the candidates are sharded over the ranks and the result is all-gathered.
+    """
+    import torch.distributed as dist
+    cand = np.asarray(candidates, dtype=np.float64)
+    C, P = cand.shape[0], np.asarray(protocols_v).shape[0]
+    on = dist.is_available() and dist.is_initialized()
+    rank, world = (dist.get_rank(group), dist.get_world_size(group)) if on else (0, 1)
+    lo, hi = distributed.shard_bounds(C, rank, world)
+    dev = batched._dev(device)
+    sse = torch.full((hi - lo,), float("inf"), dtype=torch.float64, device=dev)
+    if hi > lo:
+        params = np.tile(np.asarray(base_params, dtype=np.float64), (hi - lo, 1))
+        params[:, list(free)] = cand[lo:hi]
+        params = np.repeat(params, P, axis=0)                       # candidate-major: trajectory = c*P + p
+        pot = np.tile(np.arange(P, dtype=np.int32), hi - lo)
+        sol = batched.solve(capi.MODEL_HH2, params, protocols_v, torch.tensor([list(y0)], dtype=state_dtype), t_eval,
+                            prot_t0=prot_t0, prot_dt=prot_dt, prot_of_traj=pot, current=True, obs_g=obs_g, obs_e=obs_e,
+                            max_steps=max_steps, device=dev)
+        ref = torch.as_tensor(np.asarray(data_i), dtype=torch.float64, device=dev)     # [P, Nt]
+        err = ((sol.i.reshape(hi - lo, P, -1) - ref[None]) ** 2).sum(dim=(1, 2))
+        ok = (sol.status.reshape(hi - lo, P) == 0).all(dim=1)
+        sse = torch.where(ok, err, torch.full_like(err, float("inf")))
+    if world == 1:
+        return sse
+    # all-gather of unequal shards: pad to the largest shard
+    m = (C + world - 1) // world
+    pad = torch.full((m,), float("inf"), dtype=torch.float64, device=dev)
+    pad[: hi - lo] = sse
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat([parts[r][: distributed.shard_bounds(C, r, world)[1] - distributed.shard_bounds(C, r, world)[0]]
+                      for r in range(world)])
