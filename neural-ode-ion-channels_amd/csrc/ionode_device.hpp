@@ -340,7 +340,11 @@ struct MlpTile {
     constexpr int pstride = R * G * 64;
     MSTAMP(0);  // slot 0: everything outside the MLP (RK scalar work, emission)
 
-    // layer 0: Linear(2, N) + LeakyReLU on the VALU, written in accumulator layout; row tile rt by wavefront rt % G
+    // layer 0: Linear(2, N) + LeakyReLU on the VALU, written in accumulator layout; row tile rt by wavefront rt % G.
+    // hOwn = this wavefront's tile `wave`: the k-tile it consumes at step 0 of the next layer ((0 + w) mod NT).
+    // That B operand is taken from registers, which lets the layer barrier sit AFTER step 0: the LDS store -> barrier ->
+    // load round trip of the activations and the wait for the slowest wavefront overlap with step 0's MFMAs.
+    f32x4 hOwn = f32x4{0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
       const int rt = wave + i * G;
@@ -351,13 +355,12 @@ struct MlpTile {
           const f32x4 w = W0s[16 * rt + 4 * q + r];
           h[r] = lrelu(fmaf(w[2], x1, fmaf(w[1], x0, w[0])));
         }
+        if (i == 0) hOwn = h;
         Hs[rt * 64 + lane] = h;
         if (rt < G - 1) Hs[(rt + NT) * 64 + lane] = h;
       }
     }
     MSTAMP(1);  // slot 1: layer 0
-    if (G > 1) __syncthreads();
-    MSTAMP(2);  // slot 2: barriers
 
     for (int l = 0; l < L; ++l) {
       f32x4 *__restrict__ Hin = Hs + (l & 1) * tstride;
@@ -374,10 +377,6 @@ struct MlpTile {
       // wavefronts; each reads after its own write, so no barrier).  The fold is needed first at step G*F - wave;
       // when that is late enough it runs behind the MFMAs of step 0 instead of in the layer prologue.
       constexpr bool LAZY_FOLD = (R > 0) && (G * F - (G - 1) >= 3);
-      if (R > 0 && !LAZY_FOLD && l > 0) {
-#pragma unroll
-        for (int j = 0; j < R; ++j) Hin[(G * F + j) * 64 + lane] = remainder_h(Pin, j);
-      }
       f32x4 acc[F > 0 ? F : 1], accr[RP];
 #pragma unroll
       for (int i = 0; i < F; ++i)
@@ -394,15 +393,17 @@ struct MlpTile {
         const unsigned lref = same_layer ? lcur + (unsigned)step_base(kt0 + PD) * 1024u : lnext;
         // this wavefront's k-tile at step kt0 + u is (kt0 + u + wave) mod NT = slot kt0 + u + wave of the buffer
         const f32x4 *__restrict__ Bw = Hin + (kt0 + wave) * 64 + lane;
-        f32x4 b_nxt = Bw[0];
-        MSTAMP(8);  // slot 8: layer prologue (bias, first B read)
+        f32x4 b_nxt = hOwn;                      // step 0 of the layer: own tile, from registers (before the barrier)
+        if (kt0 > 0) b_nxt = Bw[0];
+        MSTAMP(8);  // slot 8: layer prologue (bias)
 #pragma unroll
         for (int u = 0; u < PD; ++u) {
-          if (u == 1) MSTAMP(9);       // slot 9: first k-tile
+          if (u == 1) MSTAMP(9);       // slot 9: first k-tile (+ barrier)
           if (u == PD - 1) MSTAMP(3);  // slot 3: k-tiles 1..PD-2
           const f32x4 b = b_nxt;
 #ifndef IONODE_EXPERIMENT_NO_BREAD  // timing experiment only
-          if (u + 1 < PD) b_nxt = Bw[(u + 1) * 64];  // LDS read one step ahead, immediate offset
+          // LDS read one step ahead, immediate offset -- except across the layer barrier (after step 0)
+          if (u + 1 < PD && !(u == 0 && kt0 == 0)) b_nxt = Bw[(u + 1) * 64];
 #endif
           // K-slice ownership: static, except that the last owned step wraps past NT for the higher wavefronts
           const bool own_static = (R > 0) && (u % G == 0);
@@ -432,10 +433,20 @@ struct MlpTile {
               for (int j = 0; j < R; ++j) rrem[u / G][j] = frag(lref, step_base(u) + F + j);
             }
 #endif
-            if (LAZY_FOLD && u == 0 && r == 0 && l > 0) {
+            if (LAZY_FOLD && u == 1 && r == 0 && l > 0) {
 #pragma unroll
               for (int j = 0; j < R; ++j) Hin[(G * F + j) * 64 + lane] = remainder_h(Pin, j);
             }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (u == 0 && kt0 == 0) {
+            // ---- the layer barrier: everybody's activations / partial sums of the previous layer are in LDS ----
+            if (G > 1) __syncthreads();
+            if (R > 0 && !LAZY_FOLD && l > 0) {
+#pragma unroll
+              for (int j = 0; j < R; ++j) Hin[(G * F + j) * 64 + lane] = remainder_h(Pin, j);
+            }
+            if (PD > 1) b_nxt = Bw[64];
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -446,15 +457,16 @@ struct MlpTile {
         f32x4 h;
 #pragma unroll
         for (int r = 0; r < 4; ++r) h[r] = lrelu(acc[i][r]);
+        if (i == 0) hOwn = h;
         Hout[(wave + i * G) * 64 + lane] = h;
         if (wave + i * G < G - 1) Hout[(wave + i * G + NT) * 64 + lane] = h;
       }
 #pragma unroll
       for (int j = 0; j < R; ++j) Pout[(j * G + wave) * 64 + lane] = accr[j];
       MSTAMP(4);  // slot 4: LeakyReLU + activation store
-      if (G > 1) __syncthreads();
-      MSTAMP(2);
     }
+    if (G > 1) __syncthreads();  // the last hidden layer's (or layer 0's) activations for the output layer
+    MSTAMP(2);
 
     // Linear(N, 1) on the VALU: four partial fmaf chains (one per lane group q), fixed combine tree
     const f32x4 *__restrict__ Hin = Hs + (L & 1) * tstride;
