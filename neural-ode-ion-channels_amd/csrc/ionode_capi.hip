@@ -57,6 +57,7 @@ int make_plan(const ionode_desc *d, Plan *pl) {
     pl->lds = 0;
   } else {
     if (d->mlp_width < 1 || d->mlp_layers < 0) { set_err("bad MLP shape"); return IONODE_ERR_ARG; }
+    if (d->mlp_width <= 16 && d->mlp_layers > 10) { set_err("N <= 16 kernels keep at most 10 hidden layers resident"); return IONODE_ERR_UNSUPPORTED; }
     const int NP = np_of(d->mlp_width), NT = NP / 16;
     if (d->tile_waves != 0 && d->tile_waves != 1 && d->tile_waves != 4) { set_err("tile_waves must be 0, 1 or 4 for MLP models"); return IONODE_ERR_UNSUPPORTED; }
     pl->v = find_variant(d->model, f32, d->tile_waves, NT);

@@ -256,6 +256,10 @@ struct MlpTile {
   // ring slot of step u (blocked scheme: step kt0 + u): F full fragments (+ R remainder fragments when owned)
   f32x4 ring[PD][F > 0 ? F : 1];
   f32x4 rrem[R > 0 ? (PD + G - 1) / G : 1][RP];
+  // NT == 1 (N <= 16, architectures s03-s05): the whole hidden stack is LMAX fragments -- it stays in registers
+  static constexpr bool TINY = (NT == 1 && G == 1);
+  static constexpr int LMAX = 10;
+  f32x4 wres[TINY ? LMAX : 1];
   // LDS [2][HT*64] activations after LeakyReLU, accumulator layout.  HT = NT + G - 1 slots: tiles 0..G-2 are stored
   // twice (slot kt and kt + NT) so that wavefront w reads its rotated sequence kt = (s + w) mod NT at the linear
   // address base_w + s -- an immediate offset, no per-step address arithmetic.  Remainder-tile slots are filled by
@@ -304,9 +308,13 @@ struct MlpTile {
     voff = (unsigned)(wave * FRAGS * 1024 + lane * 16);
     hid0 = (unsigned)(4 * NP * 4);
     lbytes = (unsigned)(lstride * 4);
+    if constexpr (TINY) {
+#pragma unroll
+      for (int l = 0; l < LMAX; ++l) wres[l] = (l < L) ? frag(hid0 + (unsigned)l * lbytes, 0) : f32x4{0, 0, 0, 0};
+    }
     // prime the ring with the first PD steps of hidden layer 0
 #pragma unroll
-    for (int u = 0; u < PD; ++u) {
+    for (int u = 0; u < (TINY ? 0 : PD); ++u) {
 #pragma unroll
       for (int j = 0; j < F; ++j) ring[u][j] = frag(hid0, step_base(u) + j);
       if (R > 0 && u % G == 0) {
@@ -334,7 +342,36 @@ struct MlpTile {
     return h;
   }
 
+  // N <= 16: one wavefront, one 16x16 tile per layer, weights resident, activations never leave the registers
+  // (the accumulator tile IS the next B operand).  Same canonical order as the general path with NT = 1.
+  __device__ __forceinline__ float eval_tiny(float x0, float x1) {
+    const int q = lane >> 4;
+    f32x4 h;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const f32x4 w = W0s[4 * q + r];
+      h[r] = lrelu(fmaf(w[2], x1, fmaf(w[1], x0, w[0])));
+    }
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) {
+      if (l < L) {
+        f32x4 acc = *reinterpret_cast<const f32x4 *>(biasS + l * NP + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wres[l][r], h[r], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = lrelu(acc[r]);
+      }
+    }
+    const f32x4 w = *reinterpret_cast<const f32x4 *>(wlS + 4 * q);
+    float part = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part = fmaf(w[r], h[r], part);
+    const float pair = part + __shfl_xor(part, 16);
+    return (pair + __shfl_xor(pair, 32)) + wlS[NP];
+  }
+
   __device__ __forceinline__ float eval(float x0, float x1) {
+    if constexpr (TINY) return eval_tiny(x0, x1);
     const int q = lane >> 4;
     constexpr int tstride = HT * 64;
     constexpr int pstride = R * G * 64;

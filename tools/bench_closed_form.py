@@ -22,7 +22,9 @@ ap.add_argument("--nt", type=int, default=100001)
 ap.add_argument("--prot", type=int, default=64)
 ap.add_argument("--f32", action="store_true")
 ap.add_argument("--current", action="store_true")
-ap.add_argument("--model", default="hh", choices=["hh", "m6"])
+ap.add_argument("--model", default="hh", choices=["hh", "m6", "nnf"])
+ap.add_argument("--width", type=int, default=10, help="nnf: MLP width N")
+ap.add_argument("--layers", type=int, default=5, help="nnf: hidden layers L")
 ap.add_argument("--reps", type=int, default=3)
 a = ap.parse_args()
 
@@ -34,10 +36,16 @@ dev = torch.device("cuda:0")
 B, Nt = a.batch, a.nt
 pv = P.sinewave(P.sinewave_scales(0, a.prot), n_samples=Nt, xp=torch, device=dev)
 rng = np.random.default_rng(0)
+packed = None
 if a.model == "hh":
     model, p0, y0 = ion.capi.MODEL_HH2, K.P_HH, [0.0, 1.0]
-else:
+elif a.model == "m6":
     model, p0, y0 = ion.capi.MODEL_MARKOV6, K.P_M6, [0.0, 1.0, 0, 0, 0, 0]
+else:
+    model, p0, y0 = ion.capi.MODEL_NNF, K.P_HH, [0.0, 1.0]
+    N, L = a.width, a.layers
+    w = (np.random.default_rng(1).normal(0, 0.1, 2 * N + N + L * (N * N + N) + N + 1)).astype(np.float32)
+    packed = torch.from_numpy(ion.capi.mlp_pack(w, L, N)).to(dev)
 D = len(y0)
 params = torch.from_numpy(p0[None, :] * rng.uniform(0.8, 1.25, (B, p0.size))).to(dev)
 sdt = torch.float32 if a.f32 else torch.float64
@@ -49,7 +57,9 @@ ms = []
 for rep in range(a.reps + 1):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    r = ion.capi.dopri5(model, params, pv, y0t, te, prot_t0=0.0, prot_dt=0.1, prot_of_traj=pot, current=a.current, t_eval_hint=(0.0, 0.1), out=out)
+    r = ion.capi.dopri5(model, params, pv, y0t, te, prot_t0=0.0, prot_dt=0.1, prot_of_traj=pot, current=a.current,
+                        mlp_packed=packed, mlp_layers=a.layers if packed is not None else 0,
+                        mlp_width=a.width if packed is not None else 0, t_eval_hint=(0.0, 0.1), out=out)
     e1.record()
     torch.cuda.synchronize()
     out.update({k: r[k] for k in ("y", "i", "status", "stats")})
