@@ -171,3 +171,21 @@ def test_shard_bounds(ion):
             assert all(cuts[i][1] == cuts[i + 1][0] for i in range(w - 1))
             sizes = [hi - lo for lo, hi in cuts]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_product_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under the product package (Python or C/HIP sources) or the torchdiffeq
+    shim may import, include, link or execute it; bench.py may only in its cpu_baseline legs."""
+    root = os.path.join(os.path.dirname(__file__), "..")
+    offenders = []
+    for base in ("neural-ode-ion-channels_amd", "torchdiffeq", "include"):
+        for dp, _, files in os.walk(os.path.join(root, base)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", "Makefile")):
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    if re.search(r"(from|import)\s+oracle|oracle/|liboracle|dopri5_oracle", txt):
+                        offenders.append(os.path.join(dp, f))
+    assert not offenders, offenders
+    bench = open(os.path.join(root, "bench.py")).read()
+    uses = [m.start() for m in re.finditer(r"from oracle import", bench)]
+    assert len(uses) == 1 and bench[:uses[0]].rfind("def cpu_baseline") > bench[:uses[0]].rfind("def main")
