@@ -194,8 +194,11 @@ def main():
         # doubled (gfx950 counts 128-B requests as 64 B), WRITE_SIZE is exact; both are reported in KiB
         try:
             pj = json.load(open(pmc))
-            res["roofline_hbm"]["traffic"] = (2 * pj["r01_pmc2"]["FETCH_SIZE"] + pj["r01_pmc3"]["WRITE_SIZE"]) * 1024
-            res["roofline_hbm"]["traffic_source"] = "profiles/r01_pmc_summary.json (separate --pmc passes, not this run)"
+            traffic = (2 * pj["r01_pmc2"]["FETCH_SIZE"] + pj["r01_pmc3"]["WRITE_SIZE"]) * 1024
+            for key in ("roofline", "roofline_hbm"):
+                res[key]["traffic"] = traffic
+                res[key]["traffic_source"] = ("HBM bytes per launch, profiles/r01_pmc_summary.json (separate rocprofv3 --pmc "
+                                              "passes of this command; FETCH_SIZE x2 per the gfx950 note, WRITE_SIZE exact)")
         except (KeyError, ValueError):
             pass
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
