@@ -235,8 +235,8 @@ __device__ __forceinline__ float lrelu(float x) { return fmaxf(x, x * 0.01f); }
 // Fragments are consumed from a register ring
 // refilled PD k-tiles ahead (PD == NT: a whole layer ahead) with SRSRC buffer loads issued right behind the last
 // MFMA that reads them, pinned with sched_barrier so the machine scheduler neither sinks them to the end of the
-// layer nor bunches them into an MFMA-free gap.  The kernel sits at the balance point of fp32-MFMA rate and per-CU
-// L2 streaming rate (about 28 B/clk/CU measured), so both the MFMA count and the streamed bytes matter.
+// layer nor bunches them into an MFMA-free gap.  The stream runs at ~28 B/clk/CU; it is not the limiter (cutting its
+// bytes by 17 % changed nothing): the MFMA count and the issue work per k-tile step and per layer boundary are.
 // Small vectors (layer-0 rows, biases, last-layer weights) live in LDS for the kernel's lifetime.
 // ---------------------------------------------------------------------------------------------
 template <int G, int RT, int NT, int PD, int TAIL = 0>
