@@ -65,9 +65,16 @@ def main():
                     help="rehearsal of the N > 1 code path on a 1-GPU box: every rank uses cuda:0 (use with gloo)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process becomes the launcher.  It has not touched the
+        # GPU (no HIP call so far) and never will; it starts N fresh children, one per GPU, and relays rank 0's line.
+        raise SystemExit(self_launch(args.gpus))
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; the launcher's world size is used", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the integrator has no CPU fallback")
     if args.rehearse_on_one_gpu:
@@ -212,6 +219,40 @@ def main():
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def self_launch(n):
+    """Start n ranks of this script (one per GPU, RCCL rendezvous on 127.0.0.1) as child processes and wait for them.
+    Rank 0 inherits stdout, so its single JSON line is this command's output; the exit code is non-zero if any rank
+    failed.  The parent never initialises the GPU and is never replaced by another program."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    live = dict(enumerate(procs))
+    while live:
+        time.sleep(0.2)
+        for r, p in list(live.items()):
+            c = p.poll()
+            if c is None:
+                continue
+            del live[r]
+            if c != 0:
+                print(f"bench.py: rank {r} exited with code {c}", file=sys.stderr)
+                rc = rc or (c if c > 0 else 1)
+                for q in live.values():  # a dead rank would leave the others waiting at the rendezvous / barrier
+                    q.terminate()
+    return rc
 
 
 def usable_cores():

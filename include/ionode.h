@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define IONODE_ABI_VERSION 2
+#define IONODE_ABI_VERSION 3
 
 /* RHS families (func.forward variants of the reference) */
 #define IONODE_MODEL_HH2 0     /* 2-state Hodgkin-Huxley: Lambda, train-s1.py:134-177; candidate ODEFunc train-d0.py:321-374 */
@@ -65,7 +65,8 @@ typedef struct ionode_desc {
   int32_t mlp_layers;  /* L: hidden N x N Linear layers (architectures/sNN.py: n_layers) */
   int32_t mlp_width;   /* N: nodes per layer (architectures/sNN.py: n_nodes) */
   int32_t n_params;    /* doubles per trajectory in params[]: >= 8 (p1..p8), >= 12 for MARKOV6 */
-  int64_t max_steps;   /* accepted + rejected steps allowed per trajectory */
+  int64_t max_steps;   /* torchdiffeq's max_num_steps: step attempts allowed between two emitted outputs (its _advance
+                          resets the counter for every output time); 0 = torchdiffeq's default 2**31 - 1 */
   double prot_t0;      /* uniform protocol grid t_i = prot_t0 + i*prot_dt (used when prot_t == NULL) */
   double prot_dt;
   double v_oob;        /* voltage substituted outside the protocol's time range: -80 (train-s1.py:237) */
@@ -80,7 +81,19 @@ typedef struct ionode_desc {
   int64_t step_log_cap;
   double t_eval_t0_hint; /* optional hint t_eval[k] ~ t0_hint + k*dt_hint (dt_hint <= 0: none).  Only a starting guess for */
   double t_eval_dt_hint; /* the output cursor, verified against t_eval in the kernel: a wrong hint costs time, not results */
+  int64_t max_total_steps; /* runaway bound: step attempts allowed over the whole solve of one trajectory (a tile runs until
+                          its slowest trajectory ends; the reference bounds a solve with a 600 s SIGALRM, train-d0.py:309-318).
+                          0 = library default IONODE_DEFAULT_MAX_TOTAL_STEPS; < 0 = unbounded.  Exceeding it gives
+                          IONODE_STATUS_MAX_STEPS like max_steps. */
+  double *ckpt;        /* optional DEVICE buffer [n_traj][ckpt_cap][4 + 8*n_state] fp64, one record per ACCEPTED step:
+                          {t0, dt, first output index of the step, outputs emitted, y[D], k1..k7[D]} -- what the backward
+                          sweep (ionode_dopri5_backward) replays.  Steps beyond ckpt_cap are not recorded (the caller
+                          compares stats[b][0] with ckpt_cap and retries with a larger buffer).  NULL = off */
+  int32_t ckpt_cap;
+  int32_t reserved0;
 } ionode_desc;
+
+#define IONODE_DEFAULT_MAX_TOTAL_STEPS 1000000
 
 /* Number of floats of the device-side weight image for an (L, N) MLP  Linear(2,N) + L x Linear(N,N) + Linear(N,1). */
 size_t ionode_mlp_packed_floats(int32_t mlp_layers, int32_t mlp_width);

@@ -12,6 +12,7 @@ import torch
 from . import capi
 
 _packed_cache = {}
+_dev_cache = {}  # (content digest, dtype, device) -> device tensor: protocols / output grids that do not change between calls
 
 
 def _dev(device=None):
@@ -22,12 +23,22 @@ def _dev(device=None):
     return torch.device(device)
 
 
-def _to(x, dtype, dev):
+def _to(x, dtype, dev, key=None):
+    """Device-resident contiguous copy; with `key` (a content digest) the copy is cached and re-used across calls."""
     if x is None:
         return None
+    ck = (key, dtype, str(dev)) if key is not None else None
+    if ck is not None and ck in _dev_cache:
+        return _dev_cache[ck]
     if isinstance(x, torch.Tensor):
-        return x.to(device=dev, dtype=dtype).contiguous()
-    return torch.from_numpy(np.ascontiguousarray(np.asarray(x))).to(device=dev, dtype=dtype).contiguous()
+        out = x.to(device=dev, dtype=dtype).contiguous()
+    else:
+        out = torch.from_numpy(np.ascontiguousarray(np.asarray(x))).to(device=dev, dtype=dtype).contiguous()
+    if ck is not None:
+        if len(_dev_cache) > 32:
+            _dev_cache.clear()
+        _dev_cache[ck] = out
+    return out
 
 
 def packed_weights(weights, mlp_layers, mlp_width, dev, key=None):
@@ -64,8 +75,8 @@ class Solution:
 
 def solve(model, params, prot_v, y0, t_eval, *, weights=None, mlp_layers=0, mlp_width=0, weights_key=None,
           prot_t=None, prot_t0=0.0, prot_dt=1.0, prot_of_traj=None, state_dtype=None, rtol=1e-7, atol=1e-9,
-          v_oob=-80.0, max_steps=0, current=False, obs_g=1.0, obs_e=-86.0, obs_open_state_only=False,
-          tile_waves=0, device=None, step_log=None, t_eval_hint="auto") -> Solution:
+          v_oob=-80.0, max_steps=0, max_total_steps=0, current=False, obs_g=1.0, obs_e=-86.0, obs_open_state_only=False,
+          tile_waves=0, device=None, step_log=None, t_eval_hint="auto", prot_key=None, t_eval_key=None) -> Solution:
     """Integrate B trajectories on the GPU (asynchronous on the current stream).
 
     params [B, 8|12] (or [8|12] -> B = 1), prot_v [P, Np] (or [Np]), y0 [B, D] / [D] (broadcast over B),
@@ -77,7 +88,7 @@ def solve(model, params, prot_v, y0, t_eval, *, weights=None, mlp_layers=0, mlp_
     if params_t.dim() == 1:
         params_t = params_t[None, :].contiguous()
     B = params_t.shape[0]
-    prot_v_t = _to(prot_v, torch.float64, dev)
+    prot_v_t = _to(prot_v, torch.float64, dev, key=None if prot_key is None else (prot_key, "v"))
     if prot_v_t.dim() == 1:
         prot_v_t = prot_v_t[None, :].contiguous()
     if state_dtype is None:
@@ -96,16 +107,17 @@ def solve(model, params, prot_v, y0, t_eval, *, weights=None, mlp_layers=0, mlp_
             dth = (te[-1] - te[0]) / (te.size - 1)
             if dth > 0 and np.max(np.abs(te - (te[0] + np.arange(te.size) * dth))) <= 0.5 * dth:
                 t_eval_hint = (float(te[0]), float(dth))
-    t_eval_t = _to(t_eval, torch.float64, dev)
+    t_eval_t = _to(t_eval, torch.float64, dev, key=t_eval_key)
     packed = None
     if model in (capi.MODEL_NNF, capi.MODEL_NND):
         if weights is None:
             raise capi.IonodeError("NN models need `weights` (flat fp32 state dict)")
         packed = packed_weights(weights, mlp_layers, mlp_width, dev, key=weights_key)
     r = capi.dopri5(model, params_t, prot_v_t, y0_t, t_eval_t, mlp_packed=packed, mlp_layers=mlp_layers,
-                    mlp_width=mlp_width, prot_t=_to(prot_t, torch.float64, dev), prot_t0=prot_t0, prot_dt=prot_dt,
+                    mlp_width=mlp_width, prot_t=_to(prot_t, torch.float64, dev, key=None if prot_key is None else (prot_key, "t")),
+                    prot_t0=prot_t0, prot_dt=prot_dt,
                     prot_of_traj=_to(prot_of_traj, torch.int32, dev), rtol=rtol, atol=atol, v_oob=v_oob,
-                    max_steps=max_steps, current=current, obs_g=obs_g, obs_e=obs_e,
+                    max_steps=max_steps, max_total_steps=max_total_steps, current=current, obs_g=obs_g, obs_e=obs_e,
                     obs_open_state_only=obs_open_state_only, tile_waves=tile_waves, step_log=step_log,
                     t_eval_hint=t_eval_hint)
     return Solution(y=r["y"], i=r["i"], status=r["status"], stats=r["stats"], kernel=capi.kernel_name(r["desc"]))

@@ -21,7 +21,7 @@ STATUS_TEXT = {
     2: "non-finite values in state `y`",
     3: "max_num_steps exceeded",
 }
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 EXPORTS = (
     "ionode_abi_version", "ionode_last_error", "ionode_mlp_packed_floats", "ionode_mlp_pack",
@@ -39,6 +39,7 @@ class IonodeDesc(C.Structure):
         ("obs_open_state_only", C.c_int32), ("tile_waves", C.c_int32),
         ("step_log", C.c_void_p), ("step_log_cap", C.c_int64),
         ("t_eval_t0_hint", C.c_double), ("t_eval_dt_hint", C.c_double),
+        ("max_total_steps", C.c_int64), ("ckpt", C.c_void_p), ("ckpt_cap", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -134,7 +135,7 @@ def _dev_ptr(t, dtype, name, shape=None):
 
 def dopri5(model, params, prot_v, y0, t_eval, *, mlp_packed=None, mlp_layers=0, mlp_width=0, prot_t=None,
            prot_t0=0.0, prot_dt=1.0, prot_of_traj=None, rtol=1e-7, atol=1e-9, v_oob=-80.0, max_steps=0,
-           current=False, obs_g=1.0, obs_e=-86.0, obs_open_state_only=False, tile_waves=0, stats=True,
+           max_total_steps=0, ckpt=None, current=False, obs_g=1.0, obs_e=-86.0, obs_open_state_only=False, tile_waves=0, stats=True,
            step_log=None, t_eval_hint="auto", out=None, stream=None):
     """Launch one batched solve.  Every tensor lives on the current HIP device.
 
@@ -152,7 +153,7 @@ def dopri5(model, params, prot_v, y0, t_eval, *, mlp_packed=None, mlp_layers=0, 
         raise IonodeError("y0 must be float32 or float64")
     desc = make_desc(model=model, state_f32=int(sdt == torch.float32), n_state=D, n_out=Nt, n_traj=B, n_prot=P,
                      prot_n=Np, mlp_layers=mlp_layers, mlp_width=mlp_width, n_params=params.shape[1],
-                     max_steps=max_steps, prot_t0=prot_t0, prot_dt=prot_dt, v_oob=v_oob, rtol=rtol, atol=atol,
+                     max_steps=max_steps, max_total_steps=max_total_steps, prot_t0=prot_t0, prot_dt=prot_dt, v_oob=v_oob, rtol=rtol, atol=atol,
                      obs_g=obs_g, obs_e=obs_e, obs_open_state_only=int(obs_open_state_only), tile_waves=tile_waves)
     # output-grid hint (t0, dt): a guess the kernel verifies against t_eval; "auto" derives it from the end points
     # (one tiny device->host read), None disables it (cooperative scan)
@@ -167,6 +168,10 @@ def dopri5(model, params, prot_v, y0, t_eval, *, mlp_packed=None, mlp_layers=0, 
                 t_eval_hint = (float(vals[0]), float(vals[1]))
     if t_eval_hint is not None and t_eval_hint[1] > 0:
         desc.t_eval_t0_hint, desc.t_eval_dt_hint = float(t_eval_hint[0]), float(t_eval_hint[1])
+    if ckpt is not None:  # [B, cap, 4 + 8*D] f64 device tensor: accepted-step records for the backward sweep
+        _dev_ptr(ckpt, torch.float64, "ckpt", (B, ckpt.shape[1], 4 + 8 * D))
+        desc.ckpt = ckpt.data_ptr()
+        desc.ckpt_cap = ckpt.shape[1]
     if step_log is not None:  # [cap, 4] f64 device tensor: (t0, dt, ratio, accepted) per attempt of trajectory 0
         _dev_ptr(step_log, torch.float64, "step_log")
         desc.step_log = step_log.data_ptr()

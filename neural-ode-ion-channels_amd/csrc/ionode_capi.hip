@@ -195,6 +195,10 @@ int ionode_dopri5(const ionode_desc *d, const float *mlp_packed, const double *p
   a.B = d->n_traj; a.Nt = d->n_out; a.P = d->n_prot; a.Np = d->prot_n; a.n_params = d->n_params;
   if (mlp) { a.L = d->mlp_layers; a.N = d->mlp_width; a.NP = np_of(d->mlp_width); a.NT = a.NP / 16; }
   a.max_steps = d->max_steps > 0 ? d->max_steps : (int64_t)2147483647;  // torchdiffeq max_num_steps default 2**31 - 1
+  a.max_total = d->max_total_steps > 0 ? d->max_total_steps
+                                       : (d->max_total_steps == 0 ? (int64_t)IONODE_DEFAULT_MAX_TOTAL_STEPS : INT64_MAX);
+  a.ckpt = d->ckpt; a.ckpt_cap = d->ckpt ? d->ckpt_cap : 0;
+  if (d->ckpt && d->ckpt_cap < 1) { set_err("ckpt given with ckpt_cap < 1"); return IONODE_ERR_ARG; }
   a.prot_t0 = d->prot_t0; a.prot_dt = d->prot_dt; a.v_oob = d->v_oob; a.rtol = d->rtol; a.atol = d->atol;
   a.obs_g = d->obs_g; a.obs_e = d->obs_e; a.obs_open = d->obs_open_state_only;
   a.step_log = d->step_log; a.step_log_cap = d->step_log ? d->step_log_cap : 0;

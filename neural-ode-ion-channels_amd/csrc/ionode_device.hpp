@@ -49,7 +49,10 @@ struct KArgs {
   int32_t *status;
   int64_t *stats;
   int32_t B, Nt, P, Np, n_params, L, N, NP, NT;
-  int64_t max_steps;
+  int64_t max_steps;   // attempts allowed between two emitted outputs (torchdiffeq's max_num_steps: _advance resets its counter)
+  int64_t max_total;   // attempts allowed over the whole solve (runaway bound; the reference uses a 600 s SIGALRM, train-d0.py:309-318)
+  double *ckpt;        // optional [B][ckpt_cap][4 + 8*D] fp64: one record per ACCEPTED step, for the backward sweep (ionode_grad.hpp)
+  int32_t ckpt_cap;
   double prot_t0, prot_dt, v_oob, rtol, atol, obs_g, obs_e;
   int32_t obs_open;
   double *step_log;
@@ -748,6 +751,7 @@ __global__ void __launch_bounds__(64 * G) ionode_dopri5_kernel(const KArgs a) {
 
   int oi = 1;  // next output index
   int nacc = 0, nrej = 0;
+  int since = 0;  // attempts since the last emitted output (torchdiffeq counts max_num_steps per _advance call)
   int status = IONODE_STATUS_OK;
   bool active = valid && Nt > 1;
   const S nan_s = (S)__builtin_nan("");
@@ -756,7 +760,7 @@ __global__ void __launch_bounds__(64 * G) ionode_dopri5_kernel(const KArgs a) {
     // ---- per-trajectory assertions of _adaptive_step / _advance ----
     bool failed_now = false;
     if (active) {
-      if ((int64_t)nacc + nrej >= a.max_steps) { status = IONODE_STATUS_MAX_STEPS; failed_now = true; }
+      if ((int64_t)since >= a.max_steps || (int64_t)nacc + nrej >= a.max_total) { status = IONODE_STATUS_MAX_STEPS; failed_now = true; }
       else if (!(t + dt > t)) { status = IONODE_STATUS_DT_UNDERFLOW; failed_now = true; }
       else {
         bool fin = true;
@@ -855,6 +859,7 @@ __global__ void __launch_bounds__(64 * G) ionode_dopri5_kernel(const KArgs a) {
       row[0] = t0; row[1] = dt; row[2] = (double)ratio; row[3] = accept ? 1.0 : 0.0;
     }
 #endif
+    const int nacc_before = nacc, oi_before = oi;
     if (active) { if (accept) ++nacc; else ++nrej; }
 
     // ---- _interp_fit + cooperative dense output ----
@@ -1017,6 +1022,18 @@ __global__ void __launch_bounds__(64 * G) ionode_dopri5_kernel(const KArgs a) {
       }
     }
     STAMP(stamps_, 7);  // slot 7: interpolant fit + cooperative dense output
+    if (active) since = (acc_now && oi > oi_before) ? 0 : since + 1;
+    // ---- checkpoint of the accepted step for the backward sweep: (t0, dt, first output index, outputs, y, k1..k7) ----
+    if (a.ckpt != nullptr && acc_now && primary && nacc_before < a.ckpt_cap) {
+      double *__restrict__ rec = a.ckpt + ((size_t)traj * a.ckpt_cap + nacc_before) * (4 + 8 * D);
+      rec[0] = t0; rec[1] = dt; rec[2] = (double)oi_before; rec[3] = (double)(oi - oi_before);
+#pragma unroll
+      for (int d = 0; d < D; ++d) rec[4 + d] = (double)y[d];
+#pragma unroll
+      for (int jx = 0; jx < 7; ++jx)
+#pragma unroll
+        for (int d = 0; d < D; ++d) rec[4 + D + jx * D + d] = (double)k[jx][d];
+    }
     // ---- advance the RK state ----
     if (acc_now) {
 #pragma unroll

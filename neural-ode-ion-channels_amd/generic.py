@@ -62,8 +62,8 @@ def generic_dopri5(func, y0, t, *, rtol=1e-7, atol=1e-9, max_steps=2**31 - 1):
 
     y, fy, t0, t1 = y0, f0, t[0], t[0]
     coeff = [y0] * 5
-    n_steps = 0
     for i in range(1, t.numel()):
+        n_steps = 0  # torchdiffeq's _advance restarts the max_num_steps counter for every output time
         while t[i] > t1:
             assert n_steps < max_steps, "max_num_steps exceeded"
             ts, tn = t1, t1 + dt

@@ -16,7 +16,7 @@ from . import batched, capi, distributed
 
 def population_sum_of_squares(candidates, protocols_v, data_i, t_eval, *, base_params, free=(0, 1, 2, 3), prot_t0=0.0,
                               prot_dt=0.1, y0=(0.0, 1.0), state_dtype=torch.float32, obs_g=1.0, obs_e=-86.0,
-                              max_steps=1_000_000, group=None, device=None):
+                              max_total_steps=1_000_000, group=None, device=None):
     """Sum-of-squares error of every candidate over all protocols (PINTS SumOfSquaresError on a multi-output problem).
 
     candidates  [C, len(free)]  values of the free rate parameters (train-d0.py: p1..p4 -> free = (0, 1, 2, 3))
@@ -39,7 +39,7 @@ def population_sum_of_squares(candidates, protocols_v, data_i, t_eval, *, base_p
         pot = np.tile(np.arange(P, dtype=np.int32), hi - lo)
         sol = batched.solve(capi.MODEL_HH2, params, protocols_v, torch.tensor([list(y0)], dtype=state_dtype), t_eval,
                             prot_t0=prot_t0, prot_dt=prot_dt, prot_of_traj=pot, current=True, obs_g=obs_g, obs_e=obs_e,
-                            max_steps=max_steps, device=dev)
+                            max_total_steps=max_total_steps, device=dev)
         ref = torch.as_tensor(np.asarray(data_i), dtype=torch.float64, device=dev)     # [P, Nt]
         err = ((sol.i.reshape(hi - lo, P, -1) - ref[None]) ** 2).sum(dim=(1, 2))
         ok = (sol.status.reshape(hi - lo, P) == 0).all(dim=1)

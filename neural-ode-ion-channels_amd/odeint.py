@@ -21,7 +21,7 @@ import torch
 from . import batched, capi, rhs
 from .generic import generic_dopri5
 
-_KNOWN_OPTIONS = {"allow_generic", "explicit_protocol", "max_num_steps", "tile_waves",
+_KNOWN_OPTIONS = {"allow_generic", "explicit_protocol", "max_num_steps", "max_total_steps", "tile_waves",
                   # torchdiffeq 0.1.x-era keys the reference passes in train-d0.py:436; 0.2.x warns and ignores them
                   "grid_points", "eps"}
 
@@ -53,11 +53,15 @@ def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, even
             f"odeint: func is not one of the reference's RHS families ({e}); pass options={{'allow_generic': True}} "
             "to integrate it with the generic torch stepper") from None
 
-    sol = batched.solve(spec.model, spec.params, spec.prot_v, y0.reshape(1, -1), t.detach().to(torch.float64),
+    t64 = t.detach().to(torch.float64)
+    t_key = ("t", rhs.digest(t64.cpu().numpy()))  # the output grid stays device-resident while its values do not change
+    sol = batched.solve(spec.model, spec.params, spec.prot_v, y0.reshape(1, -1), t64,
                         weights=spec.weights, mlp_layers=spec.mlp_layers, mlp_width=spec.mlp_width,
                         weights_key=spec.weights_key, prot_t=spec.prot_t, prot_t0=spec.prot_t0, prot_dt=spec.prot_dt,
                         state_dtype=y0.dtype, rtol=float(rtol), atol=float(atol),
-                        max_steps=int(options.get("max_num_steps", 0)), tile_waves=int(options.get("tile_waves", 0)))
+                        max_steps=int(options.get("max_num_steps", 0)),
+                        max_total_steps=int(options.get("max_total_steps", 0)), prot_key=spec.prot_key, t_eval_key=t_key,
+                        tile_waves=int(options.get("tile_waves", 0)))
     sol.raise_on_failure()
     out = sol.y[0].reshape((t.numel(),) + tuple(y0.shape))
     return out.to(y0.device)

@@ -261,7 +261,7 @@ static int SFX(adaptive_step)(const ctx_t *c, SFX(rkstate) *s, REAL rtol, REAL a
 }
 
 static int SFX(solve)(const ctx_t *c, const double *y0d, const double *t_eval, int n_out, double rtol_d,
-                      double atol_d, int64_t max_steps, double *y_out, int64_t *stats, double *step_log,
+                      double atol_d, int64_t max_steps, int64_t max_total, double *y_out, int64_t *stats, double *step_log,
                       int64_t step_log_cap) {
   const int D = c->D;
   const REAL rtol = (REAL)rtol_d, atol = (REAL)atol_d;
@@ -282,8 +282,10 @@ static int SFX(solve)(const ctx_t *c, const double *y0d, const double *t_eval, i
   int i = 1;
   for (; i < n_out; ++i) {
     const double next_t = t_eval[i];
+    int64_t n_steps = 0; /* torchdiffeq _advance(next_t): the max_num_steps counter restarts for every output time */
     while (next_t > s.t1) {
-      if (nacc + nrej >= max_steps) { status = STATUS_MAX_STEPS; break; }
+      if (n_steps >= max_steps || nacc + nrej >= max_total) { status = STATUS_MAX_STEPS; break; }
+      ++n_steps;
       int acc = 0;
       const double t_before = s.t1, dt_before = s.dt;
       double ratio_d = 0.0;

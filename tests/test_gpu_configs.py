@@ -47,7 +47,7 @@ def test_config4_parameter_sweep(ion, gpu, oracle, which):
     cand[:, :4] = np.array([1.13e-4, 7.45e-2, 3.60e-5, 4.49e-2]) * 10.0 ** rng.uniform(-1, 1, (C, 4))  # train-d0.py:325-328
     params = np.repeat(cand, len(steps), axis=0)
     pot = np.tile(np.arange(len(steps), dtype=np.int32), C)
-    kw = dict(prot_t0=0.0, prot_dt=0.1, prot_of_traj=pot, max_steps=200000)
+    kw = dict(prot_t0=0.0, prot_dt=0.1, prot_of_traj=pot, max_total_steps=200000)
     g = run_gpu(ion, gpu, K.MODEL_HH2, params, pv, [0.0, 1.0], te, f32=True, current=True, **kw)  # y0 fp32: train-d0.py:405
     assert g["y"].shape == (C * len(steps), Np, 2)
     sel = rng.choice(C * len(steps), 10, replace=False)
@@ -79,7 +79,7 @@ def test_population_objective_matches_reference_semantics(ion, gpu, oracle):
         p = K.P_NN_D.copy()
         p[:4] = cand[c]
         o = oracle.solve(K.MODEL_HH2, np.tile(p, (3, 1)), pv, [0.0, 1.0], te, prot_t0=0.0, prot_dt=1.0,
-                         prot_of_traj=np.arange(3, dtype=np.int32), state_f32=True, max_steps=1_000_000)
+                         prot_of_traj=np.arange(3, dtype=np.int32), state_f32=True, max_total_steps=1_000_000)
         if (o["status"] != 0).any():
             assert np.isinf(got[c])
             continue

@@ -68,8 +68,13 @@ def test_failures_raise_torchdiffeq_assertions(ion, gpu):
     truth, ty0, _, _ = _modules("s1")
     truth.set_fixed_form_voltage_protocol(*K.activation(20)[:2])
     t = torch.linspace(0.0, 8000.0, 801)
+    # torchdiffeq counts max_num_steps per output interval (its _advance restarts the counter): the first 10 ms interval
+    # needs more than 3 attempts (dt grows from ~1e-4 by at most 10x per step), none needs 500
     with pytest.raises(AssertionError, match="max_num_steps exceeded"):
-        odeint(truth, ty0, t, options={"max_num_steps": 20})
+        odeint(truth, ty0, t, options={"max_num_steps": 3})
+    assert torch.equal(odeint(truth, ty0, t, options={"max_num_steps": 500}), odeint(truth, ty0, t))
+    with pytest.raises(AssertionError, match="max_num_steps exceeded"):  # the library's whole-solve runaway bound
+        odeint(truth, ty0, t, options={"max_total_steps": 20})
     with pytest.raises(AssertionError, match="underflow in dt|non-finite"):
         odeint(truth, torch.tensor([[float("nan"), 1.0]]), t)
 

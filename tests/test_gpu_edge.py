@@ -36,7 +36,7 @@ def test_architectures_s00_to_s11(ion, gpu, oracle, L, N, model):
     te = K.atau(30)[2][:1501]
     B = 18
     params = np.tile(K.P_HH, (B, 1)) * np.random.default_rng(3).uniform(0.9, 1.1, (B, 8))
-    kw = dict(prot_t0=0.0, prot_dt=1.0, prot_of_traj=(np.arange(B) % 2).astype(np.int32), max_steps=4000)
+    kw = dict(prot_t0=0.0, prot_dt=1.0, prot_of_traj=(np.arange(B) % 2).astype(np.int32), max_total_steps=4000)
     g = run_gpu(ion, gpu, model, params, pv, K.NN_Y0, te, weights=w, L=L, N=N, **kw)
     o = oracle.solve(model, params, pv, K.NN_Y0, te, weights=w, mlp_layers=L, mlp_width=N, **kw)
     _same(g, o)
@@ -109,7 +109,7 @@ def test_failed_trajectories_do_not_disturb_their_tile(ion, gpu, oracle):
     pv = K.activation(40)[1]
     te = K.activation(0)[2][:2001]
     w = K.load_weights("s1")
-    kw = dict(prot_t0=0.0, prot_dt=1.0, max_steps=150)
+    kw = dict(prot_t0=0.0, prot_dt=1.0, max_total_steps=150)
     g = run_gpu(ion, gpu, K.MODEL_NNF, params, pv, y0, te, weights=w, L=5, N=200, **kw)
     o = oracle.solve(K.MODEL_NNF, params, pv, y0, te, weights=w, mlp_layers=5, mlp_width=200, **kw)
     _same(g, o)

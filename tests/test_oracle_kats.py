@@ -6,18 +6,18 @@ container, so these artefacts are what pins parity at the odeint boundary:
     dopri5 solves in fp32 state (NN RHS + ground-truth RHS) -> tests/golden/kat_losses.json
   * the 80 001-sample HH current trace cached in figure-0-s/i_n.pt (seeded noise removed)
 
-Tolerances: the reference's solves run with rtol = 1e-7 ~ fp32 epsilon, so its accept/reject
-sequence is rounding-noise driven and not reproducible across BLAS builds; an independent fp32
-restatement lands within ~1e-5 of the 6-decimal logged values (SURVEY.md finding 4).  We assert
-|loss - logged| <= 5e-5 for every KAT and a median <= 5e-6.
+Tolerances: SURVEY.md 8d's contract, |loss - logged| <= 2e-5 for every KAT and a median <= 5e-6.
+The reference's solves run with rtol = 1e-7 ~ fp32 epsilon, so its accept/reject sequence is
+rounding-noise driven; two of the 92 logged numbers are themselves > 1.7e-5 from the converged
+solution of their ODE -- kat_cases.kat_within_tolerance states the rule and names them.
 """
 import numpy as np
 import pytest
 
 import kat_cases as K
 
-ABS_TOL = 5e-5
-MEDIAN_TOL = 5e-6
+ABS_TOL = K.KAT_ABS_TOL
+MEDIAN_TOL = K.KAT_MEDIAN_TOL
 
 
 def test_tableau_identities(oracle):
@@ -25,13 +25,13 @@ def test_tableau_identities(oracle):
     assert abs(se) < 1e-16 and abs(ss - 1) < 1e-15 and abs(sm - 0.5) < 1e-15 and mb < 1e-15
 
 
-def _kat_loss(oracle, m, case, state_f32=True):
+def _kat_loss(oracle, m, case, state_f32=True, rtol=1e-7, atol=1e-9):
     tm, tp, ty0, nm, npar = K.MODELS[m]
     pt, pv, te = case
     w = K.load_weights(m)
-    tr = oracle.solve(tm, tp, pv, ty0, te, prot_t=pt, state_f32=state_f32)
+    tr = oracle.solve(tm, tp, pv, ty0, te, prot_t=pt, state_f32=state_f32, rtol=rtol, atol=atol)
     nn = oracle.solve(nm, npar, pv, K.NN_Y0, te, prot_t=pt, weights=w, mlp_layers=K.MLP_L,
-                      mlp_width=K.MLP_N, state_f32=state_f32)
+                      mlp_width=K.MLP_N, state_f32=state_f32, rtol=rtol, atol=atol)
     assert tr["status"][0] == 0 and nn["status"][0] == 0
     v, inr = oracle.protocol_v(pv, te, prot_t=pt)
     assert inr.all()
@@ -48,9 +48,11 @@ def test_logged_prediction_losses(oracle, m):
         got = _kat_loss(oracle, m, case)
         exp = K.expected(kats, m, sec, key)
         diffs.append(abs(got - exp))
-        assert abs(got - exp) <= ABS_TOL, f"{m} {sec} {key}: {got:.6f} vs logged {exp:.6f}"
+        assert K.kat_within_tolerance(got, exp, lambda: _kat_loss(oracle, m, case, False, 1e-10, 1e-12)), \
+            f"{m} {sec} {key}: {got:.6f} vs logged {exp:.6f}"
     assert len(diffs) == 23
     assert np.median(diffs) <= MEDIAN_TOL
+    assert sum(d > ABS_TOL for d in diffs) <= (2 if m == "s1" else 0)  # the two named cases, no others
 
 
 def test_fp64_state_agrees_with_logged_losses(oracle):
@@ -59,6 +61,24 @@ def test_fp64_state_agrees_with_logged_losses(oracle):
     for sec, key, case in K.all_cases()[:8]:
         got = _kat_loss(oracle, "s1", case, state_f32=False)
         assert abs(got - K.expected(kats, "s1", sec, key)) <= ABS_TOL
+
+
+def test_outliers_are_the_references_own_rounding_noise(oracle):
+    """The two s1 values that miss 2e-5: the converged solution (fp64 state, rtol 1e-10) is itself 1.7e-5 / 2.6e-5 from
+    the logged number, fp32 and fp64 state at the reference's tolerance scatter around it by ~1e-5, and a one-notch
+    change of rtol moves the value by more than the residual -- accept/reject noise, not a modelling difference."""
+    kats = K.load_kats()
+    for key, case in (("-70.0", K.deactivation(-70)), ("-50.0", K.deactivation(-50))):
+        logged = K.expected(kats, "s1", "deact", key)
+        conv = _kat_loss(oracle, "s1", case, False, 1e-10, 1e-12)
+        conv2 = _kat_loss(oracle, "s1", case, False, 1e-11, 1e-13)
+        assert abs(conv - conv2) <= 1e-6                   # converged: tightening further changes nothing
+        assert 1e-5 < abs(logged - conv) < 3e-5            # the logged value is off the converged answer
+        f32 = _kat_loss(oracle, "s1", case, True)
+        f64 = _kat_loss(oracle, "s1", case, False)
+        assert abs(f32 - conv) <= 2e-5 and abs(f64 - conv) <= 2e-5
+        nudged = _kat_loss(oracle, "s1", case, True, rtol=1.5e-7)
+        assert abs(nudged - f32) > 2e-6                    # the value moves at the 1e-5 level with the step sequence
 
 
 def _fig0s_protocol():
@@ -103,8 +123,14 @@ def test_uniform_grid_lookup_equals_explicit_times(oracle):
 def test_failure_status_codes(oracle):
     """max-steps and non-finite states end a trajectory with a status code and NaN-filled tail."""
     pt, v, te = K.activation(20)
-    r = oracle.solve(K.MODEL_HH2, K.P_HH, v, [0.0, 1.0], te, prot_t=pt, max_steps=50)
+    r = oracle.solve(K.MODEL_HH2, K.P_HH, v, [0.0, 1.0], te, prot_t=pt, max_total_steps=50)
     assert r["status"][0] == 3 and np.isnan(r["y"][0, -1]).all() and np.isfinite(r["y"][0, 0]).all()
+    # max_steps is torchdiffeq's max_num_steps: per output interval (1 ms grid here).  Some interval (a voltage step)
+    # needs more than 3 attempts; no interval needs 200; the whole solve needs far more than 200
+    r3 = oracle.solve(K.MODEL_HH2, K.P_HH, v, [0.0, 1.0], te, prot_t=pt, max_steps=3)
+    assert r3["status"][0] == 3 and r3["stats"][0, 0] + r3["stats"][0, 1] > 3
+    r200 = oracle.solve(K.MODEL_HH2, K.P_HH, v, [0.0, 1.0], te, prot_t=pt, max_steps=200)
+    assert r200["status"][0] == 0 and r200["stats"][0, 0] + r200["stats"][0, 1] > 200
     # a non-finite start makes dt NaN: torchdiffeq's first assertion ('underflow in dt') fires before
     # the 'non-finite values in state' one, so status is 1 here; both are failures with a NaN tail
     r = oracle.solve(K.MODEL_HH2, K.P_HH, v, [np.inf, 1.0], te, prot_t=pt)
