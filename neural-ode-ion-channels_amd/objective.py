@@ -16,13 +16,15 @@ from . import batched, capi, distributed
 
 def population_sum_of_squares(candidates, protocols_v, data_i, t_eval, *, base_params, free=(0, 1, 2, 3), prot_t0=0.0,
                               prot_dt=0.1, y0=(0.0, 1.0), state_dtype=torch.float32, obs_g=1.0, obs_e=-86.0,
-                              max_total_steps=1_000_000, group=None, device=None):
+                              max_total_steps=1_000_000, group=None, device=None, solver=None):
     """Sum-of-squares error of every candidate over all protocols (PINTS SumOfSquaresError on a multi-output problem).
 
     candidates  [C, len(free)]  values of the free rate parameters (train-d0.py: p1..p4 -> free = (0, 1, 2, 3))
     protocols_v [P, Np] mV;  data_i [P, Nt] measured currents;  t_eval [Nt] ms;  base_params [8]
     Returns a [C] fp64 tensor on the device: inf where any of a candidate's solves failed (the reference's time-limit
     rule).  Under torch.distributed the candidates are sharded over the ranks and the result is all-gathered.
+    `solver` (tests only): a stand-in with batched.solve's signature, so the sharding / all-gather logic can run under
+    gloo on a box without a GPU; the product default is the HIP solve and there is no CPU fallback.
     """
     import torch.distributed as dist
     cand = np.asarray(candidates, dtype=np.float64)
@@ -30,14 +32,15 @@ def population_sum_of_squares(candidates, protocols_v, data_i, t_eval, *, base_p
     on = dist.is_available() and dist.is_initialized()
     rank, world = (dist.get_rank(group), dist.get_world_size(group)) if on else (0, 1)
     lo, hi = distributed.shard_bounds(C, rank, world)
-    dev = batched._dev(device)
+    dev = batched._dev(device) if solver is None else torch.device(device or "cpu")
+    solve = batched.solve if solver is None else solver
     sse = torch.full((hi - lo,), float("inf"), dtype=torch.float64, device=dev)
     if hi > lo:
         params = np.tile(np.asarray(base_params, dtype=np.float64), (hi - lo, 1))
         params[:, list(free)] = cand[lo:hi]
         params = np.repeat(params, P, axis=0)                       # candidate-major: trajectory = c*P + p
         pot = np.tile(np.arange(P, dtype=np.int32), hi - lo)
-        sol = batched.solve(capi.MODEL_HH2, params, protocols_v, torch.tensor([list(y0)], dtype=state_dtype), t_eval,
+        sol = solve(capi.MODEL_HH2, params, protocols_v, torch.tensor([list(y0)], dtype=state_dtype), t_eval,
                             prot_t0=prot_t0, prot_dt=prot_dt, prot_of_traj=pot, current=True, obs_g=obs_g, obs_e=obs_e,
                             max_total_steps=max_total_steps, device=dev)
         ref = torch.as_tensor(np.asarray(data_i), dtype=torch.float64, device=dev)     # [P, Nt]

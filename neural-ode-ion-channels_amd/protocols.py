@@ -103,5 +103,19 @@ def deactivation_pr5(v_step, dt=0.1):
     return v
 
 
+def pr4_synthetic(k, n_samples=29006, dt=0.1):
+    """Pr4 sweep k of 16.  The reference only records Pr4's SHAPE (16 sweeps x 29 006 samples of 0.1 ms,
+    train-r1.py:353 + figure-3/y1-pr4.pt); its wave-form lives in the missing data CSVs, so this is a synthetic
+    three-step sweep of that shape: -80 mV hold, 1 s conditioning step to -50..+40 mV (6 mV apart), 0.5 s at -120 mV,
+    back to -80 mV."""
+    if not 0 <= k < 16:
+        raise ValueError("Pr4 has 16 sweeps")
+    t = np.arange(n_samples, dtype=np.float64) * dt
+    v = np.full(n_samples, -80.0)
+    v[(t >= 500.0) & (t < 1500.0)] = -50.0 + 6.0 * k
+    v[(t >= 1500.0) & (t < 2000.0)] = -120.0
+    return v
+
+
 PR3_STEPS = (-60, -40, -20, 0, 20, 40, 60)                   # train-s1.py:77
 PR5_STEPS = (-120, -110, -100, -90, -80, -70, -60, -50, -40)  # train-s1.py:92

@@ -38,7 +38,7 @@ def test_reference_prediction_flow_reproduces_logged_losses(ion, gpu, oracle, na
             v = func._v(t) + 86
             gate_t = yt[:, 0, -1] if tm == K.MODEL_MARKOV6 else yt[:, 0, 0] * yt[:, 0, 1]
             loss = torch.mean(torch.abs(yp[:, 0, 0] * yp[:, 0, 1] * v - gate_t.cpu() * v)).item()
-            assert abs(loss - K.expected(kats, name, sec, key)) <= 5e-5, (name, sec, key, loss)
+            assert abs(loss - K.expected(kats, name, sec, key)) <= K.KAT_ABS_TOL, (name, sec, key, loss)
             # and the same call is the oracle's fp32-state solve, bit for bit
             o = oracle.solve(nm, npar, pv, K.NN_Y0, te, prot_t=None if sec != "AP 2Hz" else None, prot_t0=float(pt[0]),
                              prot_dt=float((pt[-1] - pt[0]) / (pt.size - 1)), weights=K.load_weights(name),
