@@ -135,6 +135,54 @@ const char *ionode_kernel_name(const ionode_desc *d);
 const char *ionode_last_error(void);
 int32_t ionode_abi_version(void);
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Gradients through the solve (BASELINE.json configs[4]).  Reference interface: `from torchdiffeq import odeint_adjoint as
+ * odeint` (train-s1.py:29-32) -- the reference only switches this import and never differentiates (SURVEY.md finding 3),
+ * so what is computed is defined here: the exact reverse-mode derivative of the discretisation the forward launch executed,
+ * with its accepted steps (t0, dt) as constants; rejected attempts do not contribute.  NN-f / NN-d, N <= 208.
+ *
+ * Flow (all pointers DEVICE unless noted):
+ *   1. forward:  ionode_dopri5() with d->ckpt / d->ckpt_cap set; n_accepted[b] = stats[b][0] for status[b] == 0, else 0
+ *   2. sweep:    ionode_dopri5_backward() over iterations [0, n_iter), n_iter = max(n_accepted) + 1, in one launch or in
+ *                chunks [it_begin, it_end) (the adjoint state is carried in `state`); each tile-evaluation appends one record
+ *                of ionode_grad_record_floats() floats to `records` ([tiles][it_end - it_begin][6] records per chunk)
+ *   3. reduce:   ionode_grad_reduce() contracts a chunk's records into n_slabs partial weight gradients; the caller sums
+ *                the partials (and the chunks) and un-pads them (layout: ionode_grad_partial_floats)
+ * ------------------------------------------------------------------------------------------------------------------- */
+
+/* HOST -> HOST: flat state dict (ionode_mlp_pack's input order) -> grad image (forward AND transposed MFMA fragments). */
+size_t ionode_grad_image_floats(int32_t mlp_layers, int32_t mlp_width);
+int ionode_grad_pack(const float *state_dict_flat, int32_t mlp_layers, int32_t mlp_width, float *image);
+
+/* floats of one record (one MLP vector-Jacobian product of one 16-trajectory tile): h_0..h_L, d_0..d_L tiles + 64 scalars */
+size_t ionode_grad_record_floats(int32_t mlp_layers, int32_t mlp_width);
+
+/*
+ * Backward sweep, asynchronous on `stream`.  d: the forward launch's descriptor (model, state dtype, sizes, protocol grid,
+ * v_oob, ckpt, ckpt_cap).
+ *   grad_image   device, ionode_grad_image_floats() floats
+ *   n_accepted   device, [B] int32: accepted steps to replay per trajectory (0 = contributes nothing)
+ *   grad_y       device, [B][n_out][2] dL/dy_out in the state dtype
+ *   state        device, [B][12] fp64 scratch carried between chunk launches (need not be initialised for it_begin == 0)
+ *   records      device, [ceil(B/16)][it_end - it_begin][6][record floats] fp32, or NULL to skip the weight-gradient stream
+ *   grad_params  device, [B][8] fp64 dL/dp1..p8      (written by the launch with it_end == n_iter)
+ *   grad_y0      device, [B][2] fp64 dL/dy0
+ */
+int ionode_dopri5_backward(const ionode_desc *d, int32_t it_begin, int32_t it_end, int32_t n_iter, const float *grad_image,
+                           const double *params, const double *prot_v, const double *prot_t, const int32_t *prot_of_traj,
+                           const double *t_eval, const int32_t *n_accepted, const void *grad_y, double *state,
+                           float *records, double *grad_params, double *grad_y0, void *stream);
+
+/* floats of one slab's partial gradient: [NP][4]{db0, dW0[.][0], dW0[.][1], 0} | L x (dW_l [NP][NP] + db_l [NP]) | dwl [NP] +
+ * {dbl, 0, 0, 0}, NP = 16 * ceil(N / 16), rows/columns >= N are padding */
+size_t ionode_grad_partial_floats(int32_t mlp_layers, int32_t mlp_width);
+
+/* partials[n_slabs][ionode_grad_partial_floats()] = per-slab sums over records [n_records * s / n_slabs, ...); asynchronous */
+int ionode_grad_reduce(int32_t mlp_layers, int32_t mlp_width, const float *records, int64_t n_records, int32_t n_slabs,
+                       float *partials, void *stream);
+
+const char *ionode_grad_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,8 @@ ABI_VERSION = 3
 EXPORTS = (
     "ionode_abi_version", "ionode_last_error", "ionode_mlp_packed_floats", "ionode_mlp_pack",
     "ionode_launch_geometry", "ionode_kernel_name", "ionode_dopri5",
+    "ionode_grad_image_floats", "ionode_grad_pack", "ionode_grad_record_floats", "ionode_dopri5_backward",
+    "ionode_grad_partial_floats", "ionode_grad_reduce", "ionode_grad_last_error",
 )
 
 
@@ -78,6 +80,16 @@ def lib():
         L.ionode_launch_geometry.argtypes = [C.POINTER(IonodeDesc), C.POINTER(C.c_int32 * 4)]
         L.ionode_dopri5.restype = C.c_int
         L.ionode_dopri5.argtypes = [C.POINTER(IonodeDesc)] + [C.c_void_p] * 12
+        L.ionode_grad_last_error.restype = C.c_char_p
+        for fn in (L.ionode_grad_image_floats, L.ionode_grad_record_floats, L.ionode_grad_partial_floats):
+            fn.restype = C.c_size_t
+            fn.argtypes = [C.c_int32, C.c_int32]
+        L.ionode_grad_pack.restype = C.c_int
+        L.ionode_grad_pack.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        L.ionode_dopri5_backward.restype = C.c_int
+        L.ionode_dopri5_backward.argtypes = [C.POINTER(IonodeDesc), C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 13
+        L.ionode_grad_reduce.restype = C.c_int
+        L.ionode_grad_reduce.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
         if L.ionode_abi_version() != ABI_VERSION:
             raise IonodeError("libionode.so ABI version mismatch; rebuild")
         _lib = L

@@ -101,6 +101,14 @@ struct GradMlp {
     return __builtin_bit_cast(f32x4, v);
   }
 
+  // Record tiles are stored in the A/B-operand layout of ionode_grad_reduce's MFMAs (contraction over the 16 trajectories):
+  // G[16*kk + m][c] = X[row 16*rt + m][trajectory 4*c + kk].  This lane holds rows 4q + r of trajectory n = lane & 15.
+  __device__ __forceinline__ void rec_store(f32x4 *tile, const f32x4 &v) const {
+    const int q = lane >> 4, n = lane & 15;
+    float *p = reinterpret_cast<float *>(tile) + 64 * (n & 3) + 16 * q + (n >> 2);
+    p[0] = v[0]; p[4] = v[1]; p[8] = v[2]; p[12] = v[3];
+  }
+
   // acc[i] (+)= A(sec, l)[row tile wave + 4i][:] . B[:]   over all NT k-tiles; B read from LDS in accumulator layout
   __device__ __forceinline__ void product(unsigned sec, int l, const f32x4 *__restrict__ B, f32x4 (&acc)[RT]) const {
 #pragma unroll
@@ -137,7 +145,7 @@ struct GradMlp {
           h[r] = lrelu(fmaf(w[2], x1, fmaf(w[1], x0, w[0])));
         }
         Hs[rt * 64 + lane] = h;
-        if (rec) recH[rt * 64 + lane] = h;
+        if (rec) rec_store(recH + rt * 64, h);
       }
     }
     __syncthreads();
@@ -157,7 +165,7 @@ struct GradMlp {
 #pragma unroll
           for (int r = 0; r < 4; ++r) h[r] = lrelu(acc[i][r]);
           Hs[((size_t)l * NT + rt) * 64 + lane] = h;
-          if (rec) recH[((size_t)l * NT + rt) * 64 + lane] = h;
+          if (rec) rec_store(recH + ((size_t)l * NT + rt) * 64, h);
         }
       }
       __syncthreads();
@@ -173,7 +181,7 @@ struct GradMlp {
 #pragma unroll
         for (int r = 0; r < 4; ++r) d[r] = (seed * w[r]) * (h[r] > 0.0f ? 1.0f : 0.01f);
         Ds[((L & 1) * NT + rt) * 64 + lane] = d;
-        if (rec) recD[((size_t)L * NT + rt) * 64 + lane] = d;
+        if (rec) rec_store(recD + ((size_t)L * NT + rt) * 64, d);
       }
     }
     __syncthreads();
@@ -191,7 +199,7 @@ struct GradMlp {
 #pragma unroll
           for (int r = 0; r < 4; ++r) d[r] = acc[i][r] * (h[r] > 0.0f ? 1.0f : 0.01f);
           Ds[(((l - 1) & 1) * NT + rt) * 64 + lane] = d;
-          if (rec) recD[((size_t)(l - 1) * NT + rt) * 64 + lane] = d;
+          if (rec) rec_store(recD + ((size_t)(l - 1) * NT + rt) * 64, d);
         }
       }
       __syncthreads();

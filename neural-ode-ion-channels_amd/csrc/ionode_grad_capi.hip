@@ -1,0 +1,147 @@
+// ionode_grad_capi.hip -- C ABI of the gradient path (include/ionode.h, "gradients through the solve"): the grad image
+// packer, the backward-sweep launcher and the weight-gradient reduction launcher.
+#include <cstdio>
+#include <cstring>
+
+#include "ionode_grad.hpp"
+#include "ionode_grad_reduce.hpp"
+
+namespace {
+
+thread_local char g_gerr[256] = "";
+void gerr(const char *m) { snprintf(g_gerr, sizeof g_gerr, "%s", m); }
+
+inline int np_of(int N) { return 16 * ((N + 15) / 16); }
+
+using SweepFn = void (*)(const ionode::GArgs &, unsigned grid, size_t lds, hipStream_t);
+
+template <int MODEL, typename S, int NT>
+void launch_sweep(const ionode::GArgs &a, unsigned grid, size_t lds, hipStream_t s) {
+  auto kern = ionode::ionode_dopri5_backward_kernel<MODEL, S, NT>;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
+}
+
+template <int NT> SweepFn pick_sweep(int model, int f32) {
+  if (model == IONODE_MODEL_NNF) return f32 ? &launch_sweep<IONODE_MODEL_NNF, float, NT> : &launch_sweep<IONODE_MODEL_NNF, double, NT>;
+  return f32 ? &launch_sweep<IONODE_MODEL_NND, float, NT> : &launch_sweep<IONODE_MODEL_NND, double, NT>;
+}
+
+// the widths of architectures/s00-s11.py whose activations fit the LDS of one CU: N = 10, 100, 200
+SweepFn find_sweep(int model, int f32, int NT) {
+  switch (NT) {
+    case 1: return pick_sweep<1>(model, f32);
+    case 7: return pick_sweep<7>(model, f32);
+    case 13: return pick_sweep<13>(model, f32);
+    default: return nullptr;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *ionode_grad_last_error(void) { return g_gerr; }
+
+size_t ionode_grad_image_floats(int32_t L, int32_t N) {
+  if (L < 1 || N < 1) return 0;
+  return ionode::grad_img_floats(L, np_of(N) / 16);
+}
+
+size_t ionode_grad_record_floats(int32_t L, int32_t N) {
+  if (L < 1 || N < 1) return 0;
+  return (size_t)ionode::grad_record_floats(L, np_of(N) / 16);
+}
+
+int ionode_grad_pack(const float *w, int32_t L, int32_t N, float *out) {
+  if (!w || !out || L < 1 || N < 1) { gerr("ionode_grad_pack: bad argument"); return IONODE_ERR_ARG; }
+  const int NP = np_of(N), NT = NP / 16;
+  memset(out, 0, ionode::grad_img_floats(L, NT) * sizeof(float));
+  const float *W0 = w, *b0 = w + (size_t)N * 2;
+  for (int r = 0; r < N; ++r) {
+    out[4 * r + 0] = b0[r];
+    out[4 * r + 1] = W0[2 * r + 0];
+    out[4 * r + 2] = W0[2 * r + 1];
+  }
+  const float *src = b0 + N;
+  float *bias = out + ionode::grad_img_bias(NT);
+  float *fw = out + ionode::grad_img_fwd(L, NT), *bw = out + ionode::grad_img_bwd(L, NT);
+  for (int l = 0; l < L; ++l) {
+    const float *W = src, *b = src + (size_t)N * N;
+    for (int r = 0; r < N; ++r) bias[(size_t)l * NP + r] = b[r];
+    // A operand of v_mfma_f32_16x16x4_f32, k-step r: lane = 16*kq + m supplies A[m][kq]; with the forward kernel's
+    // k-permutation that is row 16*rt + m, contraction index 16*kt + 4*kq + r.  Transposed section: W^T.
+    for (int rt = 0; rt < NT; ++rt)
+      for (int kt = 0; kt < NT; ++kt)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int m = lane & 15, kq = lane >> 4;
+          const size_t f = ((((size_t)l * NT + rt) * NT + kt) * 64 + lane) * 4;
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * rt + m, k = 16 * kt + 4 * kq + r;
+            const bool in = row < N && k < N;
+            fw[f + r] = in ? W[(size_t)row * N + k] : 0.0f;
+            bw[f + r] = in ? W[(size_t)k * N + row] : 0.0f;
+          }
+        }
+    src += (size_t)N * N + N;
+  }
+  float *wl = out + ionode::grad_img_wl(L, NT);
+  for (int k = 0; k < N; ++k) wl[k] = src[k];
+  wl[NP] = src[N];
+  return IONODE_OK;
+}
+
+int ionode_dopri5_backward(const ionode_desc *d, int32_t it_begin, int32_t it_end, int32_t n_iter, const float *grad_image,
+                           const double *params, const double *prot_v, const double *prot_t, const int32_t *prot_of_traj,
+                           const double *t_eval, const int32_t *n_accepted, const void *grad_y, double *state,
+                           float *records, double *grad_params, double *grad_y0, void *stream) {
+  if (!d) { gerr("null descriptor"); return IONODE_ERR_ARG; }
+  if (d->model != IONODE_MODEL_NNF && d->model != IONODE_MODEL_NND) { gerr("backward sweep: NN-f / NN-d only"); return IONODE_ERR_UNSUPPORTED; }
+  if (d->n_state != 2 || d->n_traj < 1 || d->n_out < 1 || d->n_prot < 1 || d->prot_n < 2 || d->n_params < 8 || !(d->prot_dt > 0)) {
+    gerr("inconsistent descriptor"); return IONODE_ERR_ARG;
+  }
+  if (!grad_image || !params || !prot_v || !t_eval || !n_accepted || !grad_y || !state || !grad_params || !grad_y0 || !d->ckpt || d->ckpt_cap < 1) {
+    gerr("ionode_dopri5_backward: required buffer is NULL (ckpt / ckpt_cap come from the descriptor)"); return IONODE_ERR_ARG;
+  }
+  if (it_begin < 0 || it_end <= it_begin || it_end > n_iter) { gerr("bad iteration range"); return IONODE_ERR_ARG; }
+  if (d->mlp_layers < 1 || d->mlp_width < 1) { gerr("bad MLP shape"); return IONODE_ERR_ARG; }
+  const int NP = np_of(d->mlp_width), NT = NP / 16, L = d->mlp_layers;
+  SweepFn fn = find_sweep(d->model, d->state_f32 ? 1 : 0, NT);
+  const size_t lds = ionode::grad_lds_bytes(L, NT);
+  if (!fn || lds > 160 * 1024) {
+    gerr("backward sweep: (L, N) outside the compiled variants (N pads to 16, 112 or 208 and (L + 3) * N * 64 B must fit 160 KB of LDS)");
+    return IONODE_ERR_UNSUPPORTED;
+  }
+  ionode::GArgs a;
+  memset(&a, 0, sizeof a);
+  a.k.params = params; a.k.prot_v = prot_v; a.k.prot_t = prot_t; a.k.prot_of_traj = prot_of_traj; a.k.t_eval = t_eval;
+  a.k.B = d->n_traj; a.k.Nt = d->n_out; a.k.P = d->n_prot; a.k.Np = d->prot_n; a.k.n_params = d->n_params;
+  a.k.L = L; a.k.N = d->mlp_width; a.k.NP = NP; a.k.NT = NT;
+  a.k.prot_t0 = d->prot_t0; a.k.prot_dt = d->prot_dt; a.k.v_oob = d->v_oob;
+  a.img = grad_image; a.ckpt = d->ckpt; a.ckpt_cap = d->ckpt_cap; a.nacc = n_accepted; a.grad_y = grad_y; a.state = state;
+  a.records = records; a.grad_params = grad_params; a.grad_y0 = grad_y0;
+  a.it_begin = it_begin; a.it_end = it_end; a.n_iter = n_iter;
+  a.record_floats = ionode::grad_record_floats(L, NT);
+  fn(a, (unsigned)((d->n_traj + 15) / 16), lds, reinterpret_cast<hipStream_t>(stream));
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { gerr(hipGetErrorString(e)); return IONODE_ERR_LAUNCH; }
+  return IONODE_OK;
+}
+
+int ionode_grad_reduce(int32_t L, int32_t N, const float *records, int64_t n_records, int32_t n_slabs, float *partials,
+                       void *stream) {
+  if (!records || !partials || n_records < 1 || n_slabs < 1 || L < 1 || N < 1) { gerr("ionode_grad_reduce: bad argument"); return IONODE_ERR_ARG; }
+  const int NT = np_of(N) / 16;
+  const hipError_t e = ionode::launch_grad_reduce(L, NT, records, n_records, n_slabs, partials, reinterpret_cast<hipStream_t>(stream));
+  if (e == hipErrorInvalidValue) { gerr("ionode_grad_reduce: width outside the compiled variants"); return IONODE_ERR_UNSUPPORTED; }
+  if (e != hipSuccess) { gerr(hipGetErrorString(e)); return IONODE_ERR_LAUNCH; }
+  return IONODE_OK;
+}
+
+size_t ionode_grad_partial_floats(int32_t L, int32_t N) {
+  if (L < 1 || N < 1) return 0;
+  return ionode::grad_partial_floats(L, np_of(N) / 16);
+}
+
+}  // extern "C"

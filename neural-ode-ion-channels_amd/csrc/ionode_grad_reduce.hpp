@@ -1,0 +1,220 @@
+// ionode_grad_reduce.hpp -- weight gradients from the backward sweep's (d_l, h_l) record stream: a split-K fp32 MFMA GEMM.
+//
+//   dW_l[row][col] = sum over records, trajectories n:  d_l[row][n] * h_{l-1}[col][n]        l = 1..L   ("heavy" jobs)
+//   db_l[row]      = sum d_l[row][n]                                                         l = 0..L
+//   dW_0[row][c]   = sum d_0[row][n] * x_c[n]      (x = (V/100, a): the net's inputs)        ("light" job 0)
+//   dwl[k]         = sum seed[n] * h_L[k][n],  dbl = sum seed[n]                             ("light" job L+1)
+//
+// A record is one MLP vector-Jacobian product of one 16-trajectory tile (ionode_grad.hpp); its tiles are stored in the
+// operand layout of v_mfma_f32_16x16x4_f32 with the TRAJECTORY as contraction index: lane = 16*kk + m holds
+// X[16*rt + m][4*c + kk] in component c, so a 1 KiB tile is both an A operand (rows of d) and a B operand (rows of h) of four
+// MFMAs (c = 0..3) with one coalesced 16-byte load per lane.  Workgroup = (job, slab of records): the heavy jobs keep a whole
+// NP x NP accumulator (43 tiles per wavefront for N = 200) in registers, stage each record's 2 x NT tiles through LDS once
+// (double-buffered) and write one partial per slab; the host sums the slabs in fp64 (deterministic, no atomics).
+// Roofline: 2 * NP^2 * 16 FLOP per 2 * NT KiB of record -> 53 FLOP/B for N = 200: HBM- and MFMA-balanced at ~3 TB/s.
+#pragma once
+
+#include "ionode_grad.hpp"
+
+namespace ionode {
+
+// floats of one slab's partial: job 0 [NP][4] {db0, dW0[.][0], dW0[.][1], 0} | jobs 1..L: dW_l [NP][NP] + db_l [NP] | job L+1: dwl [NP] + {dbl,0,0,0}
+__host__ __device__ constexpr size_t grad_partial_floats(int L, int NT) {
+  return (size_t)4 * 16 * NT + (size_t)L * ((size_t)256 * NT * NT + 16 * NT) + 16 * NT + 4;
+}
+
+template <int NT>
+__global__ void __launch_bounds__(256) ionode_grad_reduce_kernel(const float *__restrict__ records, int64_t n_records, int n_slabs,
+                                                                 int L, float *__restrict__ partials) {
+  constexpr int NP = 16 * NT;
+  constexpr int F = NT / 4;        // full row tiles per wavefront (rt = wave + 4i, every column tile)
+  constexpr int R = NT - 4 * F;    // remainder row tiles, their column tiles dealt round-robin over the wavefronts
+  constexpr int RC = (NT + 3) / 4;
+  constexpr int STG = (2 * NT * 64 + 255) / 256;  // float4 loads per thread per record (d tiles + h tiles)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  f32x4 *buf = reinterpret_cast<f32x4 *>(smem);  // [2][2*NT*64]
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int job = blockIdx.x % (L + 2);
+  const int slab = blockIdx.x / (L + 2);
+  const int64_t r0 = n_records * slab / n_slabs, r1 = n_records * (slab + 1) / n_slabs;
+  const int64_t RECF = grad_record_floats(L, NT);
+  float *__restrict__ out = partials + (size_t)slab * grad_partial_floats(L, NT);
+  const int m = lane & 15, kk = lane >> 4;
+
+  if (job == 0 || job == L + 1) {
+    // ---- light jobs: one d (or h) tile set per record against per-trajectory scalars, VALU, straight from global ----
+    const bool first = job == 0;
+    float a0[RC], a1[RC], a2[RC];
+#pragma unroll
+    for (int i = 0; i < RC; ++i) a0[i] = a1[i] = a2[i] = 0.0f;
+    float sg = 0.0f;
+    for (int64_t rr = r0; rr < r1; ++rr) {
+      const float *rec = records + rr * RECF;
+      const f32x4 *tiles = reinterpret_cast<const f32x4 *>(rec) + (size_t)(first ? (L + 1) * NT : L * NT) * 64;  // D_0 | H_L
+      const float *sc = rec + (size_t)2 * (L + 1) * NT * 256;
+      float s0[4], s1[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        s0[c] = first ? sc[4 * c + kk] : sc[32 + 4 * c + kk];  // x0 | seed
+        s1[c] = first ? sc[16 + 4 * c + kk] : 0.0f;            // x1
+      }
+      if (!first && wave == 0 && lane < 16) sg += sc[32 + lane];
+#pragma unroll
+      for (int i = 0; i < RC; ++i) {
+        const int rt = wave + 4 * i;
+        if (rt < NT) {
+          const f32x4 t = tiles[rt * 64 + lane];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            a0[i] += first ? t[c] : t[c] * s0[c];
+            if (first) { a1[i] = fmaf(t[c], s0[c], a1[i]); a2[i] = fmaf(t[c], s1[c], a2[i]); }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RC; ++i) {
+      const int rt = wave + 4 * i;
+      float v0 = a0[i], v1 = a1[i], v2 = a2[i];
+      v0 += __shfl_xor(v0, 16); v0 += __shfl_xor(v0, 32);
+      v1 += __shfl_xor(v1, 16); v1 += __shfl_xor(v1, 32);
+      v2 += __shfl_xor(v2, 16); v2 += __shfl_xor(v2, 32);
+      if (rt < NT && lane < 16) {
+        if (first) {
+          float *o = out + (size_t)(16 * rt + m) * 4;
+          o[0] = v0; o[1] = v1; o[2] = v2; o[3] = 0.0f;
+        } else {
+          out[(size_t)4 * NP + (size_t)L * ((size_t)NP * NP + NP) + 16 * rt + m] = v0;
+        }
+      }
+    }
+    if (!first && wave == 0) {
+      float t = (lane < 16) ? sg : 0.0f;
+#pragma unroll
+      for (int s = 1; s < 16; s <<= 1) t += __shfl_xor(t, s);
+      if (lane == 0) {
+        float *o = out + (size_t)4 * NP + (size_t)L * ((size_t)NP * NP + NP) + NP;
+        o[0] = t; o[1] = o[2] = o[3] = 0.0f;
+      }
+    }
+    return;
+  }
+
+  // ---- heavy job l: dW_l += D_l . H_{l-1}^T over this slab's records ----
+  const int l = job;
+  f32x4 acc[F > 0 ? F : 1][NT], accr[R > 0 ? R : 1][RC], dba[F > 0 ? F : 1], dbr[R > 0 ? R : 1];
+#pragma unroll
+  for (int i = 0; i < F; ++i) {
+    dba[i] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) acc[i][ct] = f32x4{0, 0, 0, 0};
+  }
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    dbr[j] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < RC; ++u) accr[j][u] = f32x4{0, 0, 0, 0};
+  }
+  // staging: element e of the record's {D_l tiles, H_{l-1} tiles} (2*NT*64 float4), thread tid takes e = tid + 256*u
+  auto src_of = [&](int64_t rr, int e) -> const f32x4 * {
+    const f32x4 *base = reinterpret_cast<const f32x4 *>(records + rr * RECF);
+    return (e < NT * 64) ? base + (size_t)((L + 1) + l) * NT * 64 + e              // D_l
+                         : base + (size_t)(l - 1) * NT * 64 + (e - NT * 64);        // H_{l-1}
+  };
+  f32x4 stg[STG];
+  if (r0 < r1) {
+#pragma unroll
+    for (int u = 0; u < STG; ++u) {
+      const int e = threadIdx.x + 256 * u;
+      if (e < 2 * NT * 64) buf[e] = *src_of(r0, e);
+    }
+  }
+  __syncthreads();
+  for (int64_t rr = r0; rr < r1; ++rr) {
+    const int cur = (int)((rr - r0) & 1);
+    const f32x4 *__restrict__ Db = buf + (size_t)cur * 2 * NT * 64;
+    const f32x4 *__restrict__ Hb = Db + NT * 64;
+    const bool more = rr + 1 < r1;
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < STG; ++u) {
+        const int e = threadIdx.x + 256 * u;
+        if (e < 2 * NT * 64) stg[u] = *src_of(rr + 1, e);
+      }
+    }
+    f32x4 af[F > 0 ? F : 1], ar[R > 0 ? R : 1];
+#pragma unroll
+    for (int i = 0; i < F; ++i) { af[i] = Db[(wave + 4 * i) * 64 + lane]; dba[i] += af[i]; }
+#pragma unroll
+    for (int j = 0; j < R; ++j) { ar[j] = Db[(4 * F + j) * 64 + lane]; dbr[j] += ar[j]; }
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) {
+      const f32x4 b = Hb[ct * 64 + lane];
+#pragma unroll
+      for (int i = 0; i < F; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[i][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][c], b[c], acc[i][ct], 0, 0, 0);
+      if (R > 0 && (ct & 3) == wave) {  // wave-uniform: this wavefront's column tiles of the remainder row tiles
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) accr[j][ct / 4] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[j][c], b[c], accr[j][ct / 4], 0, 0, 0);
+      }
+    }
+    if (more) {
+      f32x4 *nb = buf + (size_t)(cur ^ 1) * 2 * NT * 64;
+#pragma unroll
+      for (int u = 0; u < STG; ++u) {
+        const int e = threadIdx.x + 256 * u;
+        if (e < 2 * NT * 64) nb[e] = stg[u];
+      }
+    }
+    __syncthreads();
+  }
+  // ---- write the partial: accumulator register r of lane (q = lane >> 4, n' = lane & 15) is dW[16*rt + 4q + r][16*ct + n'] ----
+  float *__restrict__ W = out + (size_t)4 * NP + (size_t)(l - 1) * ((size_t)NP * NP + NP);
+  float *__restrict__ bvec = W + (size_t)NP * NP;
+#pragma unroll
+  for (int i = 0; i < F; ++i) {
+    const int rt = wave + 4 * i;
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) W[(size_t)(16 * rt + 4 * kk + r) * NP + 16 * ct + m] = acc[i][ct][r];
+    float s = (dba[i][0] + dba[i][1]) + (dba[i][2] + dba[i][3]);
+    s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+    if (lane < 16) bvec[16 * rt + m] = s;
+  }
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int rt = 4 * F + j;
+#pragma unroll
+    for (int u = 0; u < RC; ++u) {
+      const int ct = 4 * u + wave;
+      if (ct < NT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) W[(size_t)(16 * rt + 4 * kk + r) * NP + 16 * ct + m] = accr[j][u][r];
+      }
+    }
+    float s = (dbr[j][0] + dbr[j][1]) + (dbr[j][2] + dbr[j][3]);
+    s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+    if (wave == 0 && lane < 16) bvec[16 * rt + m] = s;
+  }
+}
+
+inline hipError_t launch_grad_reduce(int L, int NT, const float *records, int64_t n_records, int n_slabs, float *partials,
+                                     hipStream_t s) {
+  const unsigned grid = (unsigned)(n_slabs * (L + 2));
+  const size_t lds = (size_t)2 * 2 * NT * 64 * 16;
+  switch (NT) {
+    case 1: hipLaunchKernelGGL(ionode_grad_reduce_kernel<1>, dim3(grid), dim3(256), lds, s, records, n_records, n_slabs, L, partials); break;
+    case 7: hipLaunchKernelGGL(ionode_grad_reduce_kernel<7>, dim3(grid), dim3(256), lds, s, records, n_records, n_slabs, L, partials); break;
+    case 13: hipLaunchKernelGGL(ionode_grad_reduce_kernel<13>, dim3(grid), dim3(256), lds, s, records, n_records, n_slabs, L, partials); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace ionode

@@ -1,0 +1,181 @@
+"""Gradients through the batched solve (BASELINE.json configs[4]).
+
+Reference interface: `from torchdiffeq import odeint_adjoint as odeint` (train-s1.py:29-32).  The reference only switches
+that import -- every call site runs under torch.no_grad() and nothing is ever differentiated (SURVEY.md finding 3) -- so
+there is no reference gradient to reproduce: **parity is unpinned**.  What this module computes is the exact reverse-mode
+derivative of the discretisation the forward launch executed, with the accepted steps (t0, dt) as constants
+(discretise-then-optimise, controller frozen); the checker is autograd through a torch restatement replaying the same
+steps (tests/grad_check.py).  `odeint` and `odeint_adjoint` share this backward: both names give the same values and the
+same gradients.
+
+Three launches per backward (csrc/ionode_grad.hpp, ionode_grad_reduce.hpp), all through the C ABI:
+  forward   ionode_dopri5 with accepted-step checkpoints (160 B per step and trajectory)
+  sweep     ionode_dopri5_backward: adjoints of y0 and p1..p8, and the (d_l, h_l) record stream of every MLP
+            vector-Jacobian product (160 KB per 16-trajectory tile evaluation for s00 -- sized for 288 GB of HBM3E and
+            chunked over iterations above `record_budget_bytes`)
+  reduce    ionode_grad_reduce: split-K fp32 MFMA GEMM of the records into per-slab partial weight gradients, summed here
+            in fp64.
+There is no CPU fallback: without libionode.so or a HIP device every call raises.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import capi
+
+_image_cache = {}
+DEFAULT_CKPT_CAP = 4096
+DEFAULT_RECORD_BUDGET = 24 << 30
+
+
+def grad_image(weights_flat, L, N, dev, key=None):
+    """Device-resident grad image (forward + transposed MFMA fragments) of a flat fp32 state dict."""
+    ck = (key, L, N, str(dev)) if key is not None else None
+    if ck is not None and ck in _image_cache:
+        return _image_cache[ck]
+    w = np.ascontiguousarray(np.asarray(weights_flat, dtype=np.float32).reshape(-1))
+    expect = 2 * N + N + L * (N * N + N) + N + 1
+    if w.size != expect:
+        raise capi.IonodeError(f"state dict has {w.size} floats, (L={L}, N={N}) needs {expect}")
+    n = capi.lib().ionode_grad_image_floats(L, N)
+    if n == 0:
+        raise capi.IonodeError("gradient path needs at least one hidden layer")
+    out = np.empty(n, dtype=np.float32)
+    if capi.lib().ionode_grad_pack(w.ctypes.data, L, N, out.ctypes.data) != 0:
+        raise capi.IonodeError(capi.lib().ionode_grad_last_error().decode())
+    img = torch.from_numpy(out).to(dev)
+    if ck is not None:
+        if len(_image_cache) > 8:
+            _image_cache.clear()
+        _image_cache[ck] = img
+    return img
+
+
+def unpack_partial(part, L, N):
+    """Padded partial-gradient layout (include/ionode.h: ionode_grad_partial_floats) -> flat state-dict order."""
+    NP = 16 * ((N + 15) // 16)
+    out = []
+    j0 = part[:4 * NP].reshape(NP, 4)
+    out += [j0[:N, 1:3].reshape(-1), j0[:N, 0]]
+    off = 4 * NP
+    for _ in range(L):
+        W = part[off:off + NP * NP].reshape(NP, NP)
+        b = part[off + NP * NP:off + NP * NP + NP]
+        out += [W[:N, :N].reshape(-1), b[:N]]
+        off += NP * NP + NP
+    out += [part[off:off + N], part[off + NP:off + NP + 1]]
+    return torch.cat(out)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class _Solve(torch.autograd.Function):
+    """y[B, Nt, 2] = dopri5 solve; differentiable in (weights_flat, params, y0)."""
+
+    @staticmethod
+    def forward(ctx, weights_flat, params, y0, cfg):
+        dev = y0.device
+        L, N = cfg["mlp_layers"], cfg["mlp_width"]
+        B = y0.shape[0]
+        cap = int(cfg.get("ckpt_cap") or DEFAULT_CKPT_CAP)
+        w_np = weights_flat.detach().to(torch.float32).cpu().numpy()
+        from . import batched  # packed forward image: shared cache with the plain solve
+        packed = batched.packed_weights(w_np, L, N, dev, key=cfg.get("weights_key"))
+        while True:
+            ckpt = torch.empty((B, cap, 20), dtype=torch.float64, device=dev)
+            r = capi.dopri5(cfg["model"], params.detach(), cfg["prot_v"], y0.detach(), cfg["t_eval"], mlp_packed=packed,
+                            mlp_layers=L, mlp_width=N, prot_t=cfg.get("prot_t"), prot_t0=cfg["prot_t0"], prot_dt=cfg["prot_dt"],
+                            prot_of_traj=cfg.get("prot_of_traj"), rtol=cfg["rtol"], atol=cfg["atol"], v_oob=cfg["v_oob"],
+                            max_steps=cfg["max_steps"], max_total_steps=cfg["max_total_steps"], ckpt=ckpt,
+                            t_eval_hint=cfg.get("t_eval_hint", "auto"))
+            nacc = r["stats"][:, 0]
+            most = int(nacc.max().item())
+            if most <= cap:
+                break
+            cap = 1 << int(np.ceil(np.log2(most + 1)))  # the buffer was too small: run the forward again with room
+        ctx.cfg, ctx.desc = cfg, r["desc"]
+        ctx.w_np = w_np
+        ctx.save_for_backward(params.detach(), ckpt, r["stats"], r["status"])
+        ctx.mark_non_differentiable(r["status"])
+        ctx.n_acc_max = most
+        return r["y"], r["status"]
+
+    @staticmethod
+    def backward(ctx, gy, _gstatus):
+        cfg, desc = ctx.cfg, ctx.desc
+        params, ckpt, stats, status = ctx.saved_tensors
+        dev = params.device
+        L, N = cfg["mlp_layers"], cfg["mlp_width"]
+        B, Nt = desc.n_traj, desc.n_out
+        need_w = ctx.needs_input_grad[0]
+        lib = capi.lib()
+        sdt = torch.float32 if desc.state_f32 else torch.float64
+        gy = gy.to(sdt).contiguous()
+        n_acc = torch.where(status == 0, stats[:, 0], torch.zeros_like(stats[:, 0])).to(torch.int32).contiguous()
+        n_iter = int(n_acc.max().item()) + 1
+        image = grad_image(ctx.w_np, L, N, dev, key=cfg.get("weights_key"))
+        state = torch.empty((B, 12), dtype=torch.float64, device=dev)
+        g_params = torch.zeros((B, 8), dtype=torch.float64, device=dev)
+        g_y0 = torch.zeros((B, 2), dtype=torch.float64, device=dev)
+        tiles = (B + 15) // 16
+        recf = lib.ionode_grad_record_floats(L, N)
+        partf = lib.ionode_grad_partial_floats(L, N)
+        budget = int(cfg.get("record_budget_bytes") or DEFAULT_RECORD_BUDGET)
+        chunk = n_iter if not need_w else max(1, min(n_iter, budget // (tiles * 6 * recf * 4)))
+        acc = torch.zeros(partf, dtype=torch.float64, device=dev) if need_w else None
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        records = torch.empty(tiles * chunk * 6 * recf, dtype=torch.float32, device=dev) if need_w else None
+        desc.ckpt, desc.ckpt_cap = ckpt.data_ptr(), ckpt.shape[1]
+        for it0 in range(0, n_iter, chunk):
+            it1 = min(n_iter, it0 + chunk)
+            rc = lib.ionode_dopri5_backward(C.byref(desc), it0, it1, n_iter, _ptr(image), _ptr(params), _ptr(cfg["prot_v"]),
+                                            _ptr(cfg.get("prot_t")), _ptr(cfg.get("prot_of_traj")), _ptr(cfg["t_eval"]),
+                                            _ptr(n_acc), _ptr(gy), _ptr(state), _ptr(records), _ptr(g_params), _ptr(g_y0),
+                                            C.c_void_p(stream))
+            if rc != 0:
+                raise capi.IonodeError(f"ionode_dopri5_backward failed ({rc}): {lib.ionode_grad_last_error().decode()}")
+            if need_w:
+                n_rec = tiles * (it1 - it0) * 6
+                n_slabs = int(max(1, min(256 // (L + 2), n_rec // 4)))
+                partials = torch.empty((n_slabs, partf), dtype=torch.float32, device=dev)
+                rc = lib.ionode_grad_reduce(L, N, _ptr(records), n_rec, n_slabs, _ptr(partials), C.c_void_p(stream))
+                if rc != 0:
+                    raise capi.IonodeError(f"ionode_grad_reduce failed ({rc}): {lib.ionode_grad_last_error().decode()}")
+                acc += partials.double().sum(0)
+        g_w = unpack_partial(acc, L, N).to(torch.float32) if need_w else None
+        return g_w, (g_params if ctx.needs_input_grad[1] else None), (g_y0.to(sdt) if ctx.needs_input_grad[2] else None), None
+
+
+def solve(model, weights_flat, params, prot_v, y0, t_eval, *, mlp_layers, mlp_width, prot_t=None, prot_t0=0.0,
+          prot_dt=1.0, prot_of_traj=None, rtol=1e-7, atol=1e-9, v_oob=-80.0, max_steps=0, max_total_steps=0,
+          ckpt_cap=None, record_budget_bytes=None, weights_key=None, t_eval_hint="auto"):
+    """Differentiable batched solve.  weights_flat [n] fp32 (reference state-dict order), params [B, 8] fp64, y0 [B, 2]
+    fp32 | fp64 (the state dtype) -- device tensors, any of which may require grad; prot_v [P, Np], t_eval [Nt] fp64 device
+    tensors.  Returns (y [B, Nt, 2], status [B]): gradients of failed trajectories (status != 0) are zero."""
+    if model not in (capi.MODEL_NNF, capi.MODEL_NND):
+        raise NotImplementedError("gradients through the solve are built for the NN-f / NN-d right-hand sides")
+    if not (isinstance(y0, torch.Tensor) and y0.is_cuda):
+        raise capi.IonodeError("no HIP tensors: the integrator and its backward sweep have no CPU path")
+    cfg = dict(model=model, mlp_layers=int(mlp_layers), mlp_width=int(mlp_width), prot_v=prot_v, prot_t=prot_t,
+               prot_t0=float(prot_t0), prot_dt=float(prot_dt), prot_of_traj=prot_of_traj, t_eval=t_eval, rtol=float(rtol),
+               atol=float(atol), v_oob=float(v_oob), max_steps=int(max_steps), max_total_steps=int(max_total_steps),
+               ckpt_cap=ckpt_cap, record_budget_bytes=record_budget_bytes, weights_key=weights_key, t_eval_hint=t_eval_hint)
+    return _Solve.apply(weights_flat, params, y0.contiguous(), cfg)
+
+
+def allreduce_gradients(tensors, group=None):
+    """Sum gradient tensors over the ranks with ONE collective (flattened bucket): RCCL over xGMI under `nccl`.
+    For s00 that is 201 801 fp32 = 807 KB -- latency-bound next to a >= 100 ms sweep."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return tensors
+    flat = torch.cat([t.reshape(-1).to(torch.float64) for t in tensors])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    out, off = [], 0
+    for t in tensors:
+        out.append(flat[off:off + t.numel()].reshape(t.shape).to(t.dtype))
+        off += t.numel()
+    return out

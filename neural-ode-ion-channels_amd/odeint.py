@@ -8,6 +8,13 @@ Returns a tensor of shape (len(t), *y0.shape), dtype y0.dtype, on y0.device, as 
 RHS modules (rhs.py) are integrated by the fused HIP kernel.  `func` is read at call time: the protocol set by
 `set_fixed_form_voltage_protocol` between calls and the current weights are picked up on every call.
 
+Gradients.  Called with autograd enabled and a `func.net` parameter, a tensor-valued rate parameter or `y0` requiring
+grad, the result carries a graph: the backward sweep of grad.py (exact derivative of the executed discretisation, accepted
+steps as constants).  `odeint_adjoint` is the same function -- the reference's --adjoint flag only switches the import
+(train-s1.py:29-32) and never differentiates, so there is no separate adjoint behaviour to mirror.  Cases without a
+backward kernel (closed-form RHS modules, N = 500 nets) raise NotImplementedError instead of silently returning a
+graph-less tensor; wrap such calls in torch.no_grad() as the reference does.
+
 Failures raise AssertionError with torchdiffeq's messages ('underflow in dt', 'non-finite values in state `y`',
 'max_num_steps exceeded').  There is no CPU fallback for recognised modules: without a HIP device the call raises.
 Modules that are not one of the reference's families raise UnrecognisedRhs unless the caller opts into the
@@ -18,7 +25,7 @@ import warnings
 import numpy as np
 import torch
 
-from . import batched, capi, rhs
+from . import batched, capi, grad, rhs
 from .generic import generic_dopri5
 
 _KNOWN_OPTIONS = {"allow_generic", "explicit_protocol", "max_num_steps", "max_total_steps", "tile_waves",
@@ -53,6 +60,9 @@ def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, even
             f"odeint: func is not one of the reference's RHS families ({e}); pass options={{'allow_generic': True}} "
             "to integrate it with the generic torch stepper") from None
 
+    if torch.is_grad_enabled() and _wants_grad(func, y0):
+        return _odeint_with_grad(func, y0, t, spec, rtol, atol, options)
+
     t64 = t.detach().to(torch.float64)
     t_key = ("t", rhs.digest(t64.cpu().numpy()))  # the output grid stays device-resident while its values do not change
     sol = batched.solve(spec.model, spec.params, spec.prot_v, y0.reshape(1, -1), t64,
@@ -67,9 +77,54 @@ def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, even
     return out.to(y0.device)
 
 
+def _rate_tensors(func):
+    return [getattr(func, f"p{i}", None) for i in range(1, 9)]
+
+
+def _wants_grad(func, y0):
+    if y0.requires_grad:
+        return True
+    if isinstance(func, torch.nn.Module) and any(p.requires_grad for p in func.parameters()):
+        return True
+    return any(isinstance(p, torch.Tensor) and p.requires_grad for p in _rate_tensors(func))
+
+
+def _odeint_with_grad(func, y0, t, spec, rtol, atol, options):
+    """Differentiable call: same forward kernel (plus accepted-step checkpoints), backward sweep on demand."""
+    if spec.model not in (capi.MODEL_NNF, capi.MODEL_NND):
+        raise NotImplementedError(
+            "odeint: a gradient was requested through a closed-form RHS module (HH / 6-state); the backward sweep is built "
+            "for the NN-f / NN-d modules.  Call under torch.no_grad() (as the reference does) for forward values.")
+    dev = batched._dev()
+    lin = [m for m in func.net if isinstance(m, torch.nn.Linear)]
+    flat = torch.cat([x.reshape(-1) for m in lin for x in (m.weight, m.bias)]).to(dev)
+    rates = _rate_tensors(func)
+    if any(isinstance(p, torch.Tensor) and p.requires_grad for p in rates):
+        cols = [(p.reshape(()).to(device=dev, dtype=torch.float64) if isinstance(p, torch.Tensor)
+                 else torch.tensor(float(0.0 if p is None else p), dtype=torch.float64, device=dev)) for p in rates]
+        if spec.model == capi.MODEL_NNF:
+            cols[:4] = [torch.zeros((), dtype=torch.float64, device=dev)] * 4
+        params = torch.stack(cols)[None, :]
+    else:
+        params = torch.from_numpy(spec.params[None, :]).to(dev)
+    t64 = t.detach().to(torch.float64)
+    te = batched._to(t64, torch.float64, dev, key=("t", rhs.digest(t64.cpu().numpy())))
+    y, status = grad.solve(spec.model, flat, params, batched._to(spec.prot_v[None, :], torch.float64, dev, key=(spec.prot_key, "v2")),
+                           y0.reshape(1, -1).to(dev), te, mlp_layers=spec.mlp_layers, mlp_width=spec.mlp_width,
+                           prot_t=batched._to(spec.prot_t, torch.float64, dev, key=(spec.prot_key, "t")),
+                           prot_t0=spec.prot_t0, prot_dt=spec.prot_dt, rtol=float(rtol), atol=float(atol),
+                           max_steps=int(options.get("max_num_steps", 0)), max_total_steps=int(options.get("max_total_steps", 0)),
+                           weights_key=spec.weights_key)
+    st = int(status[0].item())
+    if st != 0:
+        raise AssertionError(capi.STATUS_TEXT[st])
+    return y[0].reshape((t.numel(),) + tuple(y0.shape)).to(y0.device)
+
+
 def odeint_adjoint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, event_fn=None,
                    adjoint_rtol=None, adjoint_atol=None, adjoint_method=None, adjoint_options=None, adjoint_params=None):
     """The reference's --adjoint flag only switches this import (train-s1.py:29-32); every call site runs under
-    torch.no_grad() and never differentiates through the solve (SURVEY.md finding 3).  Forward values are identical
-    to odeint; the result carries no autograd graph."""
+    torch.no_grad() and never differentiates through the solve (SURVEY.md finding 3).  Same values and the same gradient
+    path as `odeint` (module docstring); torchdiffeq's adjoint_* knobs tune its continuous adjoint ODE and have no
+    counterpart in the discrete sweep -- they are accepted and ignored."""
     return odeint(func, y0, t, rtol=rtol, atol=atol, method=method, options=options, event_fn=event_fn)

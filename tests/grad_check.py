@@ -90,9 +90,17 @@ def accepted_steps(step_log):
     return sl[sl[:, 3] == 1.0][:, :2]
 
 
-def replay(model, flat, L, N, p, y0, prot_t, prot_v, t_eval, steps, *, f32_times=False, net_dtype=torch.float32):
+def replay(model, flat, L, N, p, y0, prot_t, prot_v, t_eval, steps, *, f32_times=False, net_dtype=torch.float32,
+           anchors=None):
     """Differentiable re-run of the accepted steps.  flat [n] fp32/fp64, p [8] fp64, y0 [2] fp64 (leaf tensors or not).
-    Returns y [Nt, 2] fp64 (outputs beyond the last step's end are not produced: the caller passes complete logs)."""
+    Returns y [Nt, 2] fp64 (outputs beyond the last step's end are not produced: the caller passes complete logs).
+
+    anchors [n_steps, 2] (optional): the state the ACTUAL forward solve had at the end of each accepted step.  The
+    replay's value is moved onto it after every step (`y + (anchor - y).detach()`: value replaced, derivative kept), so
+    the Jacobians are evaluated along the actual trajectory -- which is what the HIP sweep does, since it reads y and
+    k1..k7 from the forward launch's checkpoints.  Needed in fp32 state only: there the forward's own rounding noise
+    (rtol 1e-7 ~ fp32 epsilon, SURVEY.md finding 4) can move a trajectory by 5e-5 from the fp64 re-run of the same steps,
+    and d/dp of a 200 ms hold at -120 mV (exp(-p8 V) ~ 28) turns that into a visibly different gradient."""
     layers = split_flat(flat, L, N) if model in (MODEL_NNF, MODEL_NND) else None
     te = np.asarray(t_eval, dtype=np.float64)
     S = np.float32 if f32_times else np.float64
@@ -100,7 +108,7 @@ def replay(model, flat, L, N, p, y0, prot_t, prot_v, t_eval, steps, *, f32_times
     f = rhs(model, layers, p, protocol_v(float(S(te[0])), prot_t, prot_v), y, net_dtype)
     outs = [y0]
     oi = 1
-    for (t0, dt) in steps:
+    for n, (t0, dt) in enumerate(steps):
         if oi >= te.size:
             break
         t1 = t0 + dt
@@ -110,6 +118,8 @@ def replay(model, flat, L, N, p, y0, prot_t, prot_v, t_eval, steps, *, f32_times
         Yi = y
         for i in range(6):
             Yi = y + sum(k[j] * (BETA[i][j] * dts) for j in range(i + 1))
+            if i == 5 and anchors is not None:
+                Yi = Yi + (torch.as_tensor(anchors[n], dtype=torch.float64) - Yi).detach()
             k.append(rhs(model, layers, p, protocol_v(ts[i], prot_t, prot_v), Yi, net_dtype))
         y1 = Yi
         ymid = y + sum(k[j] * (CMID[j] * dts) for j in range(7))
