@@ -99,7 +99,7 @@ def main():
     prot_v = protocols.sinewave(protocols.sinewave_scales(first, B), n_samples=Nt, dt=0.1, xp=torch, device=dev)
     params = torch.from_numpy(np.tile(P_HH, (B, 1))).to(dev)
     y0 = torch.tensor([[0.0, 1.0]], dtype=torch.float64, device=dev).repeat(B, 1).contiguous()
-    t_eval = torch.arange(Nt, dtype=torch.float64, device=dev) * 0.1
+    t_eval = torch.arange(Nt, dtype=torch.float64, device=dev) * 0.1  # == 0.0 + k * 0.1 bit for bit (t_eval_exact)
     i_ref = torch.zeros((B, Nt), dtype=torch.float64, device=dev)  # synthetic "data" current
     out = {}
     if args.stamps:
@@ -126,7 +126,7 @@ def main():
     def step():
         r = capi.dopri5(capi.MODEL_NNF, params, prot_v, y0, t_eval, mlp_packed=packed, mlp_layers=MLP_L,
                         mlp_width=MLP_N, prot_t0=0.0, prot_dt=0.1, current=True, obs_g=1.0, obs_e=-86.0,
-                        tile_waves=args.tile_waves, t_eval_hint=(0.0, 0.1), out=out)
+                        tile_waves=args.tile_waves, t_eval_hint=(0.0, 0.1), t_eval_exact=True, out=out)
         out.update({k: r[k] for k in ("y", "i", "status", "stats")})
         part = torch.stack([(r["i"] - i_ref).abs().sum(), torch.tensor(float(B * Nt), dtype=torch.float64, device=dev)])
         part = allreduce(part)  # the path's only collective: 16 bytes
@@ -146,7 +146,7 @@ def main():
         ev[k][0].record()  # same stream as the kernel launch (torch's current stream)
         r = capi.dopri5(capi.MODEL_NNF, params, prot_v, y0, t_eval, mlp_packed=packed, mlp_layers=MLP_L,
                         mlp_width=MLP_N, prot_t0=0.0, prot_dt=0.1, current=True, obs_g=1.0, obs_e=-86.0,
-                        tile_waves=args.tile_waves, t_eval_hint=(0.0, 0.1), out=out)
+                        tile_waves=args.tile_waves, t_eval_hint=(0.0, 0.1), t_eval_exact=True, out=out)
         ev[k][1].record()
         part = torch.stack([(r["i"] - i_ref).abs().sum(), torch.tensor(float(B * Nt), dtype=torch.float64, device=dev)])
         part = allreduce(part)

@@ -90,7 +90,14 @@ typedef struct ionode_desc {
                           sweep (ionode_dopri5_backward) replays.  Steps beyond ckpt_cap are not recorded (the caller
                           compares stats[b][0] with ckpt_cap and retries with a larger buffer).  NULL = off */
   int32_t ckpt_cap;
-  int32_t reserved0;
+  int32_t t_eval_exact; /* 1: the caller has VERIFIED t_eval[k] == t_eval_t0_hint + (double)k * t_eval_dt_hint bit for bit (fp64
+                          multiply, then add) for every k.  The closed-form kernels then form output times arithmetically and
+                          take their store-friendly emission path; results are identical either way.  0 = not verified */
+  double max_step;     /* EXTENSION (torchdiffeq 0.2.1's dopri5 has no such option; 0 = off = reference behaviour): cap on the
+                          step size in ms.  At an equilibrium dopri5 grows dt until h*lambda leaves its stability region
+                          (the error estimate of a state AT equilibrium is ~0); the forward solve copes through rejections,
+                          but the reverse-mode derivative of such accepted-but-unstable steps multiplies adjoints by
+                          |R(h*lambda)| >> 1 per step.  max_step < 3.3 / lambda_max keeps the backward sweep bounded. */
 } ionode_desc;
 
 #define IONODE_DEFAULT_MAX_TOTAL_STEPS 1000000
@@ -180,6 +187,31 @@ size_t ionode_grad_partial_floats(int32_t mlp_layers, int32_t mlp_width);
 /* partials[n_slabs][ionode_grad_partial_floats()] = per-slab sums over records [n_records * s / n_slabs, ...); asynchronous */
 int ionode_grad_reduce(int32_t mlp_layers, int32_t mlp_width, const float *records, int64_t n_records, int32_t n_slabs,
                        float *partials, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * MLP state-space regression step -- the reference's actual training loop, train-s1.py:891-909 /
+ * train-d2.py:901-915:  p = net(x_av.float()) / netscale [+ model_dadt];  loss = MSELoss(reduction='sum')(p, y.float());
+ * loss.backward(); Adam(lr 1e-3).step(); StepLR.step().  One iteration = ionode_regress_step -> ionode_grad_reduce ->
+ * ionode_adam_step -> ionode_image_refresh, all asynchronous on one stream, no host synchronisation.
+ * ------------------------------------------------------------------------------------------------------------------- */
+
+/* Forward + backward of the net for every 16-row tile of x (fp32 MFMA, activations LDS-resident): one record per tile into
+ * `records` ([ceil(n_rows/16)][ionode_grad_record_floats()]) and sum((p - y)^2) partials into loss_partials[n_workgroups]
+ * (fp64).  x [n_rows][2], y [n_rows], offset [n_rows] or NULL: device fp32.  n_workgroups = persistent grid size (<= tiles). */
+int ionode_regress_step(int32_t mlp_layers, int32_t mlp_width, const float *grad_image, const float *x, const float *offset,
+                        const float *y, int32_t n_rows, float netscale, float *records, double *loss_partials,
+                        int32_t n_workgroups, void *stream);
+
+/* g[i] = sum over slabs of partials[s][padmap[i]] (flat state-dict order), then torch.optim.Adam's update (no amsgrad, no
+ * weight decay), element-wise in fp32.  `step` counts from 1.  grad_out (optional) receives g; apply = 0 only gathers g. */
+int ionode_adam_step(int32_t n_params, int32_t n_slabs, int32_t mlp_layers, int32_t mlp_width, const float *partials,
+                     const int32_t *padmap, float *weights, float *exp_avg, float *exp_avg_sq, float lr, float beta1,
+                     float beta2, float eps, int32_t step, float *grad_out, int32_t apply, void *stream);
+
+/* grad_image[k] = weights[image_map[k] - 1] (image_map[k] == 0: padding).  image_map = ionode_grad_pack() of the values
+ * 1, 2, ..., n_params (exact in fp32), converted to int32 by the caller. */
+int ionode_image_refresh(int32_t mlp_layers, int32_t mlp_width, const int32_t *image_map, const float *weights,
+                         float *grad_image, void *stream);
 
 const char *ionode_grad_last_error(void);
 

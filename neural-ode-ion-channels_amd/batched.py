@@ -84,6 +84,7 @@ def solve(model, params, prot_v, y0, t_eval, *, weights=None, mlp_layers=0, mlp_
     is a floating torch tensor, else float64.
     """
     dev = _dev(device)
+    t_eval_exact = None
     params_t = _to(params, torch.float64, dev)
     if params_t.dim() == 1:
         params_t = params_t[None, :].contiguous()
@@ -107,6 +108,7 @@ def solve(model, params, prot_v, y0, t_eval, *, weights=None, mlp_layers=0, mlp_
             dth = (te[-1] - te[0]) / (te.size - 1)
             if dth > 0 and np.max(np.abs(te - (te[0] + np.arange(te.size) * dth))) <= 0.5 * dth:
                 t_eval_hint = (float(te[0]), float(dth))
+                t_eval_exact = bool(np.array_equal(te, te[0] + np.arange(te.size, dtype=np.float64) * dth))
     t_eval_t = _to(t_eval, torch.float64, dev, key=t_eval_key)
     packed = None
     if model in (capi.MODEL_NNF, capi.MODEL_NND):
@@ -119,5 +121,5 @@ def solve(model, params, prot_v, y0, t_eval, *, weights=None, mlp_layers=0, mlp_
                     prot_of_traj=_to(prot_of_traj, torch.int32, dev), rtol=rtol, atol=atol, v_oob=v_oob,
                     max_steps=max_steps, max_total_steps=max_total_steps, current=current, obs_g=obs_g, obs_e=obs_e,
                     obs_open_state_only=obs_open_state_only, tile_waves=tile_waves, step_log=step_log,
-                    t_eval_hint=t_eval_hint)
+                    t_eval_hint=t_eval_hint, t_eval_exact=t_eval_exact)
     return Solution(y=r["y"], i=r["i"], status=r["status"], stats=r["stats"], kernel=capi.kernel_name(r["desc"]))

@@ -28,6 +28,7 @@ EXPORTS = (
     "ionode_launch_geometry", "ionode_kernel_name", "ionode_dopri5",
     "ionode_grad_image_floats", "ionode_grad_pack", "ionode_grad_record_floats", "ionode_dopri5_backward",
     "ionode_grad_partial_floats", "ionode_grad_reduce", "ionode_grad_last_error",
+    "ionode_regress_step", "ionode_adam_step", "ionode_image_refresh",
 )
 
 
@@ -41,7 +42,8 @@ class IonodeDesc(C.Structure):
         ("obs_open_state_only", C.c_int32), ("tile_waves", C.c_int32),
         ("step_log", C.c_void_p), ("step_log_cap", C.c_int64),
         ("t_eval_t0_hint", C.c_double), ("t_eval_dt_hint", C.c_double),
-        ("max_total_steps", C.c_int64), ("ckpt", C.c_void_p), ("ckpt_cap", C.c_int32), ("reserved0", C.c_int32),
+        ("max_total_steps", C.c_int64), ("ckpt", C.c_void_p), ("ckpt_cap", C.c_int32), ("t_eval_exact", C.c_int32),
+        ("max_step", C.c_double),
     ]
 
 
@@ -90,6 +92,15 @@ def lib():
         L.ionode_dopri5_backward.argtypes = [C.POINTER(IonodeDesc), C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 13
         L.ionode_grad_reduce.restype = C.c_int
         L.ionode_grad_reduce.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
+        L.ionode_regress_step.restype = C.c_int
+        L.ionode_regress_step.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                          C.c_float, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+        L.ionode_adam_step.restype = C.c_int
+        L.ionode_adam_step.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
+                                       C.c_void_p, C.c_int32, C.c_void_p]
+        L.ionode_image_refresh.restype = C.c_int
+        L.ionode_image_refresh.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         if L.ionode_abi_version() != ABI_VERSION:
             raise IonodeError("libionode.so ABI version mismatch; rebuild")
         _lib = L
@@ -147,8 +158,8 @@ def _dev_ptr(t, dtype, name, shape=None):
 
 def dopri5(model, params, prot_v, y0, t_eval, *, mlp_packed=None, mlp_layers=0, mlp_width=0, prot_t=None,
            prot_t0=0.0, prot_dt=1.0, prot_of_traj=None, rtol=1e-7, atol=1e-9, v_oob=-80.0, max_steps=0,
-           max_total_steps=0, ckpt=None, current=False, obs_g=1.0, obs_e=-86.0, obs_open_state_only=False, tile_waves=0, stats=True,
-           step_log=None, t_eval_hint="auto", out=None, stream=None):
+           max_total_steps=0, max_step=0.0, ckpt=None, current=False, obs_g=1.0, obs_e=-86.0, obs_open_state_only=False, tile_waves=0, stats=True,
+           step_log=None, t_eval_hint="auto", t_eval_exact=None, out=None, stream=None):
     """Launch one batched solve.  Every tensor lives on the current HIP device.
 
     params [B, n_params] f64, prot_v [P, Np] f64, y0 [B, D] f32|f64 (selects the state dtype),
@@ -165,7 +176,7 @@ def dopri5(model, params, prot_v, y0, t_eval, *, mlp_packed=None, mlp_layers=0, 
         raise IonodeError("y0 must be float32 or float64")
     desc = make_desc(model=model, state_f32=int(sdt == torch.float32), n_state=D, n_out=Nt, n_traj=B, n_prot=P,
                      prot_n=Np, mlp_layers=mlp_layers, mlp_width=mlp_width, n_params=params.shape[1],
-                     max_steps=max_steps, max_total_steps=max_total_steps, prot_t0=prot_t0, prot_dt=prot_dt, v_oob=v_oob, rtol=rtol, atol=atol,
+                     max_steps=max_steps, max_total_steps=max_total_steps, max_step=max_step, prot_t0=prot_t0, prot_dt=prot_dt, v_oob=v_oob, rtol=rtol, atol=atol,
                      obs_g=obs_g, obs_e=obs_e, obs_open_state_only=int(obs_open_state_only), tile_waves=tile_waves)
     # output-grid hint (t0, dt): a guess the kernel verifies against t_eval; "auto" derives it from the end points
     # (one tiny device->host read), None disables it (cooperative scan)
@@ -178,8 +189,15 @@ def dopri5(model, params, prot_v, y0, t_eval, *, mlp_packed=None, mlp_layers=0, 
             vals = torch.stack([t0h, dth, dev_]).cpu()  # one small device->host read; pass t_eval_hint=(t0, dt) to avoid it
             if float(vals[1]) > 0 and float(vals[2]) <= 0.5 * float(vals[1]):
                 t_eval_hint = (float(vals[0]), float(vals[1]))
+                if t_eval_exact is None:
+                    t_eval_exact = float(vals[2]) == 0.0
     if t_eval_hint is not None and t_eval_hint[1] > 0:
         desc.t_eval_t0_hint, desc.t_eval_dt_hint = float(t_eval_hint[0]), float(t_eval_hint[1])
+        if t_eval_exact is None:
+            # exactness is a CLAIM the kernel relies on: verify it here (one tiny device->host read) unless the caller did
+            k = torch.arange(Nt, dtype=torch.float64, device=t_eval.device)
+            t_eval_exact = bool(torch.equal(t_eval, float(t_eval_hint[0]) + k * float(t_eval_hint[1])))
+        desc.t_eval_exact = int(bool(t_eval_exact))
     if ckpt is not None:  # [B, cap, 4 + 8*D] f64 device tensor: accepted-step records for the backward sweep
         _dev_ptr(ckpt, torch.float64, "ckpt", (B, ckpt.shape[1], 4 + 8 * D))
         desc.ckpt = ckpt.data_ptr()

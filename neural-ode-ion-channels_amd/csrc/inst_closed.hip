@@ -7,6 +7,9 @@ static const Variant kTab[] = {
     IONODE_VARIANT(1, double, 0, 1, 0, 0, 0, 0),  IONODE_VARIANT(1, float, 1, 1, 0, 0, 0, 0),
     IONODE_VARIANT(0, double, 0, 1, 16, 0, 0, 0), IONODE_VARIANT(0, float, 1, 1, 16, 0, 0, 0),
     IONODE_VARIANT(1, double, 0, 1, 16, 0, 0, 0), IONODE_VARIANT(1, float, 1, 1, 16, 0, 0, 0),
+    // last parameter 1: deferred aligned emission (2-state models, exact uniform output grid, no current trace)
+    IONODE_VARIANT(0, double, 0, 1, 0, 0, 0, 1),  IONODE_VARIANT(0, float, 1, 1, 0, 0, 0, 1),
+    IONODE_VARIANT(0, double, 0, 1, 16, 0, 0, 1), IONODE_VARIANT(0, float, 1, 1, 16, 0, 0, 1),
 };
 const Variant *variants_closed(int *n) { *n = sizeof(kTab) / sizeof(kTab[0]); return kTab; }
 }  // namespace ionode

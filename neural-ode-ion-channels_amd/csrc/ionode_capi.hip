@@ -23,7 +23,7 @@ struct Plan {
 };
 
 // Closed-form kernels are registered with NT == 0 and RT = trajectories per wavefront (0 -> 64); rt < 0: any RT.
-const ionode::Variant *find_variant(int model, int f32, int G, int NT, int rt = -1) {
+const ionode::Variant *find_variant(int model, int f32, int G, int NT, int rt = -1, int tail = 0) {
   using namespace ionode;
   typedef const Variant *(*TabFn)(int *);
   static const TabFn tabs[] = {variants_closed, variants_nnf_f64, variants_nnf_f32, variants_nnd_f64, variants_nnd_f32};
@@ -31,13 +31,13 @@ const ionode::Variant *find_variant(int model, int f32, int G, int NT, int rt = 
     int n = 0;
     const Variant *t = tf(&n);
     for (int i = 0; i < n; ++i)
-      if (t[i].model == model && t[i].f32 == f32 && (G == 0 || t[i].G == G) && t[i].NT == NT && (rt < 0 || t[i].RT == rt))
+      if (t[i].model == model && t[i].f32 == f32 && (G == 0 || t[i].G == G) && t[i].NT == NT && (rt < 0 || t[i].RT == rt) && t[i].tail == tail)
         return &t[i];
   }
   return nullptr;
 }
 
-int make_plan(const ionode_desc *d, Plan *pl) {
+int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false) {
   if (!d) { set_err("null descriptor"); return IONODE_ERR_ARG; }
   const bool mlp = d->model == IONODE_MODEL_NNF || d->model == IONODE_MODEL_NND;
   const int D = d->model == IONODE_MODEL_MARKOV6 ? 6 : 2;
@@ -51,10 +51,13 @@ int make_plan(const ionode_desc *d, Plan *pl) {
     // small batches: 16 trajectories per wavefront (4x the wavefronts); >= 2 wavefronts per SIMD at 64 per wavefront
     // needs 131072 trajectories.  tile_waves = 64 / 16 forces a choice (tests).
     const int tpw = (d->tile_waves == 64 || d->tile_waves == 16) ? d->tile_waves : (d->n_traj >= 131072 ? 64 : 16);
-    pl->v = find_variant(d->model, f32, 1, 0, tpw == 64 ? 0 : 16);
+    // deferred aligned emission (2-state models): the output grid must be VERIFIED uniform and no current trace requested
+    const int defer = (D == 2 && d->t_eval_exact && d->t_eval_dt_hint > 0.0 && d->n_out > 1 && !want_current) ? 1 : 0;
+    pl->v = find_variant(d->model, f32, 1, 0, tpw == 64 ? 0 : 16, defer);
     pl->grid = (unsigned)((d->n_traj + tpw - 1) / tpw);
     pl->block = 64;
-    pl->lds = 0;
+    // one interpolant row per lane (dense-output broadcast through LDS) + one tail buffer per trajectory (2-state models)
+    pl->lds = (size_t)64 * (4 + 5 * D) * 8 + (D == 2 ? (size_t)64 * 128 : 0);
   } else {
     if (d->mlp_width < 1 || d->mlp_layers < 0) { set_err("bad MLP shape"); return IONODE_ERR_ARG; }
     if (d->mlp_width <= 16 && d->mlp_layers > 10) { set_err("N <= 16 kernels keep at most 10 hidden layers resident"); return IONODE_ERR_UNSUPPORTED; }
@@ -181,7 +184,7 @@ int ionode_dopri5(const ionode_desc *d, const float *mlp_packed, const double *p
                   const double *prot_t, const int32_t *prot_of_traj, const void *y0, const double *t_eval,
                   void *y_out, double *i_out, int32_t *status, int64_t *stats, void *stream) {
   Plan pl;
-  const int rc = make_plan(d, &pl);
+  const int rc = make_plan(d, &pl, i_out != nullptr);
   if (rc != IONODE_OK) return rc;
   const bool mlp = d->model == IONODE_MODEL_NNF || d->model == IONODE_MODEL_NND;
   if (!params || !prot_v || !y0 || !t_eval || !y_out || !status || (mlp && !mlp_packed)) {
@@ -199,10 +202,14 @@ int ionode_dopri5(const ionode_desc *d, const float *mlp_packed, const double *p
                                        : (d->max_total_steps == 0 ? (int64_t)IONODE_DEFAULT_MAX_TOTAL_STEPS : INT64_MAX);
   a.ckpt = d->ckpt; a.ckpt_cap = d->ckpt ? d->ckpt_cap : 0;
   if (d->ckpt && d->ckpt_cap < 1) { set_err("ckpt given with ckpt_cap < 1"); return IONODE_ERR_ARG; }
+  a.prot_rdt = 1.0 / d->prot_dt;  // correctly rounded: the kernels divide by prot_dt through div_by()
+  a.dt_max = d->max_step > 0.0 ? d->max_step : __builtin_inf();
   a.prot_t0 = d->prot_t0; a.prot_dt = d->prot_dt; a.v_oob = d->v_oob; a.rtol = d->rtol; a.atol = d->atol;
   a.obs_g = d->obs_g; a.obs_e = d->obs_e; a.obs_open = d->obs_open_state_only;
   a.step_log = d->step_log; a.step_log_cap = d->step_log ? d->step_log_cap : 0;
   a.te_t0 = d->t_eval_t0_hint; a.te_dt = (d->t_eval_dt_hint > 0.0 && d->n_out > 1) ? d->t_eval_dt_hint : 0.0;
+  a.te_rdt = a.te_dt > 0.0 ? 1.0 / a.te_dt : 0.0;
+  a.te_exact = (a.te_dt > 0.0 && d->t_eval_exact) ? 1 : 0;
   const hipError_t e = pl.v->fn(a, pl.grid, pl.lds, reinterpret_cast<hipStream_t>(stream));
   if (e != hipSuccess) { set_err("kernel launch failed: %s", hipGetErrorString(e)); return IONODE_ERR_LAUNCH; }
   return IONODE_OK;

@@ -54,10 +54,15 @@ struct KArgs {
   double *ckpt;        // optional [B][ckpt_cap][4 + 8*D] fp64: one record per ACCEPTED step, for the backward sweep (ionode_grad.hpp)
   int32_t ckpt_cap;
   double prot_t0, prot_dt, v_oob, rtol, atol, obs_g, obs_e;
+  double prot_rdt;     // 1.0 / prot_dt, correctly rounded (host division): divisions by prot_dt become div_by()
+  double dt_max;       // optional cap on the step size (+inf: none -- torchdiffeq 0.2.1 has no such option)
   int32_t obs_open;
   double *step_log;
   int64_t step_log_cap;
   double te_t0, te_dt;  // hint: t_eval[k] ~ te_t0 + k*te_dt (te_dt <= 0: no hint).  Only ever a guess; see emit.
+  double te_rdt;        // 1 / te_dt (for the guess only)
+  int32_t te_exact;     // 1: the caller VERIFIED t_eval[k] == te_t0 + (double)k * te_dt bit for bit (fp64 multiply, then add):
+                        // closed-form kernels then form output times arithmetically -- no vector load sits behind their stores
 };
 
 // Dormand-Prince / Shampine coefficients.
@@ -115,6 +120,21 @@ __device__ __forceinline__ double det_exp(double x) {
 }
 __device__ __forceinline__ float det_expf(float x) { return (float)det_exp((double)x); }
 
+// a / b when rb = RN(1 / b) is at hand: q0 = RN(a * rb) is a faithful quotient, and one correction step with the exact
+// remainder r = a - b*q0 (fma) gives RN(a / b) -- the correctly rounded IEEE quotient, bit for bit what `a / b` returns
+// (Markstein 1990; holds barring over/underflow: operands here are times in ms, voltages in mV and O(1) ratios).  Three
+// fp64 VALU operations instead of the ~12-instruction v_div_scale / v_rcp / Newton / v_div_fmas / v_div_fixup sequence;
+// the divisions by prot_dt (2 per protocol lookup), by 5 (det_root5) and by the step length (every dense-output sample)
+// were ~3/4 of the closed-form kernels' issue work.  Zero, infinite and NaN quotients are passed through unchanged
+// (the correction would turn inf into NaN and lose the sign of a zero).
+__device__ __forceinline__ double div_by(double a, double b, double rb) {
+  const double q0 = a * rb;
+  const double r = fma(-b, q0, a);
+  const double q1 = fma(r, rb, q0);
+  const double aq = __builtin_fabs(q0);
+  return (aq > 0.0 && aq < __builtin_inf()) ? q1 : q0;
+}
+
 __device__ __forceinline__ double det_root5(double x) {
   if (!(x < __builtin_inf()) || !(x > 0.0)) return x;
   unsigned long long u = (unsigned long long)__double_as_longlong(x);
@@ -124,7 +144,7 @@ __device__ __forceinline__ double det_root5(double x) {
   for (int it = 0; it < 7; ++it) {
     const double y2 = y * y;
     const double y4 = y2 * y2;
-    y = (4.0 * y + x / y4) / 5.0;
+    y = div_by(4.0 * y + x / y4, 5.0, 0.2);  // 0.2 == RN(1/5)
   }
   return y;
 }
@@ -196,13 +216,13 @@ __device__ __forceinline__ bool protocol_v(const KArgs &a, const double *__restr
   }
   const double t_last = a.prot_t0 + (double)(n - 1) * a.prot_dt;
   if (t < a.prot_t0 || t > t_last || t != t) { v = a.v_oob; return false; }
-  const double u = (t - a.prot_t0) / a.prot_dt;
+  const double u = div_by(t - a.prot_t0, a.prot_dt, a.prot_rdt);
   double ci = ceil(u);
   if (ci < 1.0) ci = 1.0;
   if (ci > (double)(n - 1)) ci = (double)(n - 1);
   const int i = (int)ci;
   const double x_lo = a.prot_t0 + (double)(i - 1) * a.prot_dt;
-  const double slope = (pv[i] - pv[i - 1]) / a.prot_dt;
+  const double slope = div_by(pv[i] - pv[i - 1], a.prot_dt, a.prot_rdt);
   v = slope * (t - x_lo) + pv[i - 1];
   return true;
 }
@@ -633,6 +653,13 @@ template <typename S, int D> __device__ __forceinline__ S rms_norm(const S *x) {
 }
 template <typename S> __device__ __forceinline__ S abs_(S x) { return x < 0 ? -x : x; }
 
+// Closed-form kernels are latency/issue bound at 64 trajectories per wavefront: the register budget is set for 4 (2-state)
+// or 2 (6-state) wavefronts per SIMD, so that the 4096 wavefronts of a 262 144-trajectory launch are all resident at once
+// (at 3 per SIMD a quarter of them ran in a second, nearly empty round).  MLP tiles: 1 per SIMD (512 registers).
+#ifndef IONODE_CF_WAVES
+#define IONODE_CF_WAVES(MODEL, G) ((G) > 1 ? 1 : ((MODEL) == IONODE_MODEL_HH2 ? 3 : ((MODEL) == IONODE_MODEL_MARKOV6 ? 2 : 1)))
+#endif
+
 template <typename S, int D> __device__ __forceinline__ void store_state(S *dst, const S *v) {
   if constexpr (D == 2 && sizeof(S) == 8) {
     *reinterpret_cast<double2 *>(dst) = make_double2(v[0], v[1]);
@@ -651,7 +678,7 @@ template <typename S, int D> __device__ __forceinline__ void store_state(S *dst,
 // The integrator.  One workgroup = one tile of TPW trajectories (G wavefronts for MLP models).
 // ---------------------------------------------------------------------------------------------
 template <int MODEL, typename S, int G, int RT, int NT, int PD, int TAIL>
-__global__ void __launch_bounds__(64 * G) ionode_dopri5_kernel(const KArgs a) {
+__global__ void __launch_bounds__(64 * G, IONODE_CF_WAVES(MODEL, G)) ionode_dopri5_kernel(const KArgs a) {
   using MT = ModelTraits<MODEL>;
   using R = Real<S>;
   constexpr int D = MT::D, NPAR = MT::NPAR;
@@ -734,10 +761,35 @@ __global__ void __launch_bounds__(64 * G) ionode_dopri5_kernel(const KArgs a) {
     }
     const S h = ((S)100 * h0 < h1) ? (S)100 * h0 : h1;
     dt = (double)h;
+    if (dt > a.dt_max) dt = a.dt_max;
   }
 
-  // solution[0] = y0
-  if (valid && primary) {
+  // ---- closed-form kernels, 2 states, exact uniform output grid, no current trace: "deferred aligned emission" ----
+  // gfx9 counts loads and stores in ONE in-order counter (vmcnt): a load issued behind a store cannot be consumed before that
+  // store has been acknowledged by L2 -- for a store to a cold line that is an HBM round trip.  The round-1 emission loop
+  // loaded t_eval once per 64-sample chunk behind the previous chunk's store, and the stage voltages of the next attempt
+  // behind all of them: waves sat in s_waitcnt 82 % of the time (SQ_WAIT_ANY, profiles/r02_closed_form.md).  Here
+  //   * output times are formed arithmetically (te_exact), the next attempt's protocol lookups are issued and consumed BEFORE
+  //     the emission, so the emission is LDS reads + VALU + stores only and nothing waits on a store;
+  //   * stores are whole 128-byte lines inside 1 KiB-aligned blocks of the row: samples behind the last line boundary wait in
+  //     an LDS tail buffer (< 8 samples per trajectory) for the next step -- no partial-line write, no read-for-ownership.
+  constexpr bool CF2 = !MT::MLP && D == 2;
+  constexpr int LS = 128 / (D * (int)sizeof(S));                     // samples per 128-byte line (D == 2: 8 or 16)
+  constexpr int TAILB = (((LS - 1) * D * (int)sizeof(S)) + 15) & ~15;  // bytes of one trajectory's tail buffer
+  constexpr int ROWB = (4 + 5 * D) * 8;
+  // compile-time variant (template parameter TAIL == 1 of a closed-form kernel); the dispatcher selects it only when
+  // te_dt > 0, te_exact and i_out == NULL hold (ionode_capi.hip)
+  constexpr bool defer = CF2 && TAIL == 1;
+  unsigned char *const tails = smem + 64 * ROWB;
+  int ow = 1;  // defer: next sample index of MY trajectory not yet written to HBM (ow <= oi, oi - ow < LS)
+  if constexpr (CF2 && defer) {
+    ow = 0;
+    if (valid && lane < TPW) *reinterpret_cast<S *>(tails + lane * TAILB) = y[0], *(reinterpret_cast<S *>(tails + lane * TAILB) + 1) = y[1];
+  }
+  auto te_at = [&](int idx) -> double { return a.te_t0 + (double)idx * a.te_dt; };
+
+  // solution[0] = y0  (deferred emission: it waits in the tail buffer for its line)
+  if (valid && primary && !(CF2 && defer)) {
     store_state<S, D>(yout, y);
     if (iout) {
       double v0;
@@ -755,6 +807,21 @@ __global__ void __launch_bounds__(64 * G) ionode_dopri5_kernel(const KArgs a) {
   int status = IONODE_STATUS_OK;
   bool active = valid && Nt > 1;
   const S nan_s = (S)__builtin_nan("");
+
+  // stage voltages of the coming attempt: pure functions of (t, dt).  Closed-form kernels carry them across iterations: they
+  // are looked up for the NEXT attempt right after the controller, ahead of the emission's stores (see `defer` above)
+  double vst[5];
+  bool inst[5];
+  auto lookup_stages = [&](double tt, double dd) {
+    const S tts = (S)tt, dds = (S)dd, tt1s = (S)(tt + dd);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const S ti = (i >= 4) ? R::prev_(tt1s) : tts + (S)kAlpha[i] * dds;  // alpha == 1: Perturb.PREV (stages 4 and 5)
+      inst[i] = protocol_v(a, pv, (double)ti, vst[i]);
+    }
+  };
+  constexpr bool CARRY_V = !MT::MLP && D == 2;  // (the 6-state kernel has no registers to spare for it: +50 % time when tried)
+  if constexpr (CARRY_V) lookup_stages(t, dt);
 
   for (;;) {
     // ---- per-trajectory assertions of _adaptive_step / _advance ----
@@ -793,18 +860,12 @@ __global__ void __launch_bounds__(64 * G) ionode_dopri5_kernel(const KArgs a) {
     // ---- _runge_kutta_step ----
     const double t0 = t;
     const double t1 = t0 + dt;
-    const S t0s = (S)t0, dts = (S)dt, t1s = (S)t1;
+    const S dts = (S)dt;
     S k[7][D], yi[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) k[0][d] = f[d];
     // stage voltages: pure functions of (t0, dt), so all protocol loads are issued ahead of the stages
-    double vst[5];
-    bool inst[5];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const S ti = (i >= 4) ? R::prev_(t1s) : t0s + (S)kAlpha[i] * dts;  // alpha == 1: Perturb.PREV (stages 4 and 5)
-      inst[i] = protocol_v(a, pv, (double)ti, vst[i]);
-    }
+    if constexpr (!CARRY_V) lookup_stages(t0, dt);
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       S bd[6];
@@ -861,6 +922,8 @@ __global__ void __launch_bounds__(64 * G) ionode_dopri5_kernel(const KArgs a) {
 #endif
     const int nacc_before = nacc, oi_before = oi;
     if (active) { if (accept) ++nacc; else ++nrej; }
+    const double dt_capped = (dt_next > a.dt_max) ? a.dt_max : dt_next;  // NaN stays NaN (-> 'underflow in dt')
+    if constexpr (CARRY_V) lookup_stages(acc_now ? t1 : t0, (active || acc_now) ? dt_capped : dt);
 
     // ---- _interp_fit + cooperative dense output ----
     S ic[5][D];  // e, d, c, b, a
@@ -882,6 +945,25 @@ __global__ void __launch_bounds__(64 * G) ionode_dopri5_kernel(const KArgs a) {
         ic[0][d] = Y0;
       }
     }
+    // x = (t_k - t0) / (t1 - t0) of every dense-output sample: ONE division per attempt (the reciprocal of the step length),
+    // then div_by() per sample -- the same correctly rounded quotient
+    const double den = t1 - t0;
+    const double rden = 1.0 / den;
+    // Closed-form kernels: a lane's interpolant (t0, step length, its reciprocal, 5 x D coefficients) goes to its LDS row;
+    // the wavefront then reads the emitting trajectory's row at a uniform address (7 broadcast ds_read_b128 for D = 2)
+    // instead of ~29 v_readlane per emitting trajectory.  The workgroup is one wavefront: LDS is in order, no barrier.
+    constexpr int ROW = 4 + 5 * D;  // doubles per row, 16-byte aligned rows
+    if constexpr (!MT::MLP) {
+      double2 *row = reinterpret_cast<double2 *>(smem) + lane * (ROW / 2);
+      row[0] = make_double2(t0, den);
+      row[1] = make_double2(rden, 0.0);
+      if constexpr (D % 2 == 0) {
+#pragma unroll
+        for (int c = 0; c < 5; ++c)
+#pragma unroll
+          for (int d = 0; d < D; d += 2) row[2 + (c * D + d) / 2] = make_double2((double)ic[c][d], (double)ic[c][d + 1]);
+      }
+    }
     if (a.te_dt > 0.0) {
       // ---- output cursor, lane-parallel: how many requested times fall in (t0, t1] for MY trajectory? ----
       // Guess the last index from the (nearly) uniform output grid, then VERIFY against t_eval itself and walk to the
@@ -889,12 +971,77 @@ __global__ void __launch_bounds__(64 * G) ionode_dopri5_kernel(const KArgs a) {
       // (instead of one dependent load per trajectory in the cooperative scan below).
       int n_out = 0;
       if (acc_now) {
-        const double gf = floor((t1 - a.te_t0) / a.te_dt);
+        const double gf = floor((t1 - a.te_t0) * a.te_rdt);  // a guess: verified below
         long long g = (gf < (double)(oi - 1)) ? (long long)(oi - 1) : ((gf > (double)(Nt - 1)) ? (long long)(Nt - 1) : (long long)gf);
-        while (g >= oi && a.t_eval[g] > t1) --g;
-        while (g + 1 < Nt && a.t_eval[g + 1] <= t1) ++g;
+        if constexpr (CF2 && defer) {
+          while (g >= oi && te_at((int)g) > t1) --g;
+          while (g + 1 < Nt && te_at((int)g + 1) <= t1) ++g;
+        } else {
+          while (g >= oi && a.t_eval[g] > t1) --g;
+          while (g + 1 < Nt && a.t_eval[g + 1] <= t1) ++g;
+        }
         n_out = (int)(g - oi + 1);
       }
+      if constexpr (CF2 && defer) {
+        // ---- deferred aligned emission (closed-form, D == 2): whole lines inside 1 KiB-aligned blocks of the row ----
+        unsigned long long emd = __ballot(n_out > 0 && lane < TPW);
+#ifdef IONODE_EXP_NOEMIT  // timing experiment only (wrong results): stepping cost without any dense output
+        emd = 0ull; ow = oi + n_out;
+#endif
+        while (emd) {
+          const int jj = __builtin_ctzll(emd);
+          emd &= emd - 1;
+          const int o = __builtin_amdgcn_readlane(oi, jj), n = __builtin_amdgcn_readlane(n_out, jj);
+          const int w = __builtin_amdgcn_readlane(ow, jj), tr = __builtin_amdgcn_readlane(traj, jj);
+          const double2 *rj = reinterpret_cast<const double2 *>(smem) + jj * (ROW / 2);
+          const double2 h0 = rj[0], h1 = rj[1];
+          const double t0b = h0.x, denb = h0.y, rdenb = h1.x;
+          S cb[5][D];
+#pragma unroll
+          for (int c = 0; c < 5; ++c) {
+            const double2 cc = rj[2 + c];
+            cb[c][0] = (S)cc.x; cb[c][1] = (S)cc.y;
+          }
+          const long long G0 = (long long)tr * Nt;  // global sample index of the row's first sample
+          const int end = o + n;
+          int E = Nt;                                // samples [w, E) go to HBM now, [E, end) wait in the tail buffer
+          if (end < Nt) {
+            E = (int)(((G0 + end) & ~(long long)(LS - 1)) - G0);
+            if (E < w) E = w;
+          }
+          S *__restrict__ yo = reinterpret_cast<S *>(a.y_out) + (size_t)tr * Nt * D;
+          unsigned char *const tj = tails + jj * TAILB;
+          for (int b0 = (int)(((G0 + w) & ~63ll) - G0); b0 < end; b0 += 64) {
+            const int idx = b0 + lane;
+            if (idx >= w && idx < end) {
+              S out[D];
+              if (idx < o) {  // computed by an earlier step: parked in the tail buffer
+                const S *ts = reinterpret_cast<const S *>(tj) + (size_t)(idx - w) * D;
+                out[0] = ts[0]; out[1] = ts[1];
+              } else {
+                const S x = (S)div_by(te_at(idx) - t0b, denb, rdenb);  // _interp_evaluate: x in fp64, cast; running powers
+                S xp = x;
+#pragma unroll
+                for (int d = 0; d < D; ++d) out[d] = cb[0][d] + x * cb[1][d];
+#pragma unroll
+                for (int c = 2; c < 5; ++c) {
+                  xp = xp * x;
+#pragma unroll
+                  for (int d = 0; d < D; ++d) out[d] = out[d] + xp * cb[c][d];
+                }
+              }
+#ifdef IONODE_EXP_NOSTORE  // timing experiment only (wrong results): everything but the global stores
+              if (idx < E) { if (out[0] == (S)1.2345e-300) store_state<S, D>(yo + (size_t)idx * D, out); }
+#else
+              if (idx < E) store_state<S, D>(yo + (size_t)idx * D, out);
+#endif
+              else store_state<S, D>(reinterpret_cast<S *>(tj) + (size_t)(idx - E) * D, out);
+            }
+          }
+          if (j == jj) ow = E;
+        }
+        oi += n_out;
+      } else {
       // ---- owner wavefront evaluates and stores; the t_eval loads of the next trajectory are issued ahead ----
       unsigned long long em = __ballot(n_out > 0 && lane < TPW);
       if (G > 1) {  // trajectory jj belongs to wavefront jj % G
@@ -913,12 +1060,26 @@ __global__ void __launch_bounds__(64 * G) ionode_dopri5_kernel(const KArgs a) {
         double tk = tk_nxt;
         if (em && on + lane < Nt) tk_nxt = a.t_eval[on + lane];  // next trajectory's first chunk, in flight meanwhile
         const int n = __builtin_amdgcn_readlane(n_out, jj);
-        const double t1b = bcast_f64(t1, jj), t0b = bcast_f64(t0, jj);
+        double t0b, denb, rdenb;
         S cb[5][D];
+        if constexpr (!MT::MLP) {
+          const double2 *rj = reinterpret_cast<const double2 *>(smem) + jj * (ROW / 2);
+          const double2 h0 = rj[0], h1 = rj[1];
+          t0b = h0.x; denb = h0.y; rdenb = h1.x;
 #pragma unroll
-        for (int c = 0; c < 5; ++c)
+          for (int c = 0; c < 5; ++c)
 #pragma unroll
-          for (int d = 0; d < D; ++d) cb[c][d] = bcast<S>(ic[c][d], jj);
+            for (int d = 0; d < D; d += 2) {
+              const double2 cc = rj[2 + (c * D + d) / 2];
+              cb[c][d] = (S)cc.x; cb[c][d + 1] = (S)cc.y;
+            }
+        } else {
+          t0b = bcast_f64(t0, jj); denb = bcast_f64(den, jj); rdenb = bcast_f64(rden, jj);
+#pragma unroll
+          for (int c = 0; c < 5; ++c)
+#pragma unroll
+            for (int d = 0; d < D; ++d) cb[c][d] = bcast<S>(ic[c][d], jj);
+        }
         const int tr = __builtin_amdgcn_readlane(traj, jj);
         S *__restrict__ yo = reinterpret_cast<S *>(a.y_out) + (size_t)tr * Nt * D;
         double *__restrict__ io = nullptr;
@@ -932,7 +1093,7 @@ __global__ void __launch_bounds__(64 * G) ionode_dopri5_kernel(const KArgs a) {
           const int idx = o + c0 + lane;
           if (c0 > 0 && c0 + lane < n) tk = a.t_eval[idx];
           if (c0 + lane < n) {
-            const S x = (S)((tk - t0b) / (t1b - t0b));  // _interp_evaluate: x in fp64, cast; running powers
+            const S x = (S)div_by(tk - t0b, denb, rdenb);  // _interp_evaluate: x = (t - t0) / (t1 - t0) in fp64, cast; running powers
             S out[D];
             S xp = x;
 #pragma unroll
@@ -958,6 +1119,7 @@ __global__ void __launch_bounds__(64 * G) ionode_dopri5_kernel(const KArgs a) {
         o = on;
       }
       oi += n_out;
+      }
     } else {
       // ---- no grid hint: cooperative scan, every wavefront advances every cursor ----
       unsigned long long em = __ballot(acc_now && lane < TPW);
@@ -968,13 +1130,13 @@ __global__ void __launch_bounds__(64 * G) ionode_dopri5_kernel(const KArgs a) {
         int o = __builtin_amdgcn_readlane(oi, jj);
         const double t1b = bcast_f64(t1, jj);
         // every wavefront advances the output cursor; only the owner evaluates and stores
-        double t0b = 0.0;
+        double t0b = 0.0, denb = 1.0, rdenb = 1.0;
         S cb[5][D];
         S *__restrict__ yo = nullptr;
         double *__restrict__ io = nullptr;
         const double *__restrict__ pvb = nullptr;
         if (owner) {
-          t0b = bcast_f64(t0, jj);
+          t0b = bcast_f64(t0, jj); denb = bcast_f64(den, jj); rdenb = bcast_f64(rden, jj);
 #pragma unroll
           for (int c = 0; c < 5; ++c)
 #pragma unroll
@@ -993,7 +1155,7 @@ __global__ void __launch_bounds__(64 * G) ionode_dopri5_kernel(const KArgs a) {
           const bool ok = tk <= t1b;
           if (owner && ok) {
             // _interp_evaluate: x in fp64, cast; running powers
-            const S x = (S)((tk - t0b) / (t1b - t0b));
+            const S x = (S)div_by(tk - t0b, denb, rdenb);
             S out[D];
             S xp = x;
 #pragma unroll
@@ -1041,9 +1203,24 @@ __global__ void __launch_bounds__(64 * G) ionode_dopri5_kernel(const KArgs a) {
       t = t1;
       if (oi >= Nt) active = false;  // all requested outputs produced
     }
-    if (active || acc_now) dt = dt_next;
+    if (active || acc_now) dt = dt_capped;
   }
 
+  if constexpr (CF2 && defer) {  // trajectories that did not end on their last sample (failed, or a single output): flush the tail
+    unsigned long long fl = __ballot(valid && lane < TPW && ow < oi);
+    while (fl) {
+      const int jj = __builtin_ctzll(fl);
+      fl &= fl - 1;
+      const int w = __builtin_amdgcn_readlane(ow, jj), o = __builtin_amdgcn_readlane(oi, jj);
+      const int tr = __builtin_amdgcn_readlane(traj, jj);
+      S *__restrict__ yo = reinterpret_cast<S *>(a.y_out) + (size_t)tr * Nt * D;
+      if (w + lane < o) {
+        const S *ts = reinterpret_cast<const S *>(tails + jj * TAILB) + (size_t)lane * D;
+        S out[D] = {ts[0], ts[1]};
+        store_state<S, D>(yo + (size_t)(w + lane) * D, out);
+      }
+    }
+  }
 #ifdef IONODE_STAMPS
   STAMP(stamps_, 0);
   if (blockIdx.x == 0 && threadIdx.x == 0 && a.step_log != nullptr && a.step_log_cap >= 4)

@@ -63,6 +63,12 @@ struct GradMlp {
   static constexpr int G = 4;
   static constexpr int RT = (NT + G - 1) / G;  // row tiles per wavefront (rt = wave + 4i)
   static constexpr int NP = 16 * NT;
+  // Weight fragments are consumed from a register ring one product deep that runs AHEAD of the MFMAs across product boundaries
+  // (forward layers 0..L-1, transposed layers L-1..0, then the next evaluation's layer 0): a fragment is re-loaded right behind
+  // the MFMAs that read it, so an L2 round trip (~1 us under load, ~5 k-tiles of MFMA time) is covered.  Without the ring every
+  // k-tile waited for its own loads: 18 us per product instead of the 6.7k-cycle MFMA floor (measured).
+  static constexpr int PD = NT;  // a whole product ahead (slot = k-tile: the ring phase is the same for every product)
+  f32x4 ring[PD][(NT + 3) / 4];
   f32x4 *Hs;          // LDS [L+1][NT*64]   activations after LeakyReLU, accumulator layout
   f32x4 *Ds;          // LDS [2][NT*64]     pre-activation gradients, ping-pong over layers
   const f32x4 *W0s;   // LDS [NP] {b0, w00, w01, 0}
@@ -88,8 +94,15 @@ struct GradMlp {
     rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.img), 0, (int)(grad_img_floats(L, NT) * 4), 0x00020000);
     fwd0 = (unsigned)(grad_img_fwd(L, NT) * 4);
     bwd0 = (unsigned)(grad_img_bwd(L, NT) * 4);
+#pragma unroll
+    for (int u = 0; u < PD; ++u)
+#pragma unroll
+      for (int i = 0; i < RT; ++i) ring[u][i] = frag(fwd0, 0, row_tile(i), u);  // prime: first product of the first evaluation
     __syncthreads();
   }
+  // row tile i of this wavefront; slots past the last tile re-use it (their MFMAs run into a discarded accumulator: the
+  // stream stays branch-free, and wavefront 0 -- the one with RT real tiles -- sets the pace anyway)
+  __device__ __forceinline__ int row_tile(int i) const { const int rt = wave + i * G; return rt < NT ? rt : NT - 1; }
   __device__ __forceinline__ double *gs() const {  // LDS [16][10] fp64 scratch behind the small vectors (8-byte aligned)
     return reinterpret_cast<double *>(const_cast<float *>(wlS) + NP + 4);
   }
@@ -106,23 +119,28 @@ struct GradMlp {
   __device__ __forceinline__ void rec_store(f32x4 *tile, const f32x4 &v) const {
     const int q = lane >> 4, n = lane & 15;
     float *p = reinterpret_cast<float *>(tile) + 64 * (n & 3) + 16 * q + (n >> 2);
-    p[0] = v[0]; p[4] = v[1]; p[8] = v[2]; p[12] = v[3];
+    // written once, read once by ionode_grad_reduce: non-temporal, so the stream does not evict the weight image from L2
+    __builtin_nontemporal_store(v[0], p); __builtin_nontemporal_store(v[1], p + 4);
+    __builtin_nontemporal_store(v[2], p + 8); __builtin_nontemporal_store(v[3], p + 12);
   }
 
-  // acc[i] (+)= A(sec, l)[row tile wave + 4i][:] . B[:]   over all NT k-tiles; B read from LDS in accumulator layout
-  __device__ __forceinline__ void product(unsigned sec, int l, const f32x4 *__restrict__ B, f32x4 (&acc)[RT]) const {
+  // acc[i] (+)= A(sec, l)[row tile wave + 4i][:] . B[:]   over all NT k-tiles; B read from LDS in accumulator layout.
+  // (nsec, nl): the product that follows this one -- its first PD k-tiles are loaded behind this product's last MFMAs.
+  __device__ __forceinline__ void product(unsigned sec, int l, unsigned nsec, int nl, const f32x4 *__restrict__ B,
+                                          f32x4 (&acc)[RT]) {
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
       const f32x4 b = B[kt * 64 + lane];
+      const int slot = kt % PD;
 #pragma unroll
-      for (int i = 0; i < RT; ++i) {
-        const int rt = wave + i * G;
-        if (rt < NT) {
-          const f32x4 w = frag(sec, l, rt, kt);
+      for (int i = 0; i < RT; ++i)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], b[r], acc[i], 0, 0, 0);
-        }
-      }
+        for (int r = 0; r < 4; ++r) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[slot][i][r], b[r], acc[i], 0, 0, 0);
+      const int nk = kt + PD;
+#pragma unroll
+      for (int i = 0; i < RT; ++i)
+        ring[slot][i] = (nk < NT) ? frag(sec, l, row_tile(i), nk) : frag(nsec, nl, row_tile(i), nk - NT);
+      __builtin_amdgcn_sched_barrier(0);  // keep the refills here (hipcc otherwise sinks them behind the product)
     }
   }
 
@@ -130,6 +148,13 @@ struct GradMlp {
   // x = (V/100, a) as the forward casts them, seed = adjoint of the net output.  Returns seed * d net / d x1.
   // rec != NULL: the (h_l, d_l) tiles and the scalars of this evaluation are streamed there for ionode_grad_reduce.
   __device__ __forceinline__ float vjp(float x0, float x1, float seed, float *__restrict__ rec) {
+    return vjp_from_output(x0, x1, rec, [seed](float) -> float { return seed; });
+  }
+
+  // The same product with the seed computed from the net's output: seed = seed_of(net([x0, x1])) per lane (regression:
+  // d loss / d net).  The output layer runs only when the functor needs it; a constant functor leaves it out.
+  template <typename SeedFn>
+  __device__ __forceinline__ float vjp_from_output(float x0, float x1, float *__restrict__ rec, SeedFn seed_of) {
     const int q = lane >> 4;
     f32x4 *__restrict__ recH = reinterpret_cast<f32x4 *>(rec);
     f32x4 *__restrict__ recD = recH + (size_t)(L + 1) * NT * 64;
@@ -156,7 +181,7 @@ struct GradMlp {
         const int rt = wave + i * G;
         acc[i] = (rt < NT) ? *reinterpret_cast<const f32x4 *>(biasS + (l - 1) * NP + 16 * rt + 4 * q) : f32x4{0, 0, 0, 0};
       }
-      product(fwd0, l - 1, Hs + (size_t)(l - 1) * NT * 64, acc);
+      product(fwd0, l - 1, l < L ? fwd0 : bwd0, l < L ? l : L - 1, Hs + (size_t)(l - 1) * NT * 64, acc);
 #pragma unroll
       for (int i = 0; i < RT; ++i) {
         const int rt = wave + i * G;
@@ -169,6 +194,20 @@ struct GradMlp {
         }
       }
       __syncthreads();
+    }
+    // ---- net = wl . h_L + bl (four partial chains, one per lane group, as the forward kernel's last layer), then the seed ----
+    float seed;
+    {
+      float part = 0.0f;
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt) {
+        const f32x4 w = *reinterpret_cast<const f32x4 *>(wlS + 16 * kt + 4 * q);
+        const f32x4 h = Hs[((size_t)L * NT + kt) * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part = fmaf(w[r], h[r], part);
+      }
+      const float pair = part + __shfl_xor(part, 16);
+      seed = seed_of((pair + __shfl_xor(pair, 32)) + wlS[NP]);
     }
     // ---- backward: d_L = seed * wl * lrelu'(h_L); d_{l-1} = (W_l^T d_l) * lrelu'(h_{l-1}) ----
 #pragma unroll
@@ -189,7 +228,7 @@ struct GradMlp {
       f32x4 acc[RT];
 #pragma unroll
       for (int i = 0; i < RT; ++i) acc[i] = f32x4{0, 0, 0, 0};
-      product(bwd0, l - 1, Ds + (size_t)(l & 1) * NT * 64, acc);
+      product(bwd0, l - 1, l > 1 ? bwd0 : fwd0, l > 1 ? l - 2 : 0, Ds + (size_t)(l & 1) * NT * 64, acc);
 #pragma unroll
       for (int i = 0; i < RT; ++i) {
         const int rt = wave + i * G;

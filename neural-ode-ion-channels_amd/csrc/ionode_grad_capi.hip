@@ -5,6 +5,7 @@
 
 #include "ionode_grad.hpp"
 #include "ionode_grad_reduce.hpp"
+#include "ionode_regress.hpp"
 
 namespace {
 
@@ -118,7 +119,7 @@ int ionode_dopri5_backward(const ionode_desc *d, int32_t it_begin, int32_t it_en
   a.k.params = params; a.k.prot_v = prot_v; a.k.prot_t = prot_t; a.k.prot_of_traj = prot_of_traj; a.k.t_eval = t_eval;
   a.k.B = d->n_traj; a.k.Nt = d->n_out; a.k.P = d->n_prot; a.k.Np = d->prot_n; a.k.n_params = d->n_params;
   a.k.L = L; a.k.N = d->mlp_width; a.k.NP = NP; a.k.NT = NT;
-  a.k.prot_t0 = d->prot_t0; a.k.prot_dt = d->prot_dt; a.k.v_oob = d->v_oob;
+  a.k.prot_t0 = d->prot_t0; a.k.prot_dt = d->prot_dt; a.k.prot_rdt = 1.0 / d->prot_dt; a.k.v_oob = d->v_oob;
   a.img = grad_image; a.ckpt = d->ckpt; a.ckpt_cap = d->ckpt_cap; a.nacc = n_accepted; a.grad_y = grad_y; a.state = state;
   a.records = records; a.grad_params = grad_params; a.grad_y0 = grad_y0;
   a.it_begin = it_begin; a.it_end = it_end; a.n_iter = n_iter;
@@ -135,6 +136,57 @@ int ionode_grad_reduce(int32_t L, int32_t N, const float *records, int64_t n_rec
   const int NT = np_of(N) / 16;
   const hipError_t e = ionode::launch_grad_reduce(L, NT, records, n_records, n_slabs, partials, reinterpret_cast<hipStream_t>(stream));
   if (e == hipErrorInvalidValue) { gerr("ionode_grad_reduce: width outside the compiled variants"); return IONODE_ERR_UNSUPPORTED; }
+  if (e != hipSuccess) { gerr(hipGetErrorString(e)); return IONODE_ERR_LAUNCH; }
+  return IONODE_OK;
+}
+
+int ionode_regress_step(int32_t L, int32_t N, const float *grad_image, const float *x, const float *offset, const float *y,
+                        int32_t n_rows, float netscale, float *records, double *loss_partials, int32_t n_workgroups,
+                        void *stream) {
+  if (!grad_image || !x || !y || !records || !loss_partials || n_rows < 1 || n_workgroups < 1 || L < 1 || N < 1) {
+    gerr("ionode_regress_step: bad argument"); return IONODE_ERR_ARG;
+  }
+  const int NT = np_of(N) / 16;
+  if (ionode::grad_lds_bytes(L, NT) > 160 * 1024) { gerr("ionode_regress_step: (L, N) does not fit the LDS of one CU"); return IONODE_ERR_UNSUPPORTED; }
+  ionode::RArgs a;
+  memset(&a, 0, sizeof a);
+  a.img = grad_image; a.x = x; a.y = y; a.offset = offset; a.records = records; a.loss_part = loss_partials;
+  a.M = n_rows; a.L = L; a.N = N; a.NT = NT; a.record_floats = ionode::grad_record_floats(L, NT); a.netscale = netscale;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  switch (NT) {
+    case 1: ionode::launch_regress<1>(a, (unsigned)n_workgroups, s); break;
+    case 7: ionode::launch_regress<7>(a, (unsigned)n_workgroups, s); break;
+    case 13: ionode::launch_regress<13>(a, (unsigned)n_workgroups, s); break;
+    default: gerr("ionode_regress_step: width outside the compiled variants (N pads to 16, 112 or 208)"); return IONODE_ERR_UNSUPPORTED;
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { gerr(hipGetErrorString(e)); return IONODE_ERR_LAUNCH; }
+  return IONODE_OK;
+}
+
+int ionode_adam_step(int32_t n_params, int32_t n_slabs, int32_t L, int32_t N, const float *partials, const int32_t *padmap,
+                     float *weights, float *exp_avg, float *exp_avg_sq, float lr, float beta1, float beta2, float eps,
+                     int32_t step, float *grad_out, int32_t apply, void *stream) {
+  if (!partials || !padmap || n_params < 1 || n_slabs < 1 || step < 1 || (apply && (!weights || !exp_avg || !exp_avg_sq))) {
+    gerr("ionode_adam_step: bad argument"); return IONODE_ERR_ARG;
+  }
+  const float bc1 = 1.0f - powf(beta1, (float)step);
+  const float bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
+  const size_t partf = ionode::grad_partial_floats(L, np_of(N) / 16);
+  hipLaunchKernelGGL(ionode::ionode_adam_kernel, dim3((n_params + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     n_params, n_slabs, partf, partials, padmap, weights, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, bc1, bc2_sqrt,
+                     grad_out, apply);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { gerr(hipGetErrorString(e)); return IONODE_ERR_LAUNCH; }
+  return IONODE_OK;
+}
+
+int ionode_image_refresh(int32_t L, int32_t N, const int32_t *image_map, const float *weights, float *grad_image, void *stream) {
+  if (!image_map || !weights || !grad_image || L < 1 || N < 1) { gerr("ionode_image_refresh: bad argument"); return IONODE_ERR_ARG; }
+  const size_t n = ionode::grad_img_floats(L, np_of(N) / 16);
+  hipLaunchKernelGGL(ionode::ionode_image_refresh_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), n, image_map, weights, grad_image);
+  const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { gerr(hipGetErrorString(e)); return IONODE_ERR_LAUNCH; }
   return IONODE_OK;
 }

@@ -8,6 +8,7 @@ using LaunchFn = hipError_t (*)(const KArgs &, unsigned grid, size_t lds, hipStr
 
 struct Variant {
   int model, f32, G, RT, NT, PD;  // NT = k-tiles (16*NT = padded MLP width), PD = weight-ring depth
+  int tail;                       // closed-form kernels: 1 = deferred aligned emission variant (ionode_device.hpp `defer`)
   LaunchFn fn;
   const char *name;  // as rocprofv3 --kernel-trace prints it
 };
@@ -27,7 +28,7 @@ hipError_t launch(const KArgs &a, unsigned grid, size_t lds, hipStream_t s) {
 #define IONODE_VARIANT(MODEL, S, F32, G, RT, NT, PD, TAIL) IONODE_VARIANT_(MODEL, S, F32, G, RT, NT, PD, TAIL)
 #define IONODE_VARIANT_(MODEL, S, F32, G, RT, NT, PD, TAIL)                                   \
   Variant {                                                                                   \
-    MODEL, F32, G, RT, NT, PD, &launch<MODEL, S, G, RT, NT, PD, TAIL>,                          \
+    MODEL, F32, G, RT, NT, PD, TAIL, &launch<MODEL, S, G, RT, NT, PD, TAIL>,                          \
         "ionode_dopri5_kernel<" #MODEL ", " #S ", " #G ", " #RT ", " #NT ", " #PD ", " #TAIL ">" \
   }
 #ifndef IONODE_TAIL13

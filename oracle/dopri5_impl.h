@@ -261,7 +261,7 @@ static int SFX(adaptive_step)(const ctx_t *c, SFX(rkstate) *s, REAL rtol, REAL a
 }
 
 static int SFX(solve)(const ctx_t *c, const double *y0d, const double *t_eval, int n_out, double rtol_d,
-                      double atol_d, int64_t max_steps, int64_t max_total, double *y_out, int64_t *stats, double *step_log,
+                      double atol_d, int64_t max_steps, int64_t max_total, double max_step, double *y_out, int64_t *stats, double *step_log,
                       int64_t step_log_cap) {
   const int D = c->D;
   const REAL rtol = (REAL)rtol_d, atol = (REAL)atol_d;
@@ -273,6 +273,8 @@ static int SFX(solve)(const ctx_t *c, const double *y0d, const double *t_eval, i
   ++nfe;
   for (int d = 0; d < D; ++d) s.y1[d] = y0[d];
   s.dt = SFX(select_initial_step)(c, t_eval[0], y0, s.f1, rtol, atol, &nfe);
+  const double dt_max = max_step > 0.0 ? max_step : INFINITY; /* product extension; off in every reference-parity test */
+  if (s.dt > dt_max) s.dt = dt_max;
   s.t0 = s.t1 = t_eval[0];
   for (int q = 0; q < 5; ++q)
     for (int d = 0; d < D; ++d) s.ic[q][d] = y0[d];
@@ -291,6 +293,7 @@ static int SFX(solve)(const ctx_t *c, const double *y0d, const double *t_eval, i
       double ratio_d = 0.0;
       status = SFX(adaptive_step)(c, &s, rtol, atol, &nfe, &acc, &ratio_d);
       if (status != STATUS_OK) break;
+      if (s.dt > dt_max) s.dt = dt_max;
       if (step_log && nacc + nrej < step_log_cap) {
         double *row = step_log + 4 * (nacc + nrej);
         row[0] = t_before; row[1] = dt_before; row[2] = ratio_d; row[3] = (double)acc;

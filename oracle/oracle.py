@@ -23,6 +23,7 @@ class OracleDesc(C.Structure):
         ("mlp_width", C.c_int32), ("n_params", C.c_int32), ("max_steps", C.c_int64),
         ("prot_t0", C.c_double), ("prot_dt", C.c_double), ("v_oob", C.c_double),
         ("rtol", C.c_double), ("atol", C.c_double), ("max_total_steps", C.c_int64),
+        ("max_step", C.c_double),
     ]
 
 
@@ -55,7 +56,7 @@ def _p(a):
 
 def solve(model, params, prot_v, y0, t_eval, *, weights=None, mlp_layers=0, mlp_width=0, prot_t=None,
           prot_t0=0.0, prot_dt=1.0, prot_of_traj=None, state_f32=False, rtol=1e-7, atol=1e-9,
-          v_oob=-80.0, max_steps=0, max_total_steps=0, nthreads=0, step_log_cap=0):
+          v_oob=-80.0, max_steps=0, max_total_steps=0, max_step=0.0, nthreads=0, step_log_cap=0):
     """Solve B trajectories.  Returns dict(y[B,Nt,D] f64, status[B], stats[B,4], step_log).
     max_steps: attempts per output interval (torchdiffeq max_num_steps; 0 = 2**31 - 1); max_total_steps: attempts over
     the whole solve (0 = 1 000 000, the product's default runaway bound; < 0 = unbounded)."""
@@ -82,7 +83,7 @@ def solve(model, params, prot_v, y0, t_eval, *, weights=None, mlp_layers=0, mlp_
     d = OracleDesc(model=model, state_f32=int(state_f32), n_state=D, n_out=Nt, n_traj=B, n_prot=P,
                    prot_n=Np, mlp_layers=mlp_layers, mlp_width=mlp_width, n_params=params.shape[1],
                    max_steps=max_steps, prot_t0=prot_t0, prot_dt=prot_dt, v_oob=v_oob, rtol=rtol, atol=atol,
-                   max_total_steps=max_total_steps)
+                   max_total_steps=max_total_steps, max_step=max_step)
     y = np.empty((B, Nt, D), dtype=np.float64)
     status = np.zeros(B, dtype=np.int32)
     stats = np.zeros((B, 4), dtype=np.int64)
