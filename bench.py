@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="trajectories timed on the host (0 = auto)")
     ap.add_argument("--no-python-baseline", action="store_true", help="skip the reference-structured Python leg")
     ap.add_argument("--tile-waves", type=int, default=0)
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the closed-form / gradient / regression measurements appended to the JSON line")
     ap.add_argument("--stamps", action="store_true", help="diagnostic build (-DIONODE_STAMPS): print phase shares")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -215,10 +217,129 @@ def main():
                 res["cpu_baseline_python"] = python_reference_structured_baseline(ion, prot_v, weights, Nt, out)
             except Exception as e:  # informational leg only
                 res["cpu_baseline_python"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and not args.no_extra_legs and B == 4096 and Nt == 100001:
+        # the other kernels of the path, measured in the same driver-run record: never part of `value`
+        del r, prot_v, i_ref
+        out.clear()
+        torch.cuda.empty_cache()
+        for key, fn in (("roofline_closed_form", closed_form_legs), ("gradient_config5", gradient_leg),
+                        ("regression_step", regression_leg)):
+            try:
+                res[key] = fn(ion, dev, weights)
+            except Exception as e:  # informational legs only
+                res[key] = {"error": repr(e)}
+            torch.cuda.empty_cache()
     if rank == 0:
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def _timed(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    return float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+
+def closed_form_legs(ion, dev, weights):
+    """The HBM-side kernels (SURVEY.md finding 5: the >= 50 %-of-HBM target applies to these, not to s00): 2 s sine-wave
+    protocols (64 distinct, L2-resident), 0.1 ms output grid, fp64 state, states only.  Algorithmic bytes = N_t * D * 8 per
+    trajectory written + the distinct protocols read once."""
+    capi, P = ion.capi, ion.protocols
+    Nt, n_prot = 20001, 64
+    pv = P.sinewave(P.sinewave_scales(0, n_prot), n_samples=Nt, xp=torch, device=dev)
+    te = torch.arange(Nt, dtype=torch.float64, device=dev) * 0.1
+    rng = np.random.default_rng(0)
+    p_m6 = np.array([5.94625498751561316e-02, 1.21417701632850410e+02, 4.76436985414236425e+00, 3.49383233960778904e-03,
+                     9.62243079990877703e+01, 2.26404683824047979e+01, 8.00924780462999131e+00, 2.43749808069009823e+01,
+                     2.06822607368134157e+02, 3.30791433507312362e+01, 1.26069071928587784e+00, 2.24844970727316245e+01]) * 1e-3
+    N10, L10 = 10, 5
+    w10 = np.random.default_rng(1).normal(0, 0.1, 2 * N10 + N10 + L10 * (N10 * N10 + N10) + N10 + 1).astype(np.float32)
+    legs = {}
+    for name, model, p0, y0, B, mlp in (("hh2", capi.MODEL_HH2, P_HH, [0.0, 1.0], 262144, None),
+                                        # 12 resident wavefronts per CU x 256 CUs x 64 trajectories = 196 608 per "round":
+                                        # 262 144 is 1.33 rounds (the last third runs on a third-full chip), 393 216 is 2.0
+                                        ("hh2_two_full_rounds", capi.MODEL_HH2, P_HH, [0.0, 1.0], 393216, None),
+                                        ("markov6", capi.MODEL_MARKOV6, p_m6, [0.0, 1.0, 0, 0, 0, 0], 65536, None),
+                                        ("nnf_s03_5x10", capi.MODEL_NNF, P_HH, [0.0, 1.0], 65536, (w10, L10, N10))):
+        D = len(y0)
+        params = torch.from_numpy(p0[None, :] * rng.uniform(0.8, 1.25, (B, p0.size))).to(dev)
+        y0t = torch.tensor([y0], dtype=torch.float64, device=dev).repeat(B, 1).contiguous()
+        pot = (torch.arange(B, dtype=torch.int32, device=dev) % n_prot).contiguous()
+        kw = dict(prot_t0=0.0, prot_dt=0.1, prot_of_traj=pot, t_eval_hint=(0.0, 0.1), t_eval_exact=True)
+        if mlp:
+            kw.update(mlp_packed=torch.from_numpy(capi.mlp_pack(mlp[0], mlp[1], mlp[2])).to(dev), mlp_layers=mlp[1], mlp_width=mlp[2])
+        o = {}
+        hold = {}
+
+        def run():
+            hold["r"] = capi.dopri5(model, params, pv, y0t, te, out=o, **kw)
+            o.update({k: hold["r"][k] for k in ("y", "status", "stats")})
+        ms = _timed(run, 2)
+        nbytes = B * Nt * D * 8 + n_prot * Nt * 8
+        st = hold["r"]["stats"].cpu().numpy()
+        legs[name] = {"kernel": capi.kernel_name(hold["r"]["desc"]), "trajectories": B, "n_out": Nt, "kernel_ms": ms,
+                      "trajectories_per_s": B / ms * 1e3, "bound": "hbm", "achieved": nbytes / ms / 1e6, "peak": PEAK_HBM_GBS,
+                      "unit": "GB/s", "frac": nbytes / ms / 1e6 / PEAK_HBM_GBS, "mean_nfe": float(st[:, 2].mean()),
+                      "ok": int((hold["r"]["status"] == 0).sum().item())}
+        del params, y0t, o, hold
+        torch.cuda.empty_cache()
+    legs["note"] = ("fp64-VALU-issue bound, not HBM bound: ~5000 vector instructions per step attempt and 64-trajectory wavefront "
+                    "(profiles/r02_closed_form.md: SQ_ACTIVE_INST_VALU vs SQ_WAIT_ANY, and the no-store / no-emission timing experiments)")
+    return legs
+
+
+def gradient_leg(ion, dev, weights):
+    """BASELINE.json configs[4]: gradient through the solve, one GPU's share (1024 of 8192 trajectories), fp32 state."""
+    capi, P = ion.capi, ion.protocols
+    B, Nt = 1024, 100001
+    pv = P.sinewave(P.sinewave_scales(0, B), n_samples=Nt, xp=torch, device=dev)
+    te = torch.arange(Nt, dtype=torch.float64, device=dev) * 0.1
+    vobs = pv + 86.0
+    times = []
+    for rep in range(2):
+        w = torch.from_numpy(weights.copy()).to(dev).requires_grad_(True)
+        params = torch.from_numpy(np.tile(P_HH, (B, 1))).to(dev)
+        y0 = torch.tensor([[0.0, 1.0]], dtype=torch.float32, device=dev).repeat(B, 1)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        y, status = ion.grad.solve(capi.MODEL_NNF, w, params, pv, y0, te, mlp_layers=MLP_L, mlp_width=MLP_N, prot_t0=0.0,
+                                   prot_dt=0.1, t_eval_hint=(0.0, 0.1))
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        ((y[..., 0] * y[..., 1]).double() * vobs).abs().mean().backward()   # mean |i - 0| (train-s1.py:329)
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        times.append((t1 - t0, t2 - t1))
+        gnorm = float(w.grad.double().norm())
+        del y
+    fwd, bwd = times[-1]
+    return {"workload": "configs[4]: dL/dW through odeint, NN-f s00, 1024 trajectories (1/8 of the 8192-trajectory batch), "
+                        "fp32 state, sine-wave protocols, N_t = N_p = 100001", "forward_with_checkpoints_s": fwd, "backward_s": bwd,
+            "trajectories_per_s_fwd_bwd": B / (fwd + bwd), "grad_w_norm": gnorm, "ok": int((status == 0).sum().item())}
+
+
+def regression_leg(ion, dev, weights):
+    """one iteration of the reference's MLP regression loop (train-s1.py:891-909) at its real size."""
+    import importlib as _il
+    reg = _il.import_module("neural-ode-ion-channels_amd.regression")
+    rows, iters = 132410, 30
+    rng = np.random.default_rng(0)
+    x = np.stack([rng.uniform(-1.3, 0.7, rows), rng.uniform(0.01, 0.99, rows)], 1).astype(np.float32)
+    y = rng.normal(0, 1e-3, rows).astype(np.float32)
+    r = reg.MlpRegression(weights, MLP_L, MLP_N, x, y, device=dev)
+    for _ in range(3):
+        r.step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(iters):
+        r.step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    flops = 3 * 2 * rows * (MLP_L * MLP_N * MLP_N + 3 * MLP_N)
+    return {"workload": f"MLP regression step, {rows} rows, net 2->200x5->1, fp32 (synthetic rows)", "ms_per_iteration": dt * 1e3,
+            "bound": "mfma", "achieved": flops / dt / 1e12, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+            "frac": flops / dt / 1e12 / PEAK_FP32_TFLOPS}
 
 
 def self_launch(n):

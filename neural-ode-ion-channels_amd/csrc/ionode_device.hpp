@@ -771,10 +771,12 @@ __global__ void __launch_bounds__(64 * G, IONODE_CF_WAVES(MODEL, G)) ionode_dopr
   // behind all of them: waves sat in s_waitcnt 82 % of the time (SQ_WAIT_ANY, profiles/r02_closed_form.md).  Here
   //   * output times are formed arithmetically (te_exact), the next attempt's protocol lookups are issued and consumed BEFORE
   //     the emission, so the emission is LDS reads + VALU + stores only and nothing waits on a store;
-  //   * stores are whole 128-byte lines inside 1 KiB-aligned blocks of the row: samples behind the last line boundary wait in
-  //     an LDS tail buffer (< 8 samples per trajectory) for the next step -- no partial-line write, no read-for-ownership.
+  //   * stores are whole 64-byte sectors inside 1 KiB-aligned blocks of the row: samples behind the last sector boundary wait
+  //     in an LDS tail buffer (< 4 samples per trajectory in fp64) for the next step -- no partial-sector write, no
+  //     read-for-ownership.  (64 B, not the 128-B line: 8 KiB of LDS per wavefront instead of 14 keeps 12 wavefronts per CU.)
   constexpr bool CF2 = !MT::MLP && D == 2;
-  constexpr int LS = 128 / (D * (int)sizeof(S));                     // samples per 128-byte line (D == 2: 8 or 16)
+  constexpr int LS = 64 / (D * (int)sizeof(S));                      // samples per 64-byte sector, the unit of an L2 -> HBM
+                                                                     // write request (TCC_EA0_WRREQ_64B): D == 2: 4 or 8
   constexpr int TAILB = (((LS - 1) * D * (int)sizeof(S)) + 15) & ~15;  // bytes of one trajectory's tail buffer
   constexpr int ROWB = (4 + 5 * D) * 8;
   // compile-time variant (template parameter TAIL == 1 of a closed-form kernel); the dispatcher selects it only when

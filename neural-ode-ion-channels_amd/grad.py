@@ -89,7 +89,7 @@ class _Solve(torch.autograd.Function):
             r = capi.dopri5(cfg["model"], params.detach(), cfg["prot_v"], y0.detach(), cfg["t_eval"], mlp_packed=packed,
                             mlp_layers=L, mlp_width=N, prot_t=cfg.get("prot_t"), prot_t0=cfg["prot_t0"], prot_dt=cfg["prot_dt"],
                             prot_of_traj=cfg.get("prot_of_traj"), rtol=cfg["rtol"], atol=cfg["atol"], v_oob=cfg["v_oob"],
-                            max_steps=cfg["max_steps"], max_total_steps=cfg["max_total_steps"], ckpt=ckpt,
+                            max_steps=cfg["max_steps"], max_total_steps=cfg["max_total_steps"], max_step=cfg.get("max_step", 0.0), ckpt=ckpt,
                             t_eval_hint=cfg.get("t_eval_hint", "auto"))
             nacc = r["stats"][:, 0]
             most = int(nacc.max().item())
@@ -150,11 +150,17 @@ class _Solve(torch.autograd.Function):
 
 
 def solve(model, weights_flat, params, prot_v, y0, t_eval, *, mlp_layers, mlp_width, prot_t=None, prot_t0=0.0,
-          prot_dt=1.0, prot_of_traj=None, rtol=1e-7, atol=1e-9, v_oob=-80.0, max_steps=0, max_total_steps=0,
+          prot_dt=1.0, prot_of_traj=None, rtol=1e-7, atol=1e-9, v_oob=-80.0, max_steps=0, max_total_steps=0, max_step=0.0,
           ckpt_cap=None, record_budget_bytes=None, weights_key=None, t_eval_hint="auto"):
     """Differentiable batched solve.  weights_flat [n] fp32 (reference state-dict order), params [B, 8] fp64, y0 [B, 2]
     fp32 | fp64 (the state dtype) -- device tensors, any of which may require grad; prot_v [P, Np], t_eval [Nt] fp64 device
-    tensors.  Returns (y [B, Nt, 2], status [B]): gradients of failed trajectories (status != 0) are zero."""
+    tensors.  Returns (y [B, Nt, 2], status [B]): gradients of failed trajectories (status != 0) are zero.
+
+    max_step (ms, extension; 0 = off = the reference's dopri5): at an equilibrium dopri5 lets dt grow until h*lambda is far
+    outside its stability region (the error estimate of a state AT equilibrium is ~0); the forward solve copes through
+    rejections, but the exact derivative of those accepted-but-unstable steps multiplies the adjoint by |R(h*lambda)| >> 1
+    per step (measured on the 10 s sine-wave protocol, fp32 state: |dL/dp| ~ 1e36 while dL/dW, whose state `a` is not
+    stiff, stays O(100)).  max_step < 3.3 / lambda_max -- 10 ms for the reference's rate constants -- keeps it bounded."""
     if model not in (capi.MODEL_NNF, capi.MODEL_NND):
         raise NotImplementedError("gradients through the solve are built for the NN-f / NN-d right-hand sides")
     if not (isinstance(y0, torch.Tensor) and y0.is_cuda):
@@ -162,7 +168,7 @@ def solve(model, weights_flat, params, prot_v, y0, t_eval, *, mlp_layers, mlp_wi
     cfg = dict(model=model, mlp_layers=int(mlp_layers), mlp_width=int(mlp_width), prot_v=prot_v, prot_t=prot_t,
                prot_t0=float(prot_t0), prot_dt=float(prot_dt), prot_of_traj=prot_of_traj, t_eval=t_eval, rtol=float(rtol),
                atol=float(atol), v_oob=float(v_oob), max_steps=int(max_steps), max_total_steps=int(max_total_steps),
-               ckpt_cap=ckpt_cap, record_budget_bytes=record_budget_bytes, weights_key=weights_key, t_eval_hint=t_eval_hint)
+               max_step=float(max_step), ckpt_cap=ckpt_cap, record_budget_bytes=record_budget_bytes, weights_key=weights_key, t_eval_hint=t_eval_hint)
     return _Solve.apply(weights_flat, params, y0.contiguous(), cfg)
 
 

@@ -28,7 +28,7 @@ import torch
 from . import batched, capi, grad, rhs
 from .generic import generic_dopri5
 
-_KNOWN_OPTIONS = {"allow_generic", "explicit_protocol", "max_num_steps", "max_total_steps", "tile_waves",
+_KNOWN_OPTIONS = {"allow_generic", "explicit_protocol", "max_num_steps", "max_total_steps", "max_step", "tile_waves",
                   # torchdiffeq 0.1.x-era keys the reference passes in train-d0.py:436; 0.2.x warns and ignores them
                   "grid_points", "eps"}
 
@@ -70,7 +70,8 @@ def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, even
                         weights_key=spec.weights_key, prot_t=spec.prot_t, prot_t0=spec.prot_t0, prot_dt=spec.prot_dt,
                         state_dtype=y0.dtype, rtol=float(rtol), atol=float(atol),
                         max_steps=int(options.get("max_num_steps", 0)),
-                        max_total_steps=int(options.get("max_total_steps", 0)), prot_key=spec.prot_key, t_eval_key=t_key,
+                        max_total_steps=int(options.get("max_total_steps", 0)), max_step=float(options.get("max_step", 0.0)),
+                        prot_key=spec.prot_key, t_eval_key=t_key,
                         tile_waves=int(options.get("tile_waves", 0)))
     sol.raise_on_failure()
     out = sol.y[0].reshape((t.numel(),) + tuple(y0.shape))
@@ -114,7 +115,7 @@ def _odeint_with_grad(func, y0, t, spec, rtol, atol, options):
                            prot_t=batched._to(spec.prot_t, torch.float64, dev, key=(spec.prot_key, "t")),
                            prot_t0=spec.prot_t0, prot_dt=spec.prot_dt, rtol=float(rtol), atol=float(atol),
                            max_steps=int(options.get("max_num_steps", 0)), max_total_steps=int(options.get("max_total_steps", 0)),
-                           weights_key=spec.weights_key)
+                           max_step=float(options.get("max_step", 0.0)), weights_key=spec.weights_key)
     st = int(status[0].item())
     if st != 0:
         raise AssertionError(capi.STATUS_TEXT[st])

@@ -200,3 +200,24 @@ def test_bench_gpus_2_self_launches_two_ranks(ion, gpu):
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 128 and res["config"]["trajectories_ok"] == 64
     assert res["scaling"] == "weak" and res["value"] > 0
+
+
+def test_max_step_extension_matches_the_oracle_and_is_off_by_default(ion, gpu, oracle):
+    """ionode_desc.max_step (a cap on dt; torchdiffeq 0.2.1's dopri5 has none): bit for bit the oracle's capped solve, more
+    steps than the uncapped one, and 0 leaves the reference behaviour untouched."""
+    pv = K.activation(40)[1]
+    te = K.activation(0)[2][:4001]
+    kw = dict(prot_t0=0.0, prot_dt=1.0)
+    w = K.load_weights("s1")
+    o0 = oracle.solve(K.MODEL_NNF, K.P_HH, pv, K.NN_Y0, te, weights=w, mlp_layers=5, mlp_width=200, **kw)
+    for cap in (0.0, 5.0):
+        g = run_gpu(ion, gpu, K.MODEL_NNF, K.P_HH, pv, K.NN_Y0, te, weights=w, L=5, N=200, max_step=cap, **kw)
+        o = oracle.solve(K.MODEL_NNF, K.P_HH, pv, K.NN_Y0, te, weights=w, mlp_layers=5, mlp_width=200, max_step=cap, **kw)
+        assert np.array_equal(g["y"], o["y"]) and np.array_equal(g["stats"], o["stats"])
+        if cap == 0.0:
+            assert np.array_equal(g["y"], o0["y"])
+        else:
+            assert g["stats"][0, 0] > o0["stats"][0, 0] and g["stats"][0, 0] >= 800  # 4000 ms / 5 ms
+    gh = run_gpu(ion, gpu, K.MODEL_HH2, K.P_HH, pv, [0.0, 1.0], te, max_step=5.0, **kw)
+    oh = oracle.solve(K.MODEL_HH2, K.P_HH, pv, [0.0, 1.0], te, max_step=5.0, **kw)
+    assert np.array_equal(gh["y"], oh["y"]) and np.array_equal(gh["stats"], oh["stats"])

@@ -26,6 +26,7 @@ ap.add_argument("--f64", action="store_true")
 ap.add_argument("--budget-gb", type=float, default=24.0)
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--model", default="s1", choices=["s1", "d2"])
+ap.add_argument("--max-step", type=float, default=0.0, help="ms; 0 = off (the reference's dopri5)")
 a = ap.parse_args()
 
 ion = importlib.import_module("neural-ode-ion-channels_amd")
@@ -49,7 +50,7 @@ for rep in range(a.reps + 1):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     y, status = ion.grad.solve(model, w, params, pv, y0, te, mlp_layers=5, mlp_width=200, prot_t0=0.0, prot_dt=0.1,
-                               t_eval_hint=(0.0, 0.1), record_budget_bytes=int(a.budget_gb * (1 << 30)))
+                               t_eval_hint=(0.0, 0.1), record_budget_bytes=int(a.budget_gb * (1 << 30)), max_step=a.max_step)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     loss = ((y[..., 0] * y[..., 1]).double() * vobs - i_ref).abs().mean()
@@ -65,4 +66,4 @@ print(json.dumps({"workload": f"configs[4]: gradient through odeint, NN-f s00, {
                               f"{'fp64' if a.f64 else 'fp32'} state, N_t = N_p = {Nt}", "batch": B,
                   "forward_with_checkpoints_s": fwd, "backward_s": bwd, "traj_per_s_fwd_bwd": B / (fwd + bwd),
                   "ok": int((status == 0).sum()), "grad_w_norm": gnorm, "grad_p_norm": float(params.grad.norm()),
-                  "record_budget_gb": a.budget_gb}))
+                  "record_budget_gb": a.budget_gb, "max_step_ms": a.max_step}))
