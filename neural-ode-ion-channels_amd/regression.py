@@ -130,5 +130,12 @@ class MlpRegression:
                 out.append((itr, lr, float(loss.item())))
         return out
 
+    def load_adam_state(self, exp_avg, exp_avg_sq, step):
+        """Resume: Adam moments in flat state-dict order (preprocess.adam_state_to_flat of a reference checkpoint's
+        'optimizer' entry) and the number of optimiser steps taken (also StepLR's epoch)."""
+        self.m.copy_(torch.as_tensor(np.asarray(exp_avg, dtype=np.float32)).to(self.dev))
+        self.v.copy_(torch.as_tensor(np.asarray(exp_avg_sq, dtype=np.float32)).to(self.dev))
+        self.t = int(step)
+
     def state_dict_flat(self):
         return self.w.detach().cpu().numpy().copy()

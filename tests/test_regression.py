@@ -137,3 +137,43 @@ def test_hip_training_steps_follow_torch_adam_steplr(ion, gpu):
     wt = _flat(net)
     assert np.linalg.norm(r.state_dict_flat() - wt) / np.linalg.norm(wt) <= FIT_RTOL
     assert abs(r.lr() - opt.param_groups[0]["lr"]) < 1e-12
+
+
+@pytest.mark.gpu
+def test_resume_from_a_reference_style_checkpoint(ion, gpu, tmp_path):
+    """Checkpoint compatibility both ways (train-r1.py:61-72): 6 torch iterations -> checkpoint {epoch, state_dict,
+    optimizer, loss} -> the HIP trainer resumes from the file for 6 more -> same curve as torch continuing; and the HIP
+    trainer's own checkpoint loads into torch.optim.Adam."""
+    reg = __import__("importlib").import_module("neural-ode-ion-channels_amd.regression")
+    pp = __import__("importlib").import_module("neural-ode-ion-channels_amd.preprocess")
+    torch.set_num_threads(8)
+    x, y, off = _data("d2")
+    x, y, off = x[::4], y[::4], off[::4]
+    w0 = (K.load_weights("d2") * (1.0 + 0.02 * np.random.default_rng(6).standard_normal(201801))).astype(np.float32)
+    net = _net(w0)
+    opt = torch.optim.Adam(net.parameters(), lr=0.001)
+    sch = torch.optim.lr_scheduler.StepLR(opt, step_size=4, gamma=0.9)
+
+    def torch_steps(k):
+        out = []
+        for _ in range(k):
+            loss = _torch_loss(net, x, y, off)
+            opt.zero_grad(); loss.backward(); opt.step(); sch.step()
+            out.append(loss.item())
+        return out
+    torch_steps(6)
+    path = str(tmp_path / "checkpoint-2.pt")
+    torch.save({"epoch": 6, "state_dict": {"net." + k: v for k, v in net.state_dict().items()}, "optimizer": opt.state_dict(),
+                "loss": 0.0}, path)                                     # what save_ckp writes (train-r1.py:61-66)
+    ck = pp.load_checkpoint(path)
+    r = reg.MlpRegression(ck["flat"], ck["mlp_layers"], ck["mlp_width"], x, y, off, step_size=4, gamma=0.9, device=gpu)
+    m, v, step, lr = pp.adam_state_to_flat(ck["optimizer"])
+    r.load_adam_state(m, v, step)
+    assert step == 6 and abs(r.lr() - lr) < 1e-12
+    got = [float(r.step().item()) for _ in range(6)]
+    want = torch_steps(6)
+    assert np.max(np.abs(np.array(got) - want) / np.array(want)) <= FIT_RTOL
+    # and back: the HIP trainer's state as a torch Adam state dict
+    opt2 = torch.optim.Adam(_net(r.state_dict_flat()).parameters(), lr=0.001)
+    opt2.load_state_dict(pp.adam_state_from_regression(r))
+    assert int(float(opt2.state_dict()["state"][0]["step"])) == 12
