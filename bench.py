@@ -197,16 +197,17 @@ def main():
                          "frac": gbs / PEAK_HBM_GBS, "bytes_per_trajectory": bytes_traj},
     }
 
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    pmc = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
     if os.path.exists(pmc) and B == 4096 and Nt == 100001:
         # HBM bytes per launch from the rocprofv3 --pmc passes of this same command (profiles/README.md): FETCH_SIZE is
         # doubled (gfx950 counts 128-B requests as 64 B), WRITE_SIZE is exact; both are reported in KiB
         try:
             pj = json.load(open(pmc))
-            traffic = (2 * pj["r01_pmc2"]["FETCH_SIZE"] + pj["r01_pmc3"]["WRITE_SIZE"]) * 1024
+            kname = "void ionode::" + capi.kernel_name(r["desc"]) + "(ionode::KArgs)"
+            traffic = (2 * pj["pmc2"][kname]["FETCH_SIZE"] + pj["pmc3"][kname]["WRITE_SIZE"]) * 1024
             for key in ("roofline", "roofline_hbm"):
                 res[key]["traffic"] = traffic
-                res[key]["traffic_source"] = ("HBM bytes per launch, profiles/r01_pmc_summary.json (separate rocprofv3 --pmc "
+                res[key]["traffic_source"] = ("HBM bytes per launch, profiles/r02_pmc_summary.json (separate rocprofv3 --pmc "
                                               "passes of this command; FETCH_SIZE x2 per the gfx950 note, WRITE_SIZE exact)")
         except (KeyError, ValueError):
             pass

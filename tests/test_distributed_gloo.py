@@ -149,3 +149,44 @@ def test_population_objective_all_gather_of_unequal_shards(oracle):
         assert p.exitcode == 0
     for r in (0, 1):  # every rank holds every candidate's value, in candidate order, identical to the 1-rank result
         assert np.array_equal(np.asarray(got[r]), want)
+
+
+# ---- grad.allreduce_gradients: one bucketed all-reduce of the weight gradient (config 5's collective) ---------------
+
+def _grad_worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    dist_mod = importlib.import_module("neural-ode-ion-channels_amd.distributed")
+    grad = importlib.import_module("neural-ode-ion-channels_amd.grad")
+    d = dist_mod.init_process_group()
+    g = torch.Generator().manual_seed(100 + rank)
+    tensors = [torch.randn(201801, generator=g), torch.randn(3, 8, dtype=torch.float64, generator=g)]
+    out = grad.allreduce_gradients(tensors)
+    q.put((rank, [t.double().sum().item() for t in out], [str(t.dtype) for t in out]))
+    d.barrier()
+    d.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_gradient_all_reduce_is_one_bucket_sum():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {r: (s, dt) for r, s, dt in (q.get(timeout=240) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = [0.0, 0.0]
+    for r in range(2):
+        g = torch.Generator().manual_seed(100 + r)
+        a, b = torch.randn(201801, generator=g), torch.randn(3, 8, dtype=torch.float64, generator=g)
+        want[0] += a.double().sum().item(); want[1] += b.sum().item()
+    for r in (0, 1):
+        assert got[r][1] == ["torch.float32", "torch.float64"]        # dtypes preserved
+        assert abs(got[r][0][0] - want[0]) < 1e-2 and abs(got[r][0][1] - want[1]) < 1e-9
