@@ -822,7 +822,10 @@ __global__ void __launch_bounds__(64 * G, IONODE_CF_WAVES(MODEL, G)) ionode_dopr
       inst[i] = protocol_v(a, pv, (double)ti, vst[i]);
     }
   };
-  constexpr bool CARRY_V = !MT::MLP && D == 2;  // (the 6-state kernel has no registers to spare for it: +50 % time when tried)
+#ifndef IONODE_CARRY_V_MLP
+#define IONODE_CARRY_V_MLP 0  // tried for the MLP kernels too: +1 % time (372.6 -> 376.2 ms same box), kept off
+#endif
+  constexpr bool CARRY_V = (!MT::MLP && D == 2) || (MT::MLP && IONODE_CARRY_V_MLP);  // (the 6-state kernel has no registers to spare for it: +50 % time when tried)
   if constexpr (CARRY_V) lookup_stages(t, dt);
 
   for (;;) {
