@@ -132,10 +132,12 @@ struct GradMlp {
     for (int kt = 0; kt < NT; ++kt) {
       const f32x4 b = B[kt * 64 + lane];
       const int slot = kt % PD;
+      // k-step outer, row tile inner: consecutive MFMAs go to DIFFERENT accumulators (a 16x16x4 fp32 MFMA issues every 32
+      // cycles but its result is ready after 40: four in a row on one accumulator run at the dependent rate)
 #pragma unroll
-      for (int i = 0; i < RT; ++i)
+      for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[slot][i][r], b[r], acc[i], 0, 0, 0);
+        for (int i = 0; i < RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[slot][i][r], b[r], acc[i], 0, 0, 0);
       const int nk = kt + PD;
 #pragma unroll
       for (int i = 0; i < RT; ++i)

@@ -152,15 +152,16 @@ __global__ void __launch_bounds__(256) ionode_grad_reduce_kernel(const float *__
 #pragma unroll
     for (int ct = 0; ct < NT; ++ct) {
       const f32x4 b = Hb[ct * 64 + lane];
+      // trajectory group c outer, row tile inner: consecutive MFMAs on different accumulators (issue 32 cycles, result 40)
 #pragma unroll
-      for (int i = 0; i < F; ++i)
+      for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[i][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][c], b[c], acc[i][ct], 0, 0, 0);
+        for (int i = 0; i < F; ++i) acc[i][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][c], b[c], acc[i][ct], 0, 0, 0);
       if (R > 0 && (ct & 3) == wave) {  // wave-uniform: this wavefront's column tiles of the remainder row tiles
 #pragma unroll
-        for (int j = 0; j < R; ++j)
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
-          for (int c = 0; c < 4; ++c) accr[j][ct / 4] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[j][c], b[c], accr[j][ct / 4], 0, 0, 0);
+          for (int j = 0; j < R; ++j) accr[j][ct / 4] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[j][c], b[c], accr[j][ct / 4], 0, 0, 0);
       }
     }
     if (more) {
