@@ -127,3 +127,65 @@ def test_unsupported_gradient_requests_raise(ion, gpu):
     truth.set_fixed_form_voltage_protocol(*K.activation(20)[:2])
     with pytest.raises(NotImplementedError, match="closed-form"):
         odeint(truth, torch.tensor([[0.0, 1.0]], requires_grad=True), torch.linspace(0.0, 100.0, 11))
+
+
+def _rand_weights(L, N, seed):
+    rng = np.random.default_rng(seed)  # gain ~1 per layer so that deep stacks stay O(1): sigma = 1 / sqrt(N), capped
+    return rng.normal(0, min(0.3, 1.0 / np.sqrt(N)), 2 * N + N + L * (N * N + N) + N + 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("L,N,model", [(2, 10, K.MODEL_NNF), (10, 10, K.MODEL_NND), (3, 100, K.MODEL_NND), (10, 100, K.MODEL_NNF),
+                                       (1, 200, K.MODEL_NNF)])
+def test_other_widths_and_depths_against_the_checker(ion, gpu, oracle, L, N, model):
+    """The NT = 1 (N = 10) and NT = 7 (N = 100) instantiations of the sweep / reduce kernels and other depths of the N = 200
+    one (architectures s01, s03-s05, s09-s11), ragged batch (19 trajectories = 2 tiles), explicit protocol time grid, one
+    trajectory that fails (NaN start: zero gradient) -- the checker (tests/grad_check.py) is evaluated in the test."""
+    import grad_check as G
+    w = _rand_weights(L, N, 11 * L + N)
+    rng = np.random.default_rng(L + N)
+    B = 19
+    pv = np.stack([K.atau(30)[1][900:1300], K.atau(100)[1][900:1300]])
+    pt = np.arange(400, dtype=np.float64) * 1.0
+    pt[1:] += rng.uniform(-1e-7, 1e-7, 399)                  # not uniform in bits: the explicit-grid lookup
+    te = np.arange(0.0, 140.0, 1.0)
+    params = np.tile(K.P_HH, (B, 1)) * rng.uniform(0.9, 1.1, (B, 8))
+    pot = (np.arange(B) % 2).astype(np.int32)
+    y0 = np.stack([rng.uniform(0.0, 0.3, B), rng.uniform(0.6, 1.0, B)], 1)
+    y0[5, 0] = np.nan
+    coef = rng.normal(size=(B, te.size, 2))
+    wt = torch.from_numpy(w.copy()).to(gpu).requires_grad_(True)
+    p = torch.from_numpy(params).to(gpu).requires_grad_(True)
+    y0t = torch.from_numpy(y0).to(gpu).requires_grad_(True)
+    y, status = ion.grad.solve(model, wt, p, torch.from_numpy(pv).to(gpu), y0t, torch.from_numpy(te).to(gpu), mlp_layers=L,
+                               mlp_width=N, prot_t=torch.from_numpy(pt).to(gpu), prot_of_traj=torch.from_numpy(pot).to(gpu))
+    st = status.cpu().numpy()
+    assert st[5] != 0 and (np.delete(st, 5) == 0).all()
+    ok = torch.from_numpy(st == 0).to(gpu)
+    (torch.nan_to_num(y) * torch.from_numpy(coef).to(gpu) * ok[:, None, None]).sum().backward()
+    gw, gp, gy0 = wt.grad.double().cpu().numpy(), p.grad.cpu().numpy(), y0t.grad.cpu().numpy()
+    assert np.all(gp[5] == 0) and np.all(gy0[5] == 0)         # the failed trajectory contributes nothing
+    # checker: three of the healthy trajectories (dL/dp, dL/dy0 per trajectory; dL/dW needs all of them)
+    flat = torch.from_numpy(w.copy()).requires_grad_(True)
+    torch.set_num_threads(8)
+    for b in [b for b in range(B) if b != 5]:
+        o = oracle.solve(model, params[b], pv[pot[b]], y0[b], te, weights=w, mlp_layers=L, mlp_width=N, prot_t=pt, step_log_cap=8192)
+        assert np.array_equal(y[b].detach().cpu().numpy(), o["y"][0])
+        pb = torch.tensor(params[b], dtype=torch.float64, requires_grad=True)
+        yb = torch.tensor(y0[b], dtype=torch.float64, requires_grad=True)
+        yr = G.replay(model, flat, L, N, pb, yb, pt, pv[pot[b]], te, G.accepted_steps(o["step_log"]))
+        (yr * torch.from_numpy(coef[b])).sum().backward()
+        cols = slice(4, 8) if model == K.MODEL_NNF else slice(0, 8)
+        assert _rel(gp[b, cols], pb.grad.numpy()[cols]) <= GRAD_REL_TOL and _rel(gy0[b], yb.grad.numpy()) <= GRAD_REL_TOL
+    e = _rel(gw, flat.grad.double().numpy())
+    print(f"L={L} N={N}: dL/dW rel-L2 vs checker {e:.2e}")
+    assert e <= GRAD_REL_TOL
+
+
+def test_gradient_of_unsupported_shapes_is_refused(ion, gpu):
+    w = torch.from_numpy(_rand_weights(5, 500, 1)).to(gpu).requires_grad_(True)   # s06: activations exceed one CU's LDS
+    pv = torch.zeros((1, 100), dtype=torch.float64, device=gpu) - 80.0
+    with pytest.raises(ion.IonodeError, match="LDS|variants"):
+        y, _ = ion.grad.solve(K.MODEL_NNF, w, torch.from_numpy(K.P_HH[None]).to(gpu), pv,
+                              torch.tensor([[0.0, 1.0]], dtype=torch.float64, device=gpu),
+                              torch.arange(10, dtype=torch.float64, device=gpu), mlp_layers=5, mlp_width=500)
+        y.sum().backward()

@@ -177,3 +177,52 @@ def test_resume_from_a_reference_style_checkpoint(ion, gpu, tmp_path):
     opt2 = torch.optim.Adam(_net(r.state_dict_flat()).parameters(), lr=0.001)
     opt2.load_state_dict(pp.adam_state_from_regression(r))
     assert int(float(opt2.state_dict()["state"][0]["step"])) == 12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L,N", [(5, 10), (1, 100), (10, 100), (1, 200)])
+def test_other_architectures_against_torch(ion, gpu, L, N):
+    """The N = 10 (NT = 1) and N = 100 (NT = 7) instantiations of the regression / reduce kernels and other depths, rows not
+    a multiple of 16, with and without the closed-form offset: loss + gradient + 5 Adam steps against torch."""
+    reg = __import__("importlib").import_module("neural-ode-ion-channels_amd.regression")
+    torch.set_num_threads(8)
+    rng = np.random.default_rng(L * 1000 + N)
+    M = 5003
+    x = np.stack([rng.uniform(-1.3, 0.7, M), rng.uniform(0.01, 0.99, M)], 1).astype(np.float32)
+    y = rng.normal(0, 1e-3, M).astype(np.float32)
+    off = rng.normal(0, 1e-3, M).astype(np.float32) if N == 100 else None
+    parts = []
+    for (o, i) in [(N, 2)] + [(N, N)] * L + [(1, N)]:
+        parts += [rng.normal(0, 0.3, o * i).astype(np.float32), rng.normal(0, 0.1, o).astype(np.float32)]
+    w = np.concatenate(parts)
+
+    def mk():
+        layers = [nn.Linear(2, N), nn.LeakyReLU()]
+        for _ in range(L):
+            layers += [nn.Linear(N, N), nn.LeakyReLU()]
+        net = nn.Sequential(*layers, nn.Linear(N, 1))
+        o = 0
+        with torch.no_grad():
+            for m in net:
+                if isinstance(m, nn.Linear):
+                    n = m.weight.numel()
+                    m.weight.copy_(torch.from_numpy(w[o:o + n].reshape(m.weight.shape))); o += n
+                    m.bias.copy_(torch.from_numpy(w[o:o + m.bias.numel()])); o += m.bias.numel()
+        return net
+    net = mk()
+    r = reg.MlpRegression(w, L, N, x, y, off, device=gpu)
+    loss, g = r.loss_and_grad()
+    ref = _torch_loss(net, x, y, off)
+    ref.backward()
+    gref = np.concatenate([np.concatenate([m.weight.grad.numpy().ravel(), m.bias.grad.numpy().ravel()])
+                           for m in net if isinstance(m, nn.Linear)])
+    assert abs(loss.item() - ref.item()) <= 2e-6 * ref.item()
+    assert np.linalg.norm(g.cpu().numpy() - gref) / np.linalg.norm(gref) <= GRAD_RTOL
+    net = mk()
+    opt = torch.optim.Adam(net.parameters(), lr=0.001)
+    for _ in range(5):
+        l_t = _torch_loss(net, x, y, off)
+        opt.zero_grad(); l_t.backward(); opt.step()
+        l_g = r.step()
+        assert abs(l_g.item() - l_t.item()) <= FIT_RTOL * l_t.item()
+    assert np.linalg.norm(r.state_dict_flat() - _flat(net)) / np.linalg.norm(_flat(net)) <= FIT_RTOL
