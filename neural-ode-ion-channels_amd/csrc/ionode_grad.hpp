@@ -49,7 +49,7 @@ constexpr int GRAD_STATE = 12;
 // floats of one tile-evaluation record: H_0..H_L, D_0..D_L (NT tiles of 64 lanes x float4 each) + 64 scalars (x0, x1, seed, pad) x 16
 __host__ __device__ constexpr int64_t grad_record_floats(int L, int NT) { return (int64_t)2 * (L + 1) * NT * 256 + 64; }
 __host__ __device__ constexpr size_t grad_lds_bytes(int L, int NT) {
-  return ((size_t)(L + 3) * NT * 64 + 16 * NT) * 16 + ((size_t)L * 16 * NT + 16 * NT + 4) * 4 + 16 * 10 * 8;
+  return ((size_t)(L + 3) * NT * 64 + (size_t)2 * (NT % 4) * 4 * 64 + 16 * NT) * 16 + ((size_t)L * 16 * NT + 16 * NT + 4) * 4 + 16 * 10 * 8;
 }
 // image offsets (floats): rows of layer 0 {b0, w00, w01, 0} | hidden biases | wl, bl | forward fragments | transposed fragments
 __host__ __device__ constexpr size_t grad_img_bias(int NT) { return (size_t)4 * 16 * NT; }
@@ -61,16 +61,25 @@ __host__ __device__ constexpr size_t grad_img_floats(int L, int NT) { return gra
 template <int NT>
 struct GradMlp {
   static constexpr int G = 4;
-  static constexpr int RT = (NT + G - 1) / G;  // row tiles per wavefront (rt = wave + 4i)
+  static constexpr int F = NT / G;                // full row tiles per wavefront (rt = wave + 4i, every k-tile)
+  static constexpr int R = NT - G * F;            // remainder row tiles (rt = 4F + j): their k-tiles are dealt over the wavefronts
+  static constexpr int NOWN = (NT + G - 1) / G;   // k-tiles of a remainder tile one wavefront owns (kt = wave + 4u)
+  static constexpr int FP = F > 0 ? F : 1, RP = R > 0 ? R : 1;
   static constexpr int NP = 16 * NT;
+  // Work split as in the forward kernel: every wavefront runs F full row tiles over all NT k-tiles and a 1/4 K-slice of each
+  // remainder row tile (partial sums meet in LDS, every wavefront folds them itself behind the layer barrier): 172 MFMAs per
+  // product on every wavefront for N = 200 instead of 208 on wavefront 0.  Wavefront w walks the k-tiles in the rotated order
+  // kt = (s + w) mod NT so that "this step carries my K-slice" is the static predicate s % 4 == 0 (and s + w < NT).
+  //
   // Weight fragments are consumed from a register ring one product deep that runs AHEAD of the MFMAs across product boundaries
   // (forward layers 0..L-1, transposed layers L-1..0, then the next evaluation's layer 0): a fragment is re-loaded right behind
   // the MFMAs that read it, so an L2 round trip (~1 us under load, ~5 k-tiles of MFMA time) is covered.  Without the ring every
   // k-tile waited for its own loads: 18 us per product instead of the 6.7k-cycle MFMA floor (measured).
-  static constexpr int PD = NT;  // a whole product ahead (slot = k-tile: the ring phase is the same for every product)
-  f32x4 ring[PD][(NT + 3) / 4];
+  f32x4 ringF[NT][FP];
+  f32x4 ringR[NOWN][RP];
   f32x4 *Hs;          // LDS [L+1][NT*64]   activations after LeakyReLU, accumulator layout
   f32x4 *Ds;          // LDS [2][NT*64]     pre-activation gradients, ping-pong over layers
+  f32x4 *Ps;          // LDS [2][R][G][64]  partial sums of the remainder row tiles, ping-pong over products
   const f32x4 *W0s;   // LDS [NP] {b0, w00, w01, 0}
   const float *biasS; // LDS [L][NP]
   const float *wlS;   // LDS [NP] + bl
@@ -82,7 +91,8 @@ struct GradMlp {
     L = a.k.L; wave = wave_; lane = lane_;
     Hs = reinterpret_cast<f32x4 *>(smem);
     Ds = Hs + (size_t)(L + 1) * NT * 64;
-    f32x4 *w0 = Ds + 2 * NT * 64;
+    Ps = Ds + 2 * NT * 64;
+    f32x4 *w0 = Ps + 2 * R * G * 64;
     float *bs = reinterpret_cast<float *>(w0 + NP);
     float *ws = bs + (size_t)L * NP;
     const int tid = wave * 64 + lane;
@@ -94,15 +104,21 @@ struct GradMlp {
     rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.img), 0, (int)(grad_img_floats(L, NT) * 4), 0x00020000);
     fwd0 = (unsigned)(grad_img_fwd(L, NT) * 4);
     bwd0 = (unsigned)(grad_img_bwd(L, NT) * 4);
-#pragma unroll
-    for (int u = 0; u < PD; ++u)
-#pragma unroll
-      for (int i = 0; i < RT; ++i) ring[u][i] = frag(fwd0, 0, row_tile(i), u);  // prime: first product of the first evaluation
+    refill_all(fwd0, 0);  // prime: first product of the first evaluation
     __syncthreads();
   }
-  // row tile i of this wavefront; slots past the last tile re-use it (their MFMAs run into a discarded accumulator: the
-  // stream stays branch-free, and wavefront 0 -- the one with RT real tiles -- sets the pace anyway)
-  __device__ __forceinline__ int row_tile(int i) const { const int rt = wave + i * G; return rt < NT ? rt : NT - 1; }
+  __device__ __forceinline__ int ktile(int s) const { return (s + wave) % NT; }  // wave-uniform (scalar ALU)
+  __device__ __forceinline__ int own_kt(int u) const { const int k = wave + G * u; return k < NT ? k : NT - 1; }  // clamped: never read past the layer
+  __device__ __forceinline__ void refill_all(unsigned sec, int l) {
+#pragma unroll
+    for (int s = 0; s < NT; ++s)
+#pragma unroll
+      for (int i = 0; i < F; ++i) ringF[s][i] = frag(sec, l, wave + G * i, ktile(s));
+#pragma unroll
+    for (int u = 0; u < NOWN; ++u)
+#pragma unroll
+      for (int j = 0; j < R; ++j) ringR[u][j] = frag(sec, l, G * F + j, own_kt(u));
+  }
   __device__ __forceinline__ double *gs() const {  // LDS [16][10] fp64 scratch behind the small vectors (8-byte aligned)
     return reinterpret_cast<double *>(const_cast<float *>(wlS) + NP + 4);
   }
@@ -124,26 +140,43 @@ struct GradMlp {
     __builtin_nontemporal_store(v[2], p + 8); __builtin_nontemporal_store(v[3], p + 12);
   }
 
-  // acc[i] (+)= A(sec, l)[row tile wave + 4i][:] . B[:]   over all NT k-tiles; B read from LDS in accumulator layout.
-  // (nsec, nl): the product that follows this one -- its first PD k-tiles are loaded behind this product's last MFMAs.
-  __device__ __forceinline__ void product(unsigned sec, int l, unsigned nsec, int nl, const f32x4 *__restrict__ B,
-                                          f32x4 (&acc)[RT]) {
+  // accF[i] += A(sec, l)[row tile wave + 4i][:] . B[:] over all k-tiles; accR[j] += the owned K-slice of remainder tile j.
+  // B is read from LDS in accumulator layout.  (nsec, nl): the product that follows -- its fragments replace this one's
+  // right behind the MFMAs that read them.
+  __device__ __forceinline__ void product(unsigned nsec, int nl, const f32x4 *__restrict__ B, f32x4 (&accF)[FP], f32x4 (&accR)[RP]) {
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt) {
+    for (int s = 0; s < NT; ++s) {
+      const int kt = ktile(s);
       const f32x4 b = B[kt * 64 + lane];
-      const int slot = kt % PD;
-      // k-step outer, row tile inner: consecutive MFMAs go to DIFFERENT accumulators (a 16x16x4 fp32 MFMA issues every 32
-      // cycles but its result is ready after 40: four in a row on one accumulator run at the dependent rate)
+      // k-step outer, row tile inner: consecutive MFMAs go to different accumulators (issue every 32 cycles, result after 40)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int i = 0; i < RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[slot][i][r], b[r], acc[i], 0, 0, 0);
-      const int nk = kt + PD;
+        for (int i = 0; i < F; ++i) accF[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ringF[s][i][r], b[r], accF[i], 0, 0, 0);
+      if (R > 0 && s % G == 0) {
+        if (s + G - 1 < NT || s + wave < NT) {  // static for every step but the last owned one (wave-uniform there)
 #pragma unroll
-      for (int i = 0; i < RT; ++i)
-        ring[slot][i] = (nk < NT) ? frag(sec, l, row_tile(i), nk) : frag(nsec, nl, row_tile(i), nk - NT);
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < R; ++j) accR[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ringR[s / G][j][r], b[r], accR[j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) ringR[s / G][j] = frag(nsec, nl, G * F + j, own_kt(s / G));
+      }
+#pragma unroll
+      for (int i = 0; i < F; ++i) ringF[s][i] = frag(nsec, nl, wave + G * i, kt);
       __builtin_amdgcn_sched_barrier(0);  // keep the refills here (hipcc otherwise sinks them behind the product)
     }
+  }
+
+  // fold the four K-slices of remainder tile j (fixed tree)
+  __device__ __forceinline__ f32x4 fold(const f32x4 *__restrict__ P, int j) const {
+    const f32x4 p0 = P[(j * G + 0) * 64 + lane], p1 = P[(j * G + 1) * 64 + lane];
+    const f32x4 p2 = P[(j * G + 2) * 64 + lane], p3 = P[(j * G + 3) * 64 + lane];
+    f32x4 z;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) z[r] = (p0[r] + p1[r]) + (p2[r] + p3[r]);
+    return z;
   }
 
   // One vector-Jacobian product of the net for the 16 trajectories of the tile, all four wavefronts together.
@@ -160,9 +193,11 @@ struct GradMlp {
     const int q = lane >> 4;
     f32x4 *__restrict__ recH = reinterpret_cast<f32x4 *>(rec);
     f32x4 *__restrict__ recD = recH + (size_t)(L + 1) * NT * 64;
-    // ---- forward recompute, every layer's activations stay in LDS ----
+    constexpr int pstride = R * G * 64;
+    int par = 0;  // partial-sum buffer of the running product
+    // ---- forward recompute, every layer's activations stay in LDS.  Layer 0: row tile rt by wavefront rt % 4 ----
 #pragma unroll
-    for (int i = 0; i < RT; ++i) {
+    for (int i = 0; i < (NT + G - 1) / G; ++i) {
       const int rt = wave + i * G;
       if (rt < NT) {
         f32x4 h;
@@ -177,25 +212,39 @@ struct GradMlp {
     }
     __syncthreads();
     for (int l = 1; l <= L; ++l) {
-      f32x4 acc[RT];
+      f32x4 accF[FP], accR[RP];
 #pragma unroll
-      for (int i = 0; i < RT; ++i) {
-        const int rt = wave + i * G;
-        acc[i] = (rt < NT) ? *reinterpret_cast<const f32x4 *>(biasS + (l - 1) * NP + 16 * rt + 4 * q) : f32x4{0, 0, 0, 0};
+      for (int i = 0; i < F; ++i) accF[i] = *reinterpret_cast<const f32x4 *>(biasS + (l - 1) * NP + 16 * (wave + G * i) + 4 * q);
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const f32x4 bz = *reinterpret_cast<const f32x4 *>(biasS + (l - 1) * NP + 16 * (G * F + j) + 4 * q);
+        accR[j] = (wave == 0) ? bz : f32x4{0, 0, 0, 0};  // partial sum 0 carries the bias
       }
-      product(fwd0, l - 1, l < L ? fwd0 : bwd0, l < L ? l : L - 1, Hs + (size_t)(l - 1) * NT * 64, acc);
+      product(l < L ? fwd0 : bwd0, l < L ? l : L - 1, Hs + (size_t)(l - 1) * NT * 64, accF, accR);
 #pragma unroll
-      for (int i = 0; i < RT; ++i) {
-        const int rt = wave + i * G;
-        if (rt < NT) {
-          f32x4 h;
+      for (int i = 0; i < F; ++i) {
+        const int rt = wave + G * i;
+        f32x4 h;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) h[r] = lrelu(acc[i][r]);
-          Hs[((size_t)l * NT + rt) * 64 + lane] = h;
-          if (rec) rec_store(recH + ((size_t)l * NT + rt) * 64, h);
-        }
+        for (int r = 0; r < 4; ++r) h[r] = lrelu(accF[i][r]);
+        Hs[((size_t)l * NT + rt) * 64 + lane] = h;
+        if (rec) rec_store(recH + ((size_t)l * NT + rt) * 64, h);
       }
+#pragma unroll
+      for (int j = 0; j < R; ++j) Ps[par * pstride + (j * G + wave) * 64 + lane] = accR[j];
       __syncthreads();
+      // every wavefront folds the remainder tiles itself and writes the (identical) activations into the layer's slot:
+      // each reads them back only after its own write, so no second barrier; wavefront 0 also streams the record
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const f32x4 z = fold(Ps + par * pstride, j);
+        f32x4 h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = lrelu(z[r]);
+        Hs[((size_t)l * NT + G * F + j) * 64 + lane] = h;
+        if (rec && wave == 0) rec_store(recH + ((size_t)l * NT + G * F + j) * 64, h);
+      }
+      par ^= 1;
     }
     // ---- net = wl . h_L + bl (four partial chains, one per lane group, as the forward kernel's last layer), then the seed ----
     float seed;
@@ -213,7 +262,7 @@ struct GradMlp {
     }
     // ---- backward: d_L = seed * wl * lrelu'(h_L); d_{l-1} = (W_l^T d_l) * lrelu'(h_{l-1}) ----
 #pragma unroll
-    for (int i = 0; i < RT; ++i) {
+    for (int i = 0; i < (NT + G - 1) / G; ++i) {
       const int rt = wave + i * G;
       if (rt < NT) {
         const f32x4 h = Hs[((size_t)L * NT + rt) * 64 + lane];
@@ -227,23 +276,36 @@ struct GradMlp {
     }
     __syncthreads();
     for (int l = L; l >= 1; --l) {
-      f32x4 acc[RT];
+      f32x4 accF[FP], accR[RP];
 #pragma unroll
-      for (int i = 0; i < RT; ++i) acc[i] = f32x4{0, 0, 0, 0};
-      product(bwd0, l - 1, l > 1 ? bwd0 : fwd0, l > 1 ? l - 2 : 0, Ds + (size_t)(l & 1) * NT * 64, acc);
+      for (int i = 0; i < F; ++i) accF[i] = f32x4{0, 0, 0, 0};
 #pragma unroll
-      for (int i = 0; i < RT; ++i) {
-        const int rt = wave + i * G;
-        if (rt < NT) {
-          const f32x4 h = Hs[((size_t)(l - 1) * NT + rt) * 64 + lane];
-          f32x4 d;
+      for (int j = 0; j < R; ++j) accR[j] = f32x4{0, 0, 0, 0};
+      product(l > 1 ? bwd0 : fwd0, l > 1 ? l - 2 : 0, Ds + (size_t)(l & 1) * NT * 64, accF, accR);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) d[r] = acc[i][r] * (h[r] > 0.0f ? 1.0f : 0.01f);
-          Ds[(((l - 1) & 1) * NT + rt) * 64 + lane] = d;
-          if (rec) rec_store(recD + ((size_t)(l - 1) * NT + rt) * 64, d);
-        }
+      for (int i = 0; i < F; ++i) {
+        const int rt = wave + G * i;
+        const f32x4 h = Hs[((size_t)(l - 1) * NT + rt) * 64 + lane];
+        f32x4 d;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[r] = accF[i][r] * (h[r] > 0.0f ? 1.0f : 0.01f);
+        Ds[(((l - 1) & 1) * NT + rt) * 64 + lane] = d;
+        if (rec) rec_store(recD + ((size_t)(l - 1) * NT + rt) * 64, d);
       }
+#pragma unroll
+      for (int j = 0; j < R; ++j) Ps[par * pstride + (j * G + wave) * 64 + lane] = accR[j];
       __syncthreads();
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const f32x4 z = fold(Ps + par * pstride, j);
+        const f32x4 h = Hs[((size_t)(l - 1) * NT + G * F + j) * 64 + lane];
+        f32x4 d;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[r] = z[r] * (h[r] > 0.0f ? 1.0f : 0.01f);
+        Ds[(((l - 1) & 1) * NT + G * F + j) * 64 + lane] = d;
+        if (rec && wave == 0) rec_store(recD + ((size_t)(l - 1) * NT + G * F + j) * 64, d);
+      }
+      par ^= 1;
     }
     // ---- d net / d x1 = sum_k W0[k][1] d_0[k]  (x0 is the voltage: a constant of the differentiation) ----
     float part = 0.0f;

@@ -126,25 +126,46 @@ class _Solve(torch.autograd.Function):
         budget = int(cfg.get("record_budget_bytes") or DEFAULT_RECORD_BUDGET)
         chunk = n_iter if not need_w else max(1, min(n_iter, budget // (tiles * 6 * recf * 4)))
         acc = torch.zeros(partf, dtype=torch.float64, device=dev) if need_w else None
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        records = torch.empty(tiles * chunk * 6 * recf, dtype=torch.float32, device=dev) if need_w else None
+        main = torch.cuda.current_stream(dev)
+        stream = main.cuda_stream
+        # Two record buffers and a side stream: the reduction of chunk k (whole chip, HBM-bound) runs beside the sweep of chunk
+        # k + 1 (one workgroup per 16-trajectory tile: 64 of 256 CUs at config 5's per-GPU batch).
+        n_chunks = (n_iter + chunk - 1) // chunk
+        n_buf = 2 if (need_w and n_chunks > 1) else 1
+        if need_w and n_buf == 2:
+            chunk = max(1, min(n_iter, (budget // 2) // (tiles * 6 * recf * 4)))
+        records = [torch.empty(tiles * chunk * 6 * recf, dtype=torch.float32, device=dev) for _ in range(n_buf)] if need_w else [None]
+        side = torch.cuda.Stream(dev) if n_buf == 2 else main
+        free = [None] * n_buf   # event: the reduce that last read this buffer has finished
         desc.ckpt, desc.ckpt_cap = ckpt.data_ptr(), ckpt.shape[1]
-        for it0 in range(0, n_iter, chunk):
+        for k, it0 in enumerate(range(0, n_iter, chunk)):
             it1 = min(n_iter, it0 + chunk)
+            rec = records[k % n_buf]
+            if free[k % n_buf] is not None:
+                main.wait_event(free[k % n_buf])
             rc = lib.ionode_dopri5_backward(C.byref(desc), it0, it1, n_iter, _ptr(image), _ptr(params), _ptr(cfg["prot_v"]),
                                             _ptr(cfg.get("prot_t")), _ptr(cfg.get("prot_of_traj")), _ptr(cfg["t_eval"]),
-                                            _ptr(n_acc), _ptr(gy), _ptr(state), _ptr(records), _ptr(g_params), _ptr(g_y0),
+                                            _ptr(n_acc), _ptr(gy), _ptr(state), _ptr(rec), _ptr(g_params), _ptr(g_y0),
                                             C.c_void_p(stream))
             if rc != 0:
                 raise capi.IonodeError(f"ionode_dopri5_backward failed ({rc}): {lib.ionode_grad_last_error().decode()}")
             if need_w:
                 n_rec = tiles * (it1 - it0) * 6
                 n_slabs = int(max(1, min(256 // (L + 2), n_rec // 4)))
-                partials = torch.empty((n_slabs, partf), dtype=torch.float32, device=dev)
-                rc = lib.ionode_grad_reduce(L, N, _ptr(records), n_rec, n_slabs, _ptr(partials), C.c_void_p(stream))
-                if rc != 0:
-                    raise capi.IonodeError(f"ionode_grad_reduce failed ({rc}): {lib.ionode_grad_last_error().decode()}")
-                acc += partials.double().sum(0)
+                swept = torch.cuda.Event()
+                swept.record(main)
+                side.wait_event(swept)
+                with torch.cuda.stream(side):
+                    partials = torch.empty((n_slabs, partf), dtype=torch.float32, device=dev)
+                    rc = lib.ionode_grad_reduce(L, N, _ptr(rec), n_rec, n_slabs, _ptr(partials), C.c_void_p(side.cuda_stream))
+                    if rc != 0:
+                        raise capi.IonodeError(f"ionode_grad_reduce failed ({rc}): {lib.ionode_grad_last_error().decode()}")
+                    acc += partials.double().sum(0)
+                    done = torch.cuda.Event()
+                    done.record(side)
+                free[k % n_buf] = done
+        if need_w and side is not main:
+            main.wait_stream(side)
         g_w = unpack_partial(acc, L, N).to(torch.float32) if need_w else None
         return g_w, (g_params if ctx.needs_input_grad[1] else None), (g_y0.to(sdt) if ctx.needs_input_grad[2] else None), None
 
