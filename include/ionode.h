@@ -93,6 +93,13 @@ typedef struct ionode_desc {
   int32_t t_eval_exact; /* 1: the caller has VERIFIED t_eval[k] == t_eval_t0_hint + (double)k * t_eval_dt_hint bit for bit (fp64
                           multiply, then add) for every k.  The closed-form kernels then form output times arithmetically and
                           take their store-friendly emission path; results are identical either way.  0 = not verified */
+  const double *sse_ref; /* fused objective (PINTS SumOfSquaresError over Model.simulate, train-d0.py:415-439, :508-540), optional:
+                          DEVICE [n_prot][n_out] reference currents.  With sse_out set, every trajectory's
+                          sum_k (i_k - sse_ref[protocol][k])^2 (i as in the i_out epilogue) is accumulated in the kernel and
+                          written to sse_out[b] (inf where the solve failed -- the reference's time-limit rule); y_out and i_out
+                          may then be NULL, so that no trace leaves the chip: BASELINE configs[3]'s 65 536 candidates x 32
+                          sweeps x 1e5 samples would be 4.5 TB of traces.  Needs the output-grid hint. */
+  double *sse_out;     /* DEVICE [n_traj] fp64 or NULL */
   double max_step;     /* EXTENSION (torchdiffeq 0.2.1's dopri5 has no such option; 0 = off = reference behaviour): cap on the
                           step size in ms.  At an equilibrium dopri5 grows dt until h*lambda leaves its stability region
                           (the error estimate of a state AT equilibrium is ~0); the forward solve copes through rejections,
@@ -120,7 +127,7 @@ int ionode_mlp_pack(const float *state_dict_flat, int32_t mlp_layers, int32_t ml
  *   prot_of_traj  device, [B] int32 protocol index per trajectory, or NULL (trajectory b uses b % P)
  *   y0            device, [B][D] in the state dtype
  *   t_eval        device, [n_out] fp64, strictly increasing; t_eval[0] is the initial time
- *   y_out         device, [B][n_out][D] in the state dtype
+ *   y_out         device, [B][n_out][D] in the state dtype (may be NULL when d->sse_out is set)
  *   i_out         device, [B][n_out] fp64 current trace, or NULL
  *   status        device, [B] int32 IONODE_STATUS_*
  *   stats         device, [B][4] int64 {accepted steps, rejected steps, RHS evaluations, status}, or NULL

@@ -63,6 +63,7 @@ class Solution:
     status: torch.Tensor            # [B] int32
     stats: Optional[torch.Tensor]   # [B, 4] int64: accepted, rejected, nfe, status
     kernel: str
+    sse: Optional[torch.Tensor] = None  # [B] fp64 fused sum of squared current residuals (sse_ref given), inf where failed
 
     def raise_on_failure(self):
         st = self.status.cpu().numpy()
@@ -76,7 +77,8 @@ class Solution:
 def solve(model, params, prot_v, y0, t_eval, *, weights=None, mlp_layers=0, mlp_width=0, weights_key=None,
           prot_t=None, prot_t0=0.0, prot_dt=1.0, prot_of_traj=None, state_dtype=None, rtol=1e-7, atol=1e-9,
           v_oob=-80.0, max_steps=0, max_total_steps=0, max_step=0.0, current=False, obs_g=1.0, obs_e=-86.0, obs_open_state_only=False,
-          tile_waves=0, device=None, step_log=None, t_eval_hint="auto", prot_key=None, t_eval_key=None) -> Solution:
+          tile_waves=0, device=None, step_log=None, t_eval_hint="auto", prot_key=None, t_eval_key=None, sse_ref=None,
+          states=True) -> Solution:
     """Integrate B trajectories on the GPU (asynchronous on the current stream).
 
     params [B, 8|12] (or [8|12] -> B = 1), prot_v [P, Np] (or [Np]), y0 [B, D] / [D] (broadcast over B),
@@ -121,5 +123,5 @@ def solve(model, params, prot_v, y0, t_eval, *, weights=None, mlp_layers=0, mlp_
                     prot_of_traj=_to(prot_of_traj, torch.int32, dev), rtol=rtol, atol=atol, v_oob=v_oob,
                     max_steps=max_steps, max_total_steps=max_total_steps, max_step=max_step, current=current, obs_g=obs_g, obs_e=obs_e,
                     obs_open_state_only=obs_open_state_only, tile_waves=tile_waves, step_log=step_log,
-                    t_eval_hint=t_eval_hint, t_eval_exact=t_eval_exact)
-    return Solution(y=r["y"], i=r["i"], status=r["status"], stats=r["stats"], kernel=capi.kernel_name(r["desc"]))
+                    t_eval_hint=t_eval_hint, t_eval_exact=t_eval_exact, sse_ref=_to(sse_ref, torch.float64, dev), states=states)
+    return Solution(y=r["y"], i=r["i"], status=r["status"], stats=r["stats"], kernel=capi.kernel_name(r["desc"]), sse=r["sse"])

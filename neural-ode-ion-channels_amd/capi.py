@@ -43,7 +43,7 @@ class IonodeDesc(C.Structure):
         ("step_log", C.c_void_p), ("step_log_cap", C.c_int64),
         ("t_eval_t0_hint", C.c_double), ("t_eval_dt_hint", C.c_double),
         ("max_total_steps", C.c_int64), ("ckpt", C.c_void_p), ("ckpt_cap", C.c_int32), ("t_eval_exact", C.c_int32),
-        ("max_step", C.c_double),
+        ("sse_ref", C.c_void_p), ("sse_out", C.c_void_p), ("max_step", C.c_double),
     ]
 
 
@@ -159,7 +159,7 @@ def _dev_ptr(t, dtype, name, shape=None):
 def dopri5(model, params, prot_v, y0, t_eval, *, mlp_packed=None, mlp_layers=0, mlp_width=0, prot_t=None,
            prot_t0=0.0, prot_dt=1.0, prot_of_traj=None, rtol=1e-7, atol=1e-9, v_oob=-80.0, max_steps=0,
            max_total_steps=0, max_step=0.0, ckpt=None, current=False, obs_g=1.0, obs_e=-86.0, obs_open_state_only=False, tile_waves=0, stats=True,
-           step_log=None, t_eval_hint="auto", t_eval_exact=None, out=None, stream=None):
+           step_log=None, t_eval_hint="auto", t_eval_exact=None, sse_ref=None, states=True, out=None, stream=None):
     """Launch one batched solve.  Every tensor lives on the current HIP device.
 
     params [B, n_params] f64, prot_v [P, Np] f64, y0 [B, D] f32|f64 (selects the state dtype),
@@ -210,8 +210,17 @@ def dopri5(model, params, prot_v, y0, t_eval, *, mlp_packed=None, mlp_layers=0, 
     if out is None:
         out = {}
     y = out.get("y")
-    if y is None:
+    if y is None and states:
         y = torch.empty((B, Nt, D), dtype=sdt, device=dev)
+    sse = None
+    if sse_ref is not None:  # fused objective: [P, Nt] reference currents -> per-trajectory sum of squared residuals
+        _dev_ptr(sse_ref, torch.float64, "sse_ref", (P, Nt))
+        sse = out.get("sse")
+        if sse is None:
+            sse = torch.empty((B,), dtype=torch.float64, device=dev)
+        desc.sse_ref, desc.sse_out = sse_ref.data_ptr(), sse.data_ptr()
+    elif not states:
+        raise IonodeError("states=False needs sse_ref (something must be computed)")
     i_out = out.get("i")
     if current and i_out is None:
         i_out = torch.empty((B, Nt), dtype=torch.float64, device=dev)
@@ -231,7 +240,7 @@ def dopri5(model, params, prot_v, y0, t_eval, *, mlp_packed=None, mlp_layers=0, 
         _dev_ptr(prot_of_traj, torch.int32, "prot_of_traj", (B,)) if prot_of_traj is not None else None,
         _dev_ptr(y0, sdt, "y0"),
         _dev_ptr(t_eval, torch.float64, "t_eval"),
-        _dev_ptr(y, sdt, "y_out", (B, Nt, D)),
+        _dev_ptr(y, sdt, "y_out", (B, Nt, D)) if y is not None else None,
         _dev_ptr(i_out, torch.float64, "i_out", (B, Nt)) if i_out is not None else None,
         _dev_ptr(status, torch.int32, "status", (B,)),
         _dev_ptr(st, torch.int64, "stats", (B, 4)) if st is not None else None,
@@ -239,4 +248,4 @@ def dopri5(model, params, prot_v, y0, t_eval, *, mlp_packed=None, mlp_layers=0, 
     )
     if rc != 0:
         raise IonodeError(f"ionode_dopri5 failed ({rc}): {last_error()}")
-    return {"y": y, "i": i_out, "status": status, "stats": st, "desc": desc}
+    return {"y": y, "i": i_out, "status": status, "stats": st, "sse": sse, "desc": desc}

@@ -184,11 +184,15 @@ int ionode_dopri5(const ionode_desc *d, const float *mlp_packed, const double *p
                   const double *prot_t, const int32_t *prot_of_traj, const void *y0, const double *t_eval,
                   void *y_out, double *i_out, int32_t *status, int64_t *stats, void *stream) {
   Plan pl;
-  const int rc = make_plan(d, &pl, i_out != nullptr);
+  const int rc = make_plan(d, &pl, i_out != nullptr || d->sse_out != nullptr);
   if (rc != IONODE_OK) return rc;
   const bool mlp = d->model == IONODE_MODEL_NNF || d->model == IONODE_MODEL_NND;
-  if (!params || !prot_v || !y0 || !t_eval || !y_out || !status || (mlp && !mlp_packed)) {
+  if (!params || !prot_v || !y0 || !t_eval || (!y_out && !d->sse_out) || !status || (mlp && !mlp_packed)) {
     set_err("ionode_dopri5: required buffer is NULL");
+    return IONODE_ERR_ARG;
+  }
+  if (d->sse_out && (!d->sse_ref || !(d->t_eval_dt_hint > 0.0) || d->n_out < 2)) {
+    set_err("fused objective: sse_out needs sse_ref and the output-grid hint (t_eval_dt_hint > 0)");
     return IONODE_ERR_ARG;
   }
   ionode::KArgs a;
@@ -207,6 +211,7 @@ int ionode_dopri5(const ionode_desc *d, const float *mlp_packed, const double *p
   a.prot_t0 = d->prot_t0; a.prot_dt = d->prot_dt; a.v_oob = d->v_oob; a.rtol = d->rtol; a.atol = d->atol;
   a.obs_g = d->obs_g; a.obs_e = d->obs_e; a.obs_open = d->obs_open_state_only;
   a.step_log = d->step_log; a.step_log_cap = d->step_log ? d->step_log_cap : 0;
+  a.sse_ref = d->sse_ref; a.sse_out = d->sse_out;
   a.te_t0 = d->t_eval_t0_hint; a.te_dt = (d->t_eval_dt_hint > 0.0 && d->n_out > 1) ? d->t_eval_dt_hint : 0.0;
   a.te_rdt = a.te_dt > 0.0 ? 1.0 / a.te_dt : 0.0;
   a.te_exact = (a.te_dt > 0.0 && d->t_eval_exact) ? 1 : 0;

@@ -59,6 +59,8 @@ struct KArgs {
   int32_t obs_open;
   double *step_log;
   int64_t step_log_cap;
+  const double *sse_ref;  // fused objective (hint path): reference currents [P][Nt]; per trajectory sum_k (i_k - ref[prot][k])^2 ...
+  double *sse_out;        // ... goes to sse_out[B] (inf for failed trajectories); y_out / i_out may then be NULL: no trace leaves the chip
   double te_t0, te_dt;  // hint: t_eval[k] ~ te_t0 + k*te_dt (te_dt <= 0: no hint).  Only ever a guess; see emit.
   double te_rdt;        // 1 / te_dt (for the guess only)
   int32_t te_exact;     // 1: the caller VERIFIED t_eval[k] == te_t0 + (double)k * te_dt bit for bit (fp64 multiply, then add):
@@ -791,8 +793,9 @@ __global__ void __launch_bounds__(64 * G, IONODE_CF_WAVES(MODEL, G)) ionode_dopr
   auto te_at = [&](int idx) -> double { return a.te_t0 + (double)idx * a.te_dt; };
 
   // solution[0] = y0  (deferred emission: it waits in the tail buffer for its line)
+  double sse = 0.0;  // fused objective: this lane's trajectory (accumulated by the owner wavefront's replica lanes)
   if (valid && primary && !(CF2 && defer)) {
-    store_state<S, D>(yout, y);
+    if (a.y_out) store_state<S, D>(yout, y);
     if (iout) {
       double v0;
       protocol_v(a, pv, t, v0);
@@ -801,6 +804,15 @@ __global__ void __launch_bounds__(64 * G, IONODE_CF_WAVES(MODEL, G)) ionode_dopr
       if (a.obs_g != 1.0) gate = (S)a.obs_g * gate;
       iout[0] = (double)gate * (v0 - a.obs_e);
     }
+  }
+  if (a.sse_out != nullptr && valid) {
+    double v0;
+    protocol_v(a, pv, t, v0);
+    S gate;
+    if (a.obs_open) gate = y[D - 1]; else gate = y[0] * y[1];
+    if (a.obs_g != 1.0) gate = (S)a.obs_g * gate;
+    const double r0 = (double)gate * (v0 - a.obs_e) - a.sse_ref[(size_t)pidx * Nt];
+    sse = r0 * r0;
   }
 
   int oi = 1;  // next output index
@@ -852,9 +864,11 @@ __global__ void __launch_bounds__(64 * G, IONODE_CF_WAVES(MODEL, G)) ionode_dopr
           const int o0 = __builtin_amdgcn_readlane(oi, jj);
           const int tr = __builtin_amdgcn_readlane(traj, jj);
           S *__restrict__ yo = reinterpret_cast<S *>(a.y_out) + (size_t)tr * Nt * D;
-          for (int idx = o0 + lane; idx < Nt; idx += 64) {
+          for (int idx = o0 + lane; idx < Nt && (a.y_out || a.i_out); idx += 64) {
+            if (a.y_out) {
 #pragma unroll
-            for (int d = 0; d < D; ++d) yo[(size_t)idx * D + d] = nan_s;
+              for (int d = 0; d < D; ++d) yo[(size_t)idx * D + d] = nan_s;
+            }
             if (a.i_out) a.i_out[(size_t)tr * Nt + idx] = __builtin_nan("");
           }
         }
@@ -1086,14 +1100,16 @@ __global__ void __launch_bounds__(64 * G, IONODE_CF_WAVES(MODEL, G)) ionode_dopr
             for (int d = 0; d < D; ++d) cb[c][d] = bcast<S>(ic[c][d], jj);
         }
         const int tr = __builtin_amdgcn_readlane(traj, jj);
-        S *__restrict__ yo = reinterpret_cast<S *>(a.y_out) + (size_t)tr * Nt * D;
+        S *__restrict__ yo = a.y_out ? reinterpret_cast<S *>(a.y_out) + (size_t)tr * Nt * D : nullptr;
         double *__restrict__ io = nullptr;
-        const double *__restrict__ pvb = nullptr;
-        if (a.i_out) {
-          io = a.i_out + (size_t)tr * Nt;
+        const double *__restrict__ pvb = nullptr, *__restrict__ refb = nullptr;
+        if (a.i_out || a.sse_out) {
+          if (a.i_out) io = a.i_out + (size_t)tr * Nt;
           const int pj = a.prot_of_traj ? a.prot_of_traj[tr] : (tr % a.P);
           pvb = a.prot_v + (size_t)pj * a.Np;
+          if (a.sse_out) refb = a.sse_ref + (size_t)pj * Nt;
         }
+        double sacc = 0.0;
         for (int c0 = 0; c0 < n; c0 += 64) {
           const int idx = o + c0 + lane;
           if (c0 > 0 && c0 + lane < n) tk = a.t_eval[idx];
@@ -1109,16 +1125,23 @@ __global__ void __launch_bounds__(64 * G, IONODE_CF_WAVES(MODEL, G)) ionode_dopr
 #pragma unroll
               for (int d = 0; d < D; ++d) out[d] = out[d] + xp * cb[c][d];
             }
-            store_state<S, D>(yo + (size_t)idx * D, out);
-            if (io) {
+            if (yo) store_state<S, D>(yo + (size_t)idx * D, out);
+            if (pvb) {
               double vk;
               protocol_v(a, pvb, tk, vk);
               S gate;
               if (a.obs_open) gate = out[D - 1]; else gate = out[0] * out[1];
               if (a.obs_g != 1.0) gate = (S)a.obs_g * gate;
-              io[idx] = (double)gate * (vk - a.obs_e);
+              const double ik = (double)gate * (vk - a.obs_e);
+              if (io) io[idx] = ik;
+              if (refb) { const double rr = ik - refb[idx]; sacc += rr * rr; }
             }
           }
+        }
+        if (a.sse_out) {  // fused objective: the step's squared residuals of trajectory jj, summed over the wavefront
+#pragma unroll
+          for (int msk = 32; msk >= 1; msk >>= 1) sacc += __shfl_xor(sacc, msk);
+          if (j == jj) sse += sacc;
         }
         jj = jn;
         o = on;
@@ -1231,6 +1254,8 @@ __global__ void __launch_bounds__(64 * G, IONODE_CF_WAVES(MODEL, G)) ionode_dopr
   if (blockIdx.x == 0 && threadIdx.x == 0 && a.step_log != nullptr && a.step_log_cap >= 4)
     for (int i_ = 0; i_ < 16; ++i_) a.step_log[i_] = (double)stamps_.acc[i_];
 #endif
+  if (a.sse_out != nullptr && valid && lane < TPW && (G == 1 || (lane % G) == wave))
+    a.sse_out[traj] = (status == IONODE_STATUS_OK) ? sse : __builtin_inf();  // the reference's time-limit rule: inf (train-d0.py:430-431)
   if (valid && primary) {
     a.status[traj] = status;
     if (a.stats) {

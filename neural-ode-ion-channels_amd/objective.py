@@ -16,13 +16,16 @@ from . import batched, capi, distributed
 
 def population_sum_of_squares(candidates, protocols_v, data_i, t_eval, *, base_params, free=(0, 1, 2, 3), prot_t0=0.0,
                               prot_dt=0.1, y0=(0.0, 1.0), state_dtype=torch.float32, obs_g=1.0, obs_e=-86.0,
-                              max_total_steps=1_000_000, group=None, device=None, solver=None):
+                              max_total_steps=1_000_000, group=None, device=None, solver=None, fused=True):
     """Sum-of-squares error of every candidate over all protocols (PINTS SumOfSquaresError on a multi-output problem).
 
     candidates  [C, len(free)]  values of the free rate parameters (train-d0.py: p1..p4 -> free = (0, 1, 2, 3))
     protocols_v [P, Np] mV;  data_i [P, Nt] measured currents;  t_eval [Nt] ms;  base_params [8]
     Returns a [C] fp64 tensor on the device: inf where any of a candidate's solves failed (the reference's time-limit
     rule).  Under torch.distributed the candidates are sharded over the ranks and the result is all-gathered.
+    fused (default): the squared residuals are accumulated inside the kernel (ionode_desc.sse_ref / sse_out) and neither states
+    nor current traces are written -- the only way BASELINE configs[3] fits (65 536 candidates x 32 sweeps x 1e5 samples would be
+    4.5 TB of traces); fused=False stores the traces and reduces them with torch (same values to ~1e-13, for tests).
     `solver` (tests only): a stand-in with batched.solve's signature, so the sharding / all-gather logic can run under
     gloo on a box without a GPU; the product default is the HIP solve and there is no CPU fallback.
     """
@@ -40,11 +43,17 @@ def population_sum_of_squares(candidates, protocols_v, data_i, t_eval, *, base_p
         params[:, list(free)] = cand[lo:hi]
         params = np.repeat(params, P, axis=0)                       # candidate-major: trajectory = c*P + p
         pot = np.tile(np.arange(P, dtype=np.int32), hi - lo)
-        sol = solve(capi.MODEL_HH2, params, protocols_v, torch.tensor([list(y0)], dtype=state_dtype), t_eval,
-                            prot_t0=prot_t0, prot_dt=prot_dt, prot_of_traj=pot, current=True, obs_g=obs_g, obs_e=obs_e,
-                            max_total_steps=max_total_steps, device=dev)
         ref = torch.as_tensor(np.asarray(data_i), dtype=torch.float64, device=dev)     # [P, Nt]
-        err = ((sol.i.reshape(hi - lo, P, -1) - ref[None]) ** 2).sum(dim=(1, 2))
+        if fused and solver is None:
+            sol = solve(capi.MODEL_HH2, params, protocols_v, torch.tensor([list(y0)], dtype=state_dtype), t_eval,
+                        prot_t0=prot_t0, prot_dt=prot_dt, prot_of_traj=pot, obs_g=obs_g, obs_e=obs_e,
+                        max_total_steps=max_total_steps, device=dev, sse_ref=ref.contiguous(), states=False)
+            err = sol.sse.reshape(hi - lo, P).sum(dim=1)      # failed solves are inf already
+        else:
+            sol = solve(capi.MODEL_HH2, params, protocols_v, torch.tensor([list(y0)], dtype=state_dtype), t_eval,
+                        prot_t0=prot_t0, prot_dt=prot_dt, prot_of_traj=pot, current=True, obs_g=obs_g, obs_e=obs_e,
+                        max_total_steps=max_total_steps, device=dev)
+            err = ((sol.i.reshape(hi - lo, P, -1) - ref[None]) ** 2).sum(dim=(1, 2))
         ok = (sol.status.reshape(hi - lo, P) == 0).all(dim=1)
         sse = torch.where(ok, err, torch.full_like(err, float("inf")))
     if world == 1:

@@ -75,6 +75,10 @@ def test_population_objective_matches_reference_semantics(ion, gpu, oracle):
     cand = K.P_NN_D[None, :4] * 10.0 ** rng.uniform(-0.5, 0.5, (12, 4))
     cand[5] = [np.nan, 1, 1, 1]  # a broken candidate
     got = obj.population_sum_of_squares(cand, pv, data, te, base_params=K.P_NN_D, prot_t0=0.0, prot_dt=1.0).cpu().numpy()
+    unfused = obj.population_sum_of_squares(cand, pv, data, te, base_params=K.P_NN_D, prot_t0=0.0, prot_dt=1.0,
+                                            fused=False).cpu().numpy()
+    fin = np.isfinite(unfused)
+    assert np.array_equal(fin, np.isfinite(got)) and np.allclose(got[fin], unfused[fin], rtol=1e-12, atol=0)
     for c in range(12):
         p = K.P_NN_D.copy()
         p[:4] = cand[c]

@@ -221,3 +221,46 @@ def test_max_step_extension_matches_the_oracle_and_is_off_by_default(ion, gpu, o
     gh = run_gpu(ion, gpu, K.MODEL_HH2, K.P_HH, pv, [0.0, 1.0], te, max_step=5.0, **kw)
     oh = oracle.solve(K.MODEL_HH2, K.P_HH, pv, [0.0, 1.0], te, max_step=5.0, **kw)
     assert np.array_equal(gh["y"], oh["y"]) and np.array_equal(gh["stats"], oh["stats"])
+
+
+@pytest.mark.parametrize("model,f32", [(K.MODEL_HH2, True), (K.MODEL_HH2, False), (K.MODEL_NNF, False), (K.MODEL_MARKOV6, True)])
+def test_fused_sum_of_squares_epilogue(ion, gpu, model, f32):
+    """ionode_desc.sse_ref / sse_out: per-trajectory sum_k (i_k - ref[protocol][k])^2 accumulated in the kernel, with and
+    without the traces being written, equals the same sum over the stored current trace; failed trajectories give inf."""
+    rng = np.random.default_rng(17)
+    B = 37
+    pv = np.stack([K.activation(v)[1] for v in (-20, 20, 60)])
+    te = K.activation(0)[2][:3001]
+    pot = (np.arange(B) % 3).astype(np.int32)
+    ref = rng.normal(0, 0.5, (3, te.size))
+    if model == K.MODEL_MARKOV6:
+        params, y0, kw = np.tile(K.P_M6, (B, 1)) * rng.uniform(0.8, 1.2, (B, 12)), [0, 1.0, 0, 0, 0, 0], dict(obs_open_state_only=True)
+    else:
+        params, y0, kw = np.tile(K.P_HH, (B, 1)) * rng.uniform(0.8, 1.2, (B, 8)), [0.0, 1.0], {}
+    if model == K.MODEL_NNF:
+        kw.update(weights=K.load_weights("s1"), L=5, N=200)
+    y0b = np.tile(y0, (B, 1)).astype(np.float64)
+    y0b[4, 1] = np.nan
+    kw.update(prot_t0=0.0, prot_dt=1.0, prot_of_traj=pot, f32=f32, obs_g=1.3, obs_e=-88.0)
+    capi = ion.capi
+    ref_t = torch.from_numpy(ref).to(gpu)
+    full = run_gpu(ion, gpu, model, params, pv, y0b, te, current=True, **kw)
+    want = ((full["i"] - ref[pot]) ** 2).sum(1)
+    # through the ctypes layer directly, to reach the sse outputs
+    sdt = torch.float32 if f32 else torch.float64
+    packed = torch.from_numpy(capi.mlp_pack(kw["weights"], 5, 200)).to(gpu) if model == K.MODEL_NNF else None
+    common = dict(mlp_packed=packed, mlp_layers=5 if packed is not None else 0, mlp_width=200 if packed is not None else 0,
+                  prot_t0=0.0, prot_dt=1.0, prot_of_traj=torch.from_numpy(pot).to(gpu), obs_g=1.3, obs_e=-88.0,
+                  obs_open_state_only=(model == K.MODEL_MARKOV6), sse_ref=ref_t)
+    args = (model, torch.from_numpy(params).to(gpu), torch.from_numpy(pv).to(gpu), torch.from_numpy(y0b).to(gpu).to(sdt).contiguous(),
+            torch.from_numpy(te).to(gpu))
+    r1 = capi.dopri5(*args, current=True, **common)            # traces + fused sum
+    r2 = capi.dopri5(*args, states=False, **common)            # fused sum only: nothing but [B] doubles is written
+    torch.cuda.synchronize()
+    assert r2["y"] is None and r2["i"] is None
+    for r in (r1, r2):
+        got = r["sse"].cpu().numpy()
+        assert np.isinf(got[4]) and r["status"][4].item() != 0
+        ok = np.arange(B) != 4
+        assert np.allclose(got[ok], want[ok], rtol=1e-12, atol=0)
+    assert np.array_equal(r1["y"].double().cpu().numpy(), full["y"], equal_nan=True)
