@@ -224,7 +224,7 @@ def main():
         out.clear()
         torch.cuda.empty_cache()
         for key, fn in (("roofline_closed_form", closed_form_legs), ("gradient_config5", gradient_leg),
-                        ("regression_step", regression_leg)):
+                        ("regression_step", regression_leg), ("launch_order_16384", launch_order_leg)):
             try:
                 res[key] = fn(ion, dev, weights)
             except Exception as e:  # informational legs only
@@ -319,6 +319,41 @@ def gradient_leg(ion, dev, weights):
     return {"workload": "configs[4]: dL/dW through odeint, NN-f s00, 1024 trajectories (1/8 of the 8192-trajectory batch), "
                         "fp32 state, sine-wave protocols, N_t = N_p = 100001", "forward_with_checkpoints_s": fwd, "backward_s": bwd,
             "trajectories_per_s_fwd_bwd": B / (fwd + bwd), "grad_w_norm": gnorm, "ok": int((status == 0).sum().item())}
+
+
+def launch_order_leg(ion, dev, weights):
+    """The s00 kernel at four tiles per compute unit (the batch of BASELINE configs[2]) with the configs[1] protocols: the
+    arbitrary trajectory order against schedule.lpt_order() of (a) a closed-form pilot solve and (b) the previous solve's own
+    RHS-evaluation counters (what a training loop has).  Same trajectories, bit-identical results, different tiling."""
+    capi, P, S = ion.capi, ion.protocols, ion.schedule
+    B, Nt = 16384, 100001
+    pv = P.sinewave(P.sinewave_scales(0, B), n_samples=Nt, dt=0.1, xp=torch, device=dev)
+    params = torch.from_numpy(np.tile(P_HH, (B, 1))).to(dev)
+    y0 = torch.tensor([[0.0, 1.0]], dtype=torch.float64)
+    te = torch.arange(Nt, dtype=torch.float64, device=dev) * 0.1
+
+    def run(order):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        sol = ion.solve(capi.MODEL_NNF, params, pv, y0, te, weights=weights, mlp_layers=MLP_L, mlp_width=MLP_N,
+                        weights_key="bench-s00", prot_t0=0.0, prot_dt=0.1, t_eval_hint=(0.0, 0.1), order=order)
+        e1.record()
+        torch.cuda.synchronize()
+        nfe = sol.to_original(sol.stats[:, 2]).double()
+        ms, ok, y = e0.elapsed_time(e1), int((sol.status == 0).sum()), sol.to_original(sol.y[:, ::5000].contiguous())
+        return ms, nfe, ok, y
+
+    def line(ms, nfe, ok):
+        return {"ms": ms, "trajectories_per_s": B / (ms * 1e-3), "frac_of_fp32_peak": float(nfe.sum()) * (F_MLP + F_RHS_OTHER) / (ms * 1e-3) / (PEAK_FP32_TFLOPS * 1e12), "ok": ok}
+
+    run(None)
+    ms0, nfe0, ok0, ya = run(None)
+    pc = S.pilot_cost(params, pv, 0.0, float(te[-1]), prot_t0=0.0, prot_dt=0.1)
+    ms1, nfe1, ok1, yb = run(S.lpt_order(pc))
+    ms2, nfe2, ok2, yc = run(S.lpt_order(nfe0))
+    return {"workload": "NN-f s00, 16384 sine-wave trajectories x 100001 samples, fp64 state (4 tiles per compute unit)",
+            "arbitrary_order": line(ms0, nfe0, ok0), "pilot_order": line(ms1, nfe1, ok1), "previous_nfe_order": line(ms2, nfe2, ok2),
+            "results_identical": bool(torch.equal(ya, yb) and torch.equal(ya, yc) and torch.equal(nfe0, nfe1) and torch.equal(nfe0, nfe2))}
 
 
 def regression_leg(ion, dev, weights):

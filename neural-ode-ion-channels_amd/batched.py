@@ -64,6 +64,15 @@ class Solution:
     stats: Optional[torch.Tensor]   # [B, 4] int64: accepted, rejected, nfe, status
     kernel: str
     sse: Optional[torch.Tensor] = None  # [B] fp64 fused sum of squared current residuals (sse_ref given), inf where failed
+    order: Optional[torch.Tensor] = None  # [B] int64 launch order (solve(order=...)): row k of every field is trajectory order[k]
+
+    def to_original(self, x):
+        """Scatter a per-trajectory tensor (leading dimension B, launch order) back to the caller's trajectory order."""
+        if self.order is None:
+            return x
+        out = torch.empty_like(x)
+        out.index_copy_(0, self.order, x)
+        return out
 
     def raise_on_failure(self):
         st = self.status.cpu().numpy()
@@ -78,12 +87,16 @@ def solve(model, params, prot_v, y0, t_eval, *, weights=None, mlp_layers=0, mlp_
           prot_t=None, prot_t0=0.0, prot_dt=1.0, prot_of_traj=None, state_dtype=None, rtol=1e-7, atol=1e-9,
           v_oob=-80.0, max_steps=0, max_total_steps=0, max_step=0.0, current=False, obs_g=1.0, obs_e=-86.0, obs_open_state_only=False,
           tile_waves=0, device=None, step_log=None, t_eval_hint="auto", prot_key=None, t_eval_key=None, sse_ref=None,
-          states=True) -> Solution:
+          states=True, order=None) -> Solution:
     """Integrate B trajectories on the GPU (asynchronous on the current stream).
 
     params [B, 8|12] (or [8|12] -> B = 1), prot_v [P, Np] (or [Np]), y0 [B, D] / [D] (broadcast over B),
     t_eval [Nt].  state_dtype: torch.float32 (reference-compatible) or torch.float64; default = y0's dtype if it
     is a floating torch tensor, else float64.
+    order: optional permutation of range(B) (schedule.lpt_order): launch slot k integrates trajectory order[k], so 16
+    consecutive entries share an MFMA tile and earlier tiles start first.  Every field of the Solution is then in LAUNCH
+    order (un-permuting [B, Nt, D] traces would cost a second pass over them; Solution.to_original() does it on request).
+    Each trajectory's values do not depend on its tile-mates, so the ordering changes the time, never the results.
     """
     dev = _dev(device)
     t_eval_exact = None
@@ -102,6 +115,16 @@ def solve(model, params, prot_v, y0, t_eval, *, weights=None, mlp_layers=0, mlp_
     if y0_t.shape[0] != B:
         y0_t = y0_t.expand(B, y0_t.shape[1])
     y0_t = y0_t.contiguous()
+    pot_t = _to(prot_of_traj, torch.int32, dev)
+    order_t = None
+    if order is not None:
+        order_t = _to(order, torch.int64, dev)
+        if order_t.shape != (B,):
+            raise capi.IonodeError(f"order must be a permutation of range({B})")
+        params_t = params_t.index_select(0, order_t)
+        y0_t = y0_t.index_select(0, order_t)
+        # the kernel's default protocol of trajectory b is b % P: make it explicit before permuting
+        pot_t = (order_t % prot_v_t.shape[0]).to(torch.int32) if pot_t is None else pot_t.index_select(0, order_t)
     if isinstance(t_eval_hint, str) and t_eval_hint == "auto" and not (isinstance(t_eval, torch.Tensor) and t_eval.is_cuda):
         # host-side grid: derive the output-cursor hint without touching the device
         te = t_eval.detach().double().numpy() if isinstance(t_eval, torch.Tensor) else np.asarray(t_eval, dtype=np.float64)
@@ -120,8 +143,9 @@ def solve(model, params, prot_v, y0, t_eval, *, weights=None, mlp_layers=0, mlp_
     r = capi.dopri5(model, params_t, prot_v_t, y0_t, t_eval_t, mlp_packed=packed, mlp_layers=mlp_layers,
                     mlp_width=mlp_width, prot_t=_to(prot_t, torch.float64, dev, key=None if prot_key is None else (prot_key, "t")),
                     prot_t0=prot_t0, prot_dt=prot_dt,
-                    prot_of_traj=_to(prot_of_traj, torch.int32, dev), rtol=rtol, atol=atol, v_oob=v_oob,
+                    prot_of_traj=pot_t, rtol=rtol, atol=atol, v_oob=v_oob,
                     max_steps=max_steps, max_total_steps=max_total_steps, max_step=max_step, current=current, obs_g=obs_g, obs_e=obs_e,
                     obs_open_state_only=obs_open_state_only, tile_waves=tile_waves, step_log=step_log,
                     t_eval_hint=t_eval_hint, t_eval_exact=t_eval_exact, sse_ref=_to(sse_ref, torch.float64, dev), states=states)
-    return Solution(y=r["y"], i=r["i"], status=r["status"], stats=r["stats"], kernel=capi.kernel_name(r["desc"]), sse=r["sse"])
+    return Solution(y=r["y"], i=r["i"], status=r["status"], stats=r["stats"], kernel=capi.kernel_name(r["desc"]), sse=r["sse"],
+                    order=order_t)

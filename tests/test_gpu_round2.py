@@ -264,3 +264,47 @@ def test_fused_sum_of_squares_epilogue(ion, gpu, model, f32):
         ok = np.arange(B) != 4
         assert np.allclose(got[ok], want[ok], rtol=1e-12, atol=0)
     assert np.array_equal(r1["y"].double().cpu().numpy(), full["y"], equal_nan=True)
+
+
+@pytest.mark.parametrize("model", [K.MODEL_NNF, K.MODEL_NND, K.MODEL_HH2])
+def test_launch_order_changes_the_tiling_never_the_results(ion, gpu, model):
+    """batched.solve(order=perm): launch slot k integrates trajectory perm[k] (schedule.lpt_order puts the expensive ones first
+    so that tiles are homogeneous); every trajectory's trace, counters and fused objective are bit-identical to the plain
+    launch, because a trajectory's arithmetic does not depend on its tile-mates.  Default protocol map (b % P) and explicit map."""
+    rng = np.random.default_rng(23)
+    B, P = 53, 5
+    pv = np.stack([K.activation(v)[1] for v in (-40, -20, 0, 20, 40)])
+    te = K.activation(0)[2][:1201]
+    params = np.tile(K.P_NN_D if model == K.MODEL_NND else K.P_HH, (B, 1)) * rng.uniform(0.8, 1.25, (B, 8))
+    y0 = np.tile([0.0, 1.0], (B, 1)) + rng.uniform(0, 0.05, (B, 2)) * [1, -1]
+    kw = dict(prot_t0=0.0, prot_dt=1.0, current=True, sse_ref=rng.normal(0, 1, (P, te.size)))
+    if model != K.MODEL_HH2:
+        kw.update(weights=K.load_weights("d2" if model == K.MODEL_NND else "s1"), mlp_layers=5, mlp_width=200)
+    for pot in (None, rng.integers(0, P, B).astype(np.int32)):
+        plain = ion.solve(model, params, pv, torch.from_numpy(y0), te, prot_of_traj=pot, **kw)
+        cost = plain.stats[:, 2]
+        for order in (ion.schedule.lpt_order(cost), torch.from_numpy(rng.permutation(B))):
+            sol = ion.solve(model, params, pv, torch.from_numpy(y0), te, prot_of_traj=pot, order=order, **kw)
+            assert torch.equal(sol.order.cpu(), order.cpu())
+            for name in ("y", "i", "status", "stats", "sse"):
+                a, b = getattr(plain, name), sol.to_original(getattr(sol, name))
+                assert torch.equal(a, b), name
+            assert torch.equal(sol.y[0], plain.y[int(order[0])])      # launch order: row k is trajectory order[k]
+        c = cost.cpu().numpy()[ion.schedule.lpt_order(cost).cpu().numpy()]
+        assert (np.diff(c) <= 0).all()
+    with pytest.raises(ion.IonodeError):
+        ion.solve(model, params, pv, torch.from_numpy(y0), te, order=np.arange(B - 1), **kw)
+
+
+def test_pilot_cost_ranks_the_trajectories(ion, gpu):
+    """schedule.pilot_cost: RHS-evaluation counts of a closed-form HH solve over the same protocols -- positive, and ranked
+    like the NN-f model's own counts (rank correlation > 0.8 on sine-wave protocols of different speed)."""
+    B, Nt = 64, 20001
+    pv = ion.protocols.sinewave(ion.protocols.sinewave_scales(0, B), n_samples=Nt, dt=0.1, xp=torch, device=gpu)
+    params = np.tile(K.P_HH, (B, 1))
+    pc = ion.schedule.pilot_cost(params, pv, 0.0, (Nt - 1) * 0.1, prot_t0=0.0, prot_dt=0.1)
+    sol = ion.solve(K.MODEL_NNF, params, pv, torch.tensor([[0.0, 1.0]], dtype=torch.float64), np.array([0.0, (Nt - 1) * 0.1]),
+                    weights=K.load_weights("s1"), mlp_layers=5, mlp_width=200, prot_t0=0.0, prot_dt=0.1)
+    assert pc.shape == (B,) and bool((pc > 0).all()) and bool((sol.status == 0).all())
+    ra, rb = torch.argsort(torch.argsort(pc)).double(), torch.argsort(torch.argsort(sol.stats[:, 2])).double()
+    assert float(torch.corrcoef(torch.stack([ra, rb]))[0, 1]) > 0.8

@@ -173,6 +173,14 @@ def test_shard_bounds(ion):
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_lpt_order_is_a_stable_descending_permutation(ion):
+    cost = np.array([5, 9, 5, 1, 9, 7], dtype=np.int64)
+    o = ion.schedule.lpt_order(cost).numpy()
+    assert sorted(o.tolist()) == list(range(6))
+    assert o.tolist() == [1, 4, 5, 0, 2, 3]            # ties keep the caller's order
+    assert ion.schedule.lpt_order(torch.tensor([0.5, 2.5])).tolist() == [1, 0]
+
+
 def test_product_never_touches_the_oracle():
     """oracle/ is test infrastructure: nothing under the product package (Python or C/HIP sources) or the torchdiffeq
     shim may import, include, link or execute it; bench.py may only in its cpu_baseline legs."""

@@ -26,6 +26,7 @@ ap.add_argument("--model", default="hh", choices=["hh", "m6", "nnf"])
 ap.add_argument("--width", type=int, default=10, help="nnf: MLP width N")
 ap.add_argument("--layers", type=int, default=5, help="nnf: hidden layers L")
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--protocol-major", action="store_true", help="trajectories of one protocol adjacent (lanes of a wavefront share it)")
 a = ap.parse_args()
 
 ion = importlib.import_module("neural-ode-ion-channels_amd")
@@ -52,6 +53,8 @@ sdt = torch.float32 if a.f32 else torch.float64
 y0t = torch.tensor([y0], dtype=sdt, device=dev).repeat(B, 1).contiguous()
 te = torch.arange(Nt, dtype=torch.float64, device=dev) * 0.1
 pot = torch.arange(B, dtype=torch.int32, device=dev) % a.prot
+if a.protocol_major:
+    pot = (torch.arange(B, dtype=torch.int64, device=dev) * a.prot // B).to(torch.int32)
 out = {}
 ms = []
 for rep in range(a.reps + 1):
