@@ -183,7 +183,7 @@ def main():
         "config": {"workload": "configs[1]: NN-f (arch s00) batched synthetic sinewave trajectories, fp64 state, "
                                "N_p = N_t = %d, rtol 1e-7 atol 1e-9" % Nt,
                    "trajectories_per_gpu": B, "global_batch": world * B, "parallelism": f"traj-shard x{world}",
-                   "kernel": capi.kernel_name(r["desc"]), "geometry": capi.launch_geometry(r["desc"]),
+                   "kernel": r["kernel"], "geometry": capi.launch_geometry(r["desc"]),
                    "mean_nfe": float(nfe.mean()), "max_nfe": float(nfe.max()),
                    "us_per_rhs_eval_slowest_tile": kern_ms * 1e3 / float(nfe.max()),
                    "mean_accepted": float(stats[:, 0].mean()),
@@ -203,7 +203,7 @@ def main():
         # doubled (gfx950 counts 128-B requests as 64 B), WRITE_SIZE is exact; both are reported in KiB
         try:
             pj = json.load(open(pmc))
-            kname = "void ionode::" + capi.kernel_name(r["desc"]) + "(ionode::KArgs)"
+            kname = "void ionode::" + r["kernel"] + "(ionode::KArgs)"
             traffic = (2 * pj["pmc2"][kname]["FETCH_SIZE"] + pj["pmc3"][kname]["WRITE_SIZE"]) * 1024
             for key in ("roofline", "roofline_hbm"):
                 res[key]["traffic"] = traffic
@@ -283,12 +283,31 @@ def closed_form_legs(ion, dev, weights):
         ms = _timed(run, 2)
         nbytes = B * Nt * D * 8 + n_prot * Nt * 8
         st = hold["r"]["stats"].cpu().numpy()
-        legs[name] = {"kernel": capi.kernel_name(hold["r"]["desc"]), "trajectories": B, "n_out": Nt, "kernel_ms": ms,
+        legs[name] = {"kernel": hold["r"]["kernel"], "trajectories": B, "n_out": Nt, "kernel_ms": ms,
                       "trajectories_per_s": B / ms * 1e3, "bound": "hbm", "achieved": nbytes / ms / 1e6, "peak": PEAK_HBM_GBS,
                       "unit": "GB/s", "frac": nbytes / ms / 1e6 / PEAK_HBM_GBS, "mean_nfe": float(st[:, 2].mean()),
                       "ok": int((hold["r"]["status"] == 0).sum().item())}
         del params, y0t, o, hold
         torch.cuda.empty_cache()
+    # BASELINE configs[3]'s inner operation: the fused sum-of-squares objective of HH candidates (fp32 state as train-d0.py:405),
+    # nothing but one double per solve written; V(t_k) from the protocol-at-outputs table (ionode_desc.v_at_outputs)
+    B = 196608
+    params = torch.from_numpy(P_HH[None, :] * rng.uniform(0.8, 1.25, (B, 8))).to(dev)
+    y0t = torch.tensor([[0.0, 1.0]], dtype=torch.float32, device=dev).repeat(B, 1).contiguous()
+    pot = (torch.arange(B, dtype=torch.int32, device=dev) % n_prot).contiguous()
+    ref = torch.zeros((n_prot, Nt), dtype=torch.float64, device=dev)
+    hold = {}
+
+    def run_obj():
+        hold["r"] = capi.dopri5(capi.MODEL_HH2, params, pv, y0t, te, prot_t0=0.0, prot_dt=0.1, prot_of_traj=pot,
+                                t_eval_hint=(0.0, 0.1), t_eval_exact=True, sse_ref=ref, states=False, stats=False)
+    ms = _timed(run_obj, 2)
+    legs["hh2_fused_objective_f32"] = {"kernel": hold["r"]["kernel"], "trajectories": B, "n_out": Nt, "kernel_ms": ms,
+                                       "trajectories_per_s": B / ms * 1e3, "samples_per_s": B * Nt / ms * 1e3,
+                                       "ok": int((hold["r"]["status"] == 0).sum().item()),
+                                       "note": "ms includes the protocol-at-outputs pre-pass (64 x 20001 lookups)"}
+    del params, y0t, hold
+    torch.cuda.empty_cache()
     legs["note"] = ("fp64-VALU-issue bound, not HBM bound: ~5000 vector instructions per step attempt and 64-trajectory wavefront "
                     "(profiles/r02_closed_form.md: SQ_ACTIVE_INST_VALU vs SQ_WAIT_ANY, and the no-store / no-emission timing experiments)")
     return legs

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define IONODE_ABI_VERSION 3
+#define IONODE_ABI_VERSION 4
 
 /* RHS families (func.forward variants of the reference) */
 #define IONODE_MODEL_HH2 0     /* 2-state Hodgkin-Huxley: Lambda, train-s1.py:134-177; candidate ODEFunc train-d0.py:321-374 */
@@ -105,6 +105,10 @@ typedef struct ionode_desc {
                           (the error estimate of a state AT equilibrium is ~0); the forward solve copes through rejections,
                           but the reverse-mode derivative of such accepted-but-unstable steps multiplies adjoints by
                           |R(h*lambda)| >> 1 per step.  max_step < 3.3 / lambda_max keeps the backward sweep bounded. */
+  const double *v_at_outputs; /* optional (NULL = off), closed-form models with i_out or sse_out: DEVICE [n_prot][n_out] protocol
+                          voltage at the output times, filled by ionode_protocol_at_outputs() for the same protocols and t_eval.
+                          The current / objective epilogue then loads V(t_k) instead of re-deriving it per trajectory per sample
+                          (same values: the pre-pass runs the integrator's own lookup).  Pays when n_prot << n_traj. */
 } ionode_desc;
 
 #define IONODE_DEFAULT_MAX_TOTAL_STEPS 1000000
@@ -140,11 +144,21 @@ int ionode_dopri5(const ionode_desc *d, const float *mlp_packed, const double *p
                   const double *prot_t, const int32_t *prot_of_traj, const void *y0, const double *t_eval,
                   void *y_out, double *i_out, int32_t *status, int64_t *stats, void *stream);
 
+/* Pre-pass for ionode_desc.v_at_outputs: v_out[p][k] = V_p(t_eval[k]) for the d->n_prot protocols at the d->n_out output
+ * times, by the integrator's own lookup (linear interpolation, -80 mV / v_oob outside the protocol: train-s1.py:218-237).
+ * Reads d->n_out, n_prot, prot_n, prot_t0, prot_dt, v_oob.  Asynchronous on `stream`. */
+int ionode_protocol_at_outputs(const ionode_desc *d, const double *prot_v, const double *prot_t, const double *t_eval,
+                               double *v_out, void *stream);
+
 /* Launch geometry the dispatcher would use for `d` (for tests / bench reporting): grid, block, LDS bytes, tile_waves. */
 int ionode_launch_geometry(const ionode_desc *d, int32_t out[4]);
 
-/* Name of the kernel instantiation ionode_dopri5 would launch for `d` (matches rocprofv3 kernel-trace). */
+/* Name of the kernel instantiation ionode_dopri5 would launch for `d` (matches rocprofv3 kernel-trace).  The descriptor does
+ * not say whether an i_out buffer will be passed; a fused objective or a v_at_outputs table implies the epilogue variant. */
 const char *ionode_kernel_name(const ionode_desc *d);
+
+/* Name of the instantiation this thread's last successful ionode_dopri5 call launched ("" before the first). */
+const char *ionode_last_kernel_name(void);
 
 const char *ionode_last_error(void);
 int32_t ionode_abi_version(void);

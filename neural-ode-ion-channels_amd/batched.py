@@ -147,5 +147,5 @@ def solve(model, params, prot_v, y0, t_eval, *, weights=None, mlp_layers=0, mlp_
                     max_steps=max_steps, max_total_steps=max_total_steps, max_step=max_step, current=current, obs_g=obs_g, obs_e=obs_e,
                     obs_open_state_only=obs_open_state_only, tile_waves=tile_waves, step_log=step_log,
                     t_eval_hint=t_eval_hint, t_eval_exact=t_eval_exact, sse_ref=_to(sse_ref, torch.float64, dev), states=states)
-    return Solution(y=r["y"], i=r["i"], status=r["status"], stats=r["stats"], kernel=capi.kernel_name(r["desc"]), sse=r["sse"],
+    return Solution(y=r["y"], i=r["i"], status=r["status"], stats=r["stats"], kernel=r["kernel"], sse=r["sse"],
                     order=order_t)

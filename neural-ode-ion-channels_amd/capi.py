@@ -21,11 +21,11 @@ STATUS_TEXT = {
     2: "non-finite values in state `y`",
     3: "max_num_steps exceeded",
 }
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 EXPORTS = (
     "ionode_abi_version", "ionode_last_error", "ionode_mlp_packed_floats", "ionode_mlp_pack",
-    "ionode_launch_geometry", "ionode_kernel_name", "ionode_dopri5",
+    "ionode_launch_geometry", "ionode_kernel_name", "ionode_last_kernel_name", "ionode_dopri5", "ionode_protocol_at_outputs",
     "ionode_grad_image_floats", "ionode_grad_pack", "ionode_grad_record_floats", "ionode_dopri5_backward",
     "ionode_grad_partial_floats", "ionode_grad_reduce", "ionode_grad_last_error",
     "ionode_regress_step", "ionode_adam_step", "ionode_image_refresh",
@@ -43,7 +43,7 @@ class IonodeDesc(C.Structure):
         ("step_log", C.c_void_p), ("step_log_cap", C.c_int64),
         ("t_eval_t0_hint", C.c_double), ("t_eval_dt_hint", C.c_double),
         ("max_total_steps", C.c_int64), ("ckpt", C.c_void_p), ("ckpt_cap", C.c_int32), ("t_eval_exact", C.c_int32),
-        ("sse_ref", C.c_void_p), ("sse_out", C.c_void_p), ("max_step", C.c_double),
+        ("sse_ref", C.c_void_p), ("sse_out", C.c_void_p), ("max_step", C.c_double), ("v_at_outputs", C.c_void_p),
     ]
 
 
@@ -101,6 +101,10 @@ def lib():
                                        C.c_void_p, C.c_int32, C.c_void_p]
         L.ionode_image_refresh.restype = C.c_int
         L.ionode_image_refresh.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ionode_last_kernel_name.restype = C.c_char_p
+        L.ionode_last_kernel_name.argtypes = []
+        L.ionode_protocol_at_outputs.restype = C.c_int
+        L.ionode_protocol_at_outputs.argtypes = [C.POINTER(IonodeDesc)] + [C.c_void_p] * 5
         if L.ionode_abi_version() != ABI_VERSION:
             raise IonodeError("libionode.so ABI version mismatch; rebuild")
         _lib = L
@@ -159,7 +163,8 @@ def _dev_ptr(t, dtype, name, shape=None):
 def dopri5(model, params, prot_v, y0, t_eval, *, mlp_packed=None, mlp_layers=0, mlp_width=0, prot_t=None,
            prot_t0=0.0, prot_dt=1.0, prot_of_traj=None, rtol=1e-7, atol=1e-9, v_oob=-80.0, max_steps=0,
            max_total_steps=0, max_step=0.0, ckpt=None, current=False, obs_g=1.0, obs_e=-86.0, obs_open_state_only=False, tile_waves=0, stats=True,
-           step_log=None, t_eval_hint="auto", t_eval_exact=None, sse_ref=None, states=True, out=None, stream=None):
+           step_log=None, t_eval_hint="auto", t_eval_exact=None, sse_ref=None, states=True, out=None, stream=None,
+           v_at_outputs="auto"):
     """Launch one batched solve.  Every tensor lives on the current HIP device.
 
     params [B, n_params] f64, prot_v [P, Np] f64, y0 [B, D] f32|f64 (selects the state dtype),
@@ -231,6 +236,18 @@ def dopri5(model, params, prot_v, y0, t_eval, *, mlp_packed=None, mlp_layers=0, 
     if stats and st is None:
         st = torch.empty((B, 4), dtype=torch.int64, device=dev)
     s = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
+    # closed-form current / objective epilogue: V(t_k) once per protocol instead of once per trajectory per sample ("auto":
+    # when every protocol serves at least four trajectories; a [P, Nt] f64 tensor from an earlier call may be passed back in)
+    vtab = None
+    if (current or sse_ref is not None) and model in (MODEL_HH2, MODEL_MARKOV6) and v_at_outputs is not None:
+        if isinstance(v_at_outputs, str):
+            if 4 * P <= B:
+                vtab = protocol_at_outputs(desc, prot_v, prot_t, t_eval, stream=s)
+        else:
+            vtab = v_at_outputs
+            _dev_ptr(vtab, torch.float64, "v_at_outputs", (P, Nt))
+        if vtab is not None:
+            desc.v_at_outputs = vtab.data_ptr()
     rc = lib().ionode_dopri5(
         C.byref(desc),
         _dev_ptr(mlp_packed, torch.float32, "mlp_packed"),
@@ -248,4 +265,17 @@ def dopri5(model, params, prot_v, y0, t_eval, *, mlp_packed=None, mlp_layers=0, 
     )
     if rc != 0:
         raise IonodeError(f"ionode_dopri5 failed ({rc}): {last_error()}")
-    return {"y": y, "i": i_out, "status": status, "stats": st, "sse": sse, "desc": desc}
+    return {"y": y, "i": i_out, "status": status, "stats": st, "sse": sse, "desc": desc, "v_at_outputs": vtab,
+            "kernel": lib().ionode_last_kernel_name().decode()}
+
+
+def protocol_at_outputs(desc, prot_v, prot_t, t_eval, stream=None):
+    """[P, Nt] f64: every protocol's voltage at the output times (ionode_protocol_at_outputs), on prot_v's device."""
+    out = torch.empty((desc.n_prot, desc.n_out), dtype=torch.float64, device=prot_v.device)
+    s = stream if stream is not None else torch.cuda.current_stream(prot_v.device).cuda_stream
+    rc = lib().ionode_protocol_at_outputs(C.byref(desc), _dev_ptr(prot_v, torch.float64, "prot_v"),
+                                          _dev_ptr(prot_t, torch.float64, "prot_t") if prot_t is not None else None,
+                                          _dev_ptr(t_eval, torch.float64, "t_eval"), out.data_ptr(), C.c_void_p(s))
+    if rc != 0:
+        raise IonodeError(f"ionode_protocol_at_outputs failed ({rc}): {last_error()}")
+    return out

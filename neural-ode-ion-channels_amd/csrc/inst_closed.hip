@@ -10,6 +10,11 @@ static const Variant kTab[] = {
     // last parameter 1: deferred aligned emission (2-state models, exact uniform output grid, no current trace)
     IONODE_VARIANT(0, double, 0, 1, 0, 0, 0, 1),  IONODE_VARIANT(0, float, 1, 1, 0, 0, 0, 1),
     IONODE_VARIANT(0, double, 0, 1, 16, 0, 0, 1), IONODE_VARIANT(0, float, 1, 1, 16, 0, 0, 1),
+    // last parameter 2: current / objective epilogue through the protocol-at-outputs table (ionode_desc.v_at_outputs)
+    IONODE_VARIANT(0, double, 0, 1, 0, 0, 0, 2),  IONODE_VARIANT(0, float, 1, 1, 0, 0, 0, 2),
+    IONODE_VARIANT(1, double, 0, 1, 0, 0, 0, 2),  IONODE_VARIANT(1, float, 1, 1, 0, 0, 0, 2),
+    IONODE_VARIANT(0, double, 0, 1, 16, 0, 0, 2), IONODE_VARIANT(0, float, 1, 1, 16, 0, 0, 2),
+    IONODE_VARIANT(1, double, 0, 1, 16, 0, 0, 2), IONODE_VARIANT(1, float, 1, 1, 16, 0, 0, 2),
 };
 const Variant *variants_closed(int *n) { *n = sizeof(kTab) / sizeof(kTab[0]); return kTab; }
 }  // namespace ionode

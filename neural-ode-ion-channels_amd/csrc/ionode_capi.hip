@@ -10,6 +10,7 @@
 namespace {
 
 thread_local char g_err[256] = "";
+thread_local const char *g_last_kernel = "";  // variant name of this thread's last successful ionode_dopri5 launch
 
 void set_err(const char *fmt, const char *detail = "") { snprintf(g_err, sizeof g_err, fmt, detail); }
 
@@ -52,7 +53,9 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false) {
     // needs 131072 trajectories.  tile_waves = 64 / 16 forces a choice (tests).
     const int tpw = (d->tile_waves == 64 || d->tile_waves == 16) ? d->tile_waves : (d->n_traj >= 131072 ? 64 : 16);
     // deferred aligned emission (2-state models): the output grid must be VERIFIED uniform and no current trace requested
-    const int defer = (D == 2 && d->t_eval_exact && d->t_eval_dt_hint > 0.0 && d->n_out > 1 && !want_current) ? 1 : 0;
+    // ... or, with a current trace / fused objective and the protocol-at-outputs table given, the table variant (hint path)
+    const int defer = (want_current && d->v_at_outputs && d->t_eval_dt_hint > 0.0 && d->n_out > 1) ? 2
+                      : ((D == 2 && d->t_eval_exact && d->t_eval_dt_hint > 0.0 && d->n_out > 1 && !want_current) ? 1 : 0);
     pl->v = find_variant(d->model, f32, 1, 0, tpw == 64 ? 0 : 16, defer);
     pl->grid = (unsigned)((d->n_traj + tpw - 1) / tpw);
     pl->block = 64;
@@ -79,6 +82,21 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false) {
 }
 
 }  // namespace
+
+namespace ionode {
+// Pre-pass of the current / objective epilogue: V(t_k) for every protocol at every requested output time, evaluated ONCE per
+// protocol with the same protocol_v() the integrator uses (so the epilogue's values do not change), instead of once per
+// trajectory per sample (~35 fp64 vector instructions each: as much as the dense-output polynomial itself).
+__global__ void __launch_bounds__(256) ionode_protocol_at_outputs_kernel(const KArgs a, double *__restrict__ v_out) {
+  const long long n = (long long)a.P * a.Nt;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+    const int p = (int)(e / a.Nt), k = (int)(e - (long long)p * a.Nt);
+    double v;
+    protocol_v(a, a.prot_v + (size_t)p * a.Np, a.t_eval[k], v);
+    v_out[e] = v;
+  }
+}
+}  // namespace ionode
 
 extern "C" {
 
@@ -176,9 +194,12 @@ int ionode_launch_geometry(const ionode_desc *d, int32_t out[4]) {
 
 const char *ionode_kernel_name(const ionode_desc *d) {
   Plan pl;
-  if (make_plan(d, &pl) != IONODE_OK) return "";
+  // the descriptor does not say whether i_out will be passed: a table or a fused objective implies the epilogue
+  if (make_plan(d, &pl, d && (d->sse_out != nullptr || d->v_at_outputs != nullptr)) != IONODE_OK) return "";
   return pl.v->name;
 }
+
+const char *ionode_last_kernel_name(void) { return g_last_kernel; }
 
 int ionode_dopri5(const ionode_desc *d, const float *mlp_packed, const double *params, const double *prot_v,
                   const double *prot_t, const int32_t *prot_of_traj, const void *y0, const double *t_eval,
@@ -211,11 +232,28 @@ int ionode_dopri5(const ionode_desc *d, const float *mlp_packed, const double *p
   a.prot_t0 = d->prot_t0; a.prot_dt = d->prot_dt; a.v_oob = d->v_oob; a.rtol = d->rtol; a.atol = d->atol;
   a.obs_g = d->obs_g; a.obs_e = d->obs_e; a.obs_open = d->obs_open_state_only;
   a.step_log = d->step_log; a.step_log_cap = d->step_log ? d->step_log_cap : 0;
-  a.sse_ref = d->sse_ref; a.sse_out = d->sse_out;
+  a.sse_ref = d->sse_ref; a.sse_out = d->sse_out; a.v_tab = d->v_at_outputs;
   a.te_t0 = d->t_eval_t0_hint; a.te_dt = (d->t_eval_dt_hint > 0.0 && d->n_out > 1) ? d->t_eval_dt_hint : 0.0;
   a.te_rdt = a.te_dt > 0.0 ? 1.0 / a.te_dt : 0.0;
   a.te_exact = (a.te_dt > 0.0 && d->t_eval_exact) ? 1 : 0;
   const hipError_t e = pl.v->fn(a, pl.grid, pl.lds, reinterpret_cast<hipStream_t>(stream));
+  if (e != hipSuccess) { set_err("kernel launch failed: %s", hipGetErrorString(e)); return IONODE_ERR_LAUNCH; }
+  g_last_kernel = pl.v->name;
+  return IONODE_OK;
+}
+
+int ionode_protocol_at_outputs(const ionode_desc *d, const double *prot_v, const double *prot_t, const double *t_eval,
+                               double *v_out, void *stream) {
+  if (!d || !prot_v || !t_eval || !v_out) { set_err("ionode_protocol_at_outputs: required buffer is NULL"); return IONODE_ERR_ARG; }
+  if (d->n_out < 1 || d->n_prot < 1 || d->prot_n < 2 || !(d->prot_dt > 0)) { set_err("ionode_protocol_at_outputs: empty grid / protocol"); return IONODE_ERR_ARG; }
+  ionode::KArgs a;
+  memset(&a, 0, sizeof a);
+  a.prot_v = prot_v; a.prot_t = prot_t; a.t_eval = t_eval; a.Nt = d->n_out; a.P = d->n_prot; a.Np = d->prot_n;
+  a.prot_t0 = d->prot_t0; a.prot_dt = d->prot_dt; a.prot_rdt = 1.0 / d->prot_dt; a.v_oob = d->v_oob;
+  const long long n = (long long)a.P * a.Nt;
+  const unsigned grid = (unsigned)((n + 255) / 256 > 65536 ? 65536 : (n + 255) / 256);
+  hipLaunchKernelGGL(ionode::ionode_protocol_at_outputs_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a, v_out);
+  const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_err("kernel launch failed: %s", hipGetErrorString(e)); return IONODE_ERR_LAUNCH; }
   return IONODE_OK;
 }

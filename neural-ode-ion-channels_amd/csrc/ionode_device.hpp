@@ -65,6 +65,8 @@ struct KArgs {
   double te_rdt;        // 1 / te_dt (for the guess only)
   int32_t te_exact;     // 1: the caller VERIFIED t_eval[k] == te_t0 + (double)k * te_dt bit for bit (fp64 multiply, then add):
                         // closed-form kernels then form output times arithmetically -- no vector load sits behind their stores
+  const double *v_tab;  // optional [P][Nt]: protocol voltage AT the output times (ionode_protocol_at_outputs); the closed-form
+                        // kernels' current / objective epilogue then loads V(t_k) instead of re-deriving it per trajectory
 };
 
 // Dormand-Prince / Shampine coefficients.
@@ -197,6 +199,23 @@ __device__ __forceinline__ float bcast_f32(float x, int src) {
 template <typename S> __device__ __forceinline__ S bcast(S x, int src);
 template <> __device__ __forceinline__ double bcast<double>(double x, int src) { return bcast_f64(x, src); }
 template <> __device__ __forceinline__ float bcast<float>(float x, int src) { return bcast_f32(x, src); }
+
+// Sum of x over the 64 lanes with DPP row operations (VALU speed; __shfl_xor would take 12 LDS-crossbar round trips for a
+// double).  Fixed order: ((quad) + half-row + row) then rows (2 + 3) + (0 + 1); the total is returned to every lane.
+template <int CTRL, int ROWMASK> __device__ __forceinline__ double dpp_f64(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROWMASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROWMASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_f64(double x) {
+  x = x + dpp_f64<0xB1, 0xf>(x);   // quad_perm [1,0,3,2]
+  x = x + dpp_f64<0x4E, 0xf>(x);   // quad_perm [2,3,0,1]
+  x = x + dpp_f64<0x141, 0xf>(x);  // row_half_mirror
+  x = x + dpp_f64<0x140, 0xf>(x);  // row_mirror: every lane of a row holds the row's sum
+  x = x + dpp_f64<0x142, 0xa>(x);  // row_bcast:15 into rows 1 and 3
+  x = x + dpp_f64<0x143, 0xc>(x);  // row_bcast:31 into rows 2 and 3: row 3 holds the total
+  return bcast_f64(x, 63);
+}
 
 // interp1d(t, v) (linear) with the reference's out-of-range rule (train-s1.py:218-229, :234-237).
 // scipy: i = searchsorted(x, t) [left], clipped to [1, n-1]; y = slope*(t - x[i-1]) + y[i-1].
@@ -784,6 +803,10 @@ __global__ void __launch_bounds__(64 * G, IONODE_CF_WAVES(MODEL, G)) ionode_dopr
   // compile-time variant (template parameter TAIL == 1 of a closed-form kernel); the dispatcher selects it only when
   // te_dt > 0, te_exact and i_out == NULL hold (ionode_capi.hip)
   constexpr bool defer = CF2 && TAIL == 1;
+  // TAIL == 2 of a closed-form kernel: the current / objective epilogue reads V(t_k) from the pre-pass table a.v_tab (selected
+  // by the dispatcher when ionode_desc.v_at_outputs is given); a compile-time variant so that neither variant carries the
+  // other's code and registers
+  constexpr bool VTAB = !MT::MLP && TAIL == 2;
   unsigned char *const tails = smem + 64 * ROWB;
   int ow = 1;  // defer: next sample index of MY trajectory not yet written to HBM (ow <= oi, oi - ow < LS)
   if constexpr (CF2 && defer) {
@@ -1071,13 +1094,15 @@ __global__ void __launch_bounds__(64 * G, IONODE_CF_WAVES(MODEL, G)) ionode_dopr
       }
       int jj = em ? __builtin_ctzll(em) : 0;
       int o = __builtin_amdgcn_readlane(oi, jj);
-      double tk_nxt = (em && o + lane < Nt) ? a.t_eval[o + lane] : 0.0;
+      // closed-form kernels on a verified uniform output grid form t_k arithmetically (bit-equal to the t_eval entry)
+      const bool arith_t = !MT::MLP && a.te_exact;
+      double tk_nxt = (em && o + lane < Nt) ? (arith_t ? te_at(o + lane) : a.t_eval[o + lane]) : 0.0;
       while (em) {
         em &= em - 1;
         const int jn = em ? __builtin_ctzll(em) : 0;
         const int on = __builtin_amdgcn_readlane(oi, jn);
         double tk = tk_nxt;
-        if (em && on + lane < Nt) tk_nxt = a.t_eval[on + lane];  // next trajectory's first chunk, in flight meanwhile
+        if (em && on + lane < Nt) tk_nxt = arith_t ? te_at(on + lane) : a.t_eval[on + lane];  // next trajectory's first chunk, in flight meanwhile
         const int n = __builtin_amdgcn_readlane(n_out, jj);
         double t0b, denb, rdenb;
         S cb[5][D];
@@ -1102,17 +1127,20 @@ __global__ void __launch_bounds__(64 * G, IONODE_CF_WAVES(MODEL, G)) ionode_dopr
         const int tr = __builtin_amdgcn_readlane(traj, jj);
         S *__restrict__ yo = a.y_out ? reinterpret_cast<S *>(a.y_out) + (size_t)tr * Nt * D : nullptr;
         double *__restrict__ io = nullptr;
-        const double *__restrict__ pvb = nullptr, *__restrict__ refb = nullptr;
+        const double *__restrict__ pvb = nullptr, *__restrict__ refb = nullptr, *__restrict__ vtb = nullptr;
         if (a.i_out || a.sse_out) {
           if (a.i_out) io = a.i_out + (size_t)tr * Nt;
-          const int pj = a.prot_of_traj ? a.prot_of_traj[tr] : (tr % a.P);
+          int pj;
+          if constexpr (!MT::MLP) pj = __builtin_amdgcn_readlane(pidx, jj);  // no dependent global load per emitting trajectory
+          else pj = a.prot_of_traj ? a.prot_of_traj[tr] : (tr % a.P);
           pvb = a.prot_v + (size_t)pj * a.Np;
           if (a.sse_out) refb = a.sse_ref + (size_t)pj * Nt;
+          if constexpr (VTAB) vtb = a.v_tab + (size_t)pj * Nt;
         }
         double sacc = 0.0;
         for (int c0 = 0; c0 < n; c0 += 64) {
           const int idx = o + c0 + lane;
-          if (c0 > 0 && c0 + lane < n) tk = a.t_eval[idx];
+          if (c0 > 0 && c0 + lane < n) tk = arith_t ? te_at(idx) : a.t_eval[idx];
           if (c0 + lane < n) {
             const S x = (S)div_by(tk - t0b, denb, rdenb);  // _interp_evaluate: x = (t - t0) / (t1 - t0) in fp64, cast; running powers
             S out[D];
@@ -1128,7 +1156,8 @@ __global__ void __launch_bounds__(64 * G, IONODE_CF_WAVES(MODEL, G)) ionode_dopr
             if (yo) store_state<S, D>(yo + (size_t)idx * D, out);
             if (pvb) {
               double vk;
-              protocol_v(a, pvb, tk, vk);
+              if constexpr (VTAB) vk = vtb[idx];  // == protocol_v(a, pvb, t_eval[idx]), evaluated once per protocol by the pre-pass
+              else protocol_v(a, pvb, tk, vk);
               S gate;
               if (a.obs_open) gate = out[D - 1]; else gate = out[0] * out[1];
               if (a.obs_g != 1.0) gate = (S)a.obs_g * gate;
@@ -1139,8 +1168,11 @@ __global__ void __launch_bounds__(64 * G, IONODE_CF_WAVES(MODEL, G)) ionode_dopr
           }
         }
         if (a.sse_out) {  // fused objective: the step's squared residuals of trajectory jj, summed over the wavefront
+          if constexpr (!MT::MLP) sacc = wave_sum_f64(sacc);
+          else {
 #pragma unroll
-          for (int msk = 32; msk >= 1; msk >>= 1) sacc += __shfl_xor(sacc, msk);
+            for (int msk = 32; msk >= 1; msk >>= 1) sacc += __shfl_xor(sacc, msk);
+          }
           if (j == jj) sse += sacc;
         }
         jj = jn;

@@ -8,7 +8,7 @@ using LaunchFn = hipError_t (*)(const KArgs &, unsigned grid, size_t lds, hipStr
 
 struct Variant {
   int model, f32, G, RT, NT, PD;  // NT = k-tiles (16*NT = padded MLP width), PD = weight-ring depth
-  int tail;                       // closed-form kernels: 1 = deferred aligned emission variant (ionode_device.hpp `defer`)
+  int tail;                       // closed-form kernels: 1 = deferred aligned emission variant (ionode_device.hpp `defer`), 2 = epilogue through v_at_outputs
   LaunchFn fn;
   const char *name;  // as rocprofv3 --kernel-trace prints it
 };

@@ -308,3 +308,39 @@ def test_pilot_cost_ranks_the_trajectories(ion, gpu):
     assert pc.shape == (B,) and bool((pc > 0).all()) and bool((sol.status == 0).all())
     ra, rb = torch.argsort(torch.argsort(pc)).double(), torch.argsort(torch.argsort(sol.stats[:, 2])).double()
     assert float(torch.corrcoef(torch.stack([ra, rb]))[0, 1]) > 0.8
+
+
+@pytest.mark.parametrize("explicit_grid", [False, True])
+def test_protocol_at_outputs_table(ion, gpu, oracle, explicit_grid):
+    """ionode_protocol_at_outputs / ionode_desc.v_at_outputs: the pre-pass table equals the oracle's protocol lookup at every
+    output time (inside the protocol, at its ends, beyond it: -80 mV), and the closed-form current trace and fused objective
+    computed through the table are bit-identical to the per-sample lookup (sums: same terms, different order)."""
+    capi = ion.capi
+    rng = np.random.default_rng(31)
+    P, B = 3, 40
+    pv = np.stack([K.activation(v)[1] for v in (-30, 10, 50)])
+    Np = pv.shape[1]
+    pt = np.cumsum(rng.uniform(0.5, 1.5, Np)) if explicit_grid else None
+    t_end = (pt[-1] if explicit_grid else (Np - 1) * 1.0)
+    te = np.linspace(0.0 if not explicit_grid else pt[0], t_end * 1.02, 2501)      # the last 2 % lie beyond the protocol
+    kw = dict(prot_t0=0.0, prot_dt=1.0)
+    params = torch.from_numpy(np.tile(K.P_HH, (B, 1)) * rng.uniform(0.8, 1.2, (B, 8))).to(gpu)
+    pv_t, te_t = torch.from_numpy(pv).to(gpu), torch.from_numpy(te).to(gpu)
+    pt_t = torch.from_numpy(pt).to(gpu) if explicit_grid else None
+    y0 = torch.tensor([[0.0, 1.0]], dtype=torch.float64, device=gpu).repeat(B, 1).contiguous()
+    pot = torch.from_numpy((np.arange(B) % P).astype(np.int32)).to(gpu)
+    ref = torch.from_numpy(rng.normal(0, 0.3, (P, te.size))).to(gpu)
+    common = dict(prot_t=pt_t, prot_of_traj=pot, current=True, sse_ref=ref, obs_g=0.9, obs_e=-85.0, **kw)
+    with_tab = capi.dopri5(K.MODEL_HH2, params, pv_t, y0, te_t, **common)
+    without = capi.dopri5(K.MODEL_HH2, params, pv_t, y0, te_t, v_at_outputs=None, **common)
+    torch.cuda.synchronize()
+    assert with_tab["v_at_outputs"] is not None and without["v_at_outputs"] is None
+    tab = with_tab["v_at_outputs"].cpu().numpy()
+    for p in range(P):
+        want, _ = oracle.protocol_v(pv[p], te, prot_t=pt, **kw)
+        assert np.array_equal(tab[p], want)
+    assert (tab[:, -1] == -80.0).all()
+    assert torch.equal(with_tab["i"], without["i"]) and torch.equal(with_tab["y"], without["y"])
+    assert torch.allclose(with_tab["sse"], without["sse"], rtol=1e-13, atol=0)
+    again = capi.dopri5(K.MODEL_HH2, params, pv_t, y0, te_t, v_at_outputs=with_tab["v_at_outputs"], **common)   # a caller-kept table
+    assert torch.equal(again["i"], with_tab["i"])

@@ -22,6 +22,7 @@ ap.add_argument("--nt", type=int, default=100001)
 ap.add_argument("--prot", type=int, default=64)
 ap.add_argument("--f32", action="store_true")
 ap.add_argument("--current", action="store_true")
+ap.add_argument("--sse", action="store_true", help="fused objective only: no states, no current trace written")
 ap.add_argument("--model", default="hh", choices=["hh", "m6", "nnf"])
 ap.add_argument("--width", type=int, default=10, help="nnf: MLP width N")
 ap.add_argument("--layers", type=int, default=5, help="nnf: hidden layers L")
@@ -57,22 +58,25 @@ if a.protocol_major:
     pot = (torch.arange(B, dtype=torch.int64, device=dev) * a.prot // B).to(torch.int32)
 out = {}
 ms = []
+sse_ref = torch.zeros((a.prot, Nt), dtype=torch.float64, device=dev) if a.sse else None
 for rep in range(a.reps + 1):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     r = ion.capi.dopri5(model, params, pv, y0t, te, prot_t0=0.0, prot_dt=0.1, prot_of_traj=pot, current=a.current,
                         mlp_packed=packed, mlp_layers=a.layers if packed is not None else 0,
-                        mlp_width=a.width if packed is not None else 0, t_eval_hint=(0.0, 0.1), out=out)
+                        mlp_width=a.width if packed is not None else 0, t_eval_hint=(0.0, 0.1), out=None if a.sse else out,
+                        sse_ref=sse_ref, states=not a.sse)
     e1.record()
     torch.cuda.synchronize()
-    out.update({k: r[k] for k in ("y", "i", "status", "stats")})
+    if not a.sse:
+        out.update({k: r[k] for k in ("y", "i", "status", "stats")})
     if rep:
         ms.append(e0.elapsed_time(e1))
 st = r["stats"].cpu().numpy()
 s = 4 if a.f32 else 8
-bytes_traj = Nt * D * s + (Nt * 8 if a.current else 0)
+bytes_traj = (0 if a.sse else Nt * D * s) + (Nt * 8 if a.current else 0)
 total = B * bytes_traj + a.prot * Nt * 8
 t = float(np.mean(ms)) * 1e-3
-print(json.dumps({"kernel": ion.capi.kernel_name(r["desc"]), "B": B, "Nt": Nt, "ms": t * 1e3, "traj_per_s": B / t,
+print(json.dumps({"kernel": ion.r["kernel"], "B": B, "Nt": Nt, "ms": t * 1e3, "traj_per_s": B / t,
                   "GBps_algorithmic": total / t / 1e9, "frac_of_8TBps": total / t / 8e12, "mean_nfe": float(st[:, 2].mean()),
                   "max_nfe": float(st[:, 2].max()), "ok": int((r["status"].cpu().numpy() == 0).sum())}))
