@@ -1097,12 +1097,26 @@ __global__ void __launch_bounds__(64 * G, IONODE_CF_WAVES(MODEL, G)) ionode_dopr
       // closed-form kernels on a verified uniform output grid form t_k arithmetically (bit-equal to the t_eval entry)
       const bool arith_t = !MT::MLP && a.te_exact;
       double tk_nxt = (em && o + lane < Nt) ? (arith_t ? te_at(o + lane) : a.t_eval[o + lane]) : 0.0;
+      // table variant: V(t_k) and the reference current of the next trajectory's first chunk are in flight as well
+      double vk_nxt = 0.0, rf_nxt = 0.0;
+      auto prefetch_obs = [&](int jx, int ox) {
+        if constexpr (VTAB) {
+          const int pjx = __builtin_amdgcn_readlane(pidx, jx);
+          if (ox + lane < Nt) {
+            vk_nxt = a.v_tab[(size_t)pjx * Nt + ox + lane];
+            if (a.sse_out) rf_nxt = a.sse_ref[(size_t)pjx * Nt + ox + lane];
+          }
+        }
+      };
+      if (em) prefetch_obs(jj, o);
       while (em) {
         em &= em - 1;
         const int jn = em ? __builtin_ctzll(em) : 0;
         const int on = __builtin_amdgcn_readlane(oi, jn);
         double tk = tk_nxt;
+        const double vk_first = vk_nxt, rf_first = rf_nxt;
         if (em && on + lane < Nt) tk_nxt = arith_t ? te_at(on + lane) : a.t_eval[on + lane];  // next trajectory's first chunk, in flight meanwhile
+        if (em) prefetch_obs(jn, on);
         const int n = __builtin_amdgcn_readlane(n_out, jj);
         double t0b, denb, rdenb;
         S cb[5][D];
@@ -1156,14 +1170,14 @@ __global__ void __launch_bounds__(64 * G, IONODE_CF_WAVES(MODEL, G)) ionode_dopr
             if (yo) store_state<S, D>(yo + (size_t)idx * D, out);
             if (pvb) {
               double vk;
-              if constexpr (VTAB) vk = vtb[idx];  // == protocol_v(a, pvb, t_eval[idx]), evaluated once per protocol by the pre-pass
+              if constexpr (VTAB) vk = (c0 == 0) ? vk_first : vtb[idx];  // == protocol_v(a, pvb, t_eval[idx]), evaluated once per protocol by the pre-pass
               else protocol_v(a, pvb, tk, vk);
               S gate;
               if (a.obs_open) gate = out[D - 1]; else gate = out[0] * out[1];
               if (a.obs_g != 1.0) gate = (S)a.obs_g * gate;
               const double ik = (double)gate * (vk - a.obs_e);
               if (io) io[idx] = ik;
-              if (refb) { const double rr = ik - refb[idx]; sacc += rr * rr; }
+              if (refb) { const double rr = ik - ((VTAB && c0 == 0) ? rf_first : refb[idx]); sacc += rr * rr; }
             }
           }
         }

@@ -77,6 +77,6 @@ s = 4 if a.f32 else 8
 bytes_traj = (0 if a.sse else Nt * D * s) + (Nt * 8 if a.current else 0)
 total = B * bytes_traj + a.prot * Nt * 8
 t = float(np.mean(ms)) * 1e-3
-print(json.dumps({"kernel": ion.r["kernel"], "B": B, "Nt": Nt, "ms": t * 1e3, "traj_per_s": B / t,
+print(json.dumps({"kernel": r["kernel"], "B": B, "Nt": Nt, "ms": t * 1e3, "traj_per_s": B / t,
                   "GBps_algorithmic": total / t / 1e9, "frac_of_8TBps": total / t / 8e12, "mean_nfe": float(st[:, 2].mean()),
                   "max_nfe": float(st[:, 2].max()), "ok": int((r["status"].cpu().numpy() == 0).sum())}))
