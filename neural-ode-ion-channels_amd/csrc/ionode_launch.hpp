@@ -31,13 +31,10 @@ hipError_t launch(const KArgs &a, unsigned grid, size_t lds, hipStream_t s) {
     MODEL, F32, G, RT, NT, PD, TAIL, &launch<MODEL, S, G, RT, NT, PD, TAIL>,                          \
         "ionode_dopri5_kernel<" #MODEL ", " #S ", " #G ", " #RT ", " #NT ", " #PD ", " #TAIL ">" \
   }
-#ifndef IONODE_TAIL13
-#define IONODE_TAIL13 0
-#endif
 // the MLP shapes of the reference's architectures/s00-s11.py: N = 10, 100, 200, 500
 #define IONODE_MLP_VARIANTS(MODEL, S, F32)                                                      \
   IONODE_VARIANT(MODEL, S, F32, 1, 1, 1, 1, 0), IONODE_VARIANT(MODEL, S, F32, 4, 4, 7, 7, 0),        \
-      IONODE_VARIANT(MODEL, S, F32, 4, 4, 13, 13, IONODE_TAIL13), IONODE_VARIANT(MODEL, S, F32, 4, 8, 32, 4, 0)
+      IONODE_VARIANT(MODEL, S, F32, 4, 4, 13, 13, 0), IONODE_VARIANT(MODEL, S, F32, 4, 8, 32, 4, 0)
 
 // one table per translation unit (they compile in parallel)
 const Variant *variants_closed(int *n);

@@ -16,7 +16,7 @@ from . import batched, capi, distributed
 
 def population_sum_of_squares(candidates, protocols_v, data_i, t_eval, *, base_params, free=(0, 1, 2, 3), prot_t0=0.0,
                               prot_dt=0.1, y0=(0.0, 1.0), state_dtype=torch.float32, obs_g=1.0, obs_e=-86.0,
-                              max_total_steps=1_000_000, group=None, device=None, solver=None, fused=True):
+                              max_total_steps=1_000_000, group=None, device=None, solver=None, fused=True, cost=None):
     """Sum-of-squares error of every candidate over all protocols (PINTS SumOfSquaresError on a multi-output problem).
 
     candidates  [C, len(free)]  values of the free rate parameters (train-d0.py: p1..p4 -> free = (0, 1, 2, 3))
@@ -26,6 +26,8 @@ def population_sum_of_squares(candidates, protocols_v, data_i, t_eval, *, base_p
     fused (default): the squared residuals are accumulated inside the kernel (ionode_desc.sse_ref / sse_out) and neither states
     nor current traces are written -- the only way BASELINE configs[3] fits (65 536 candidates x 32 sweeps x 1e5 samples would be
     4.5 TB of traces); fused=False stores the traces and reduces them with torch (same values to ~1e-13, for tests).
+    cost (optional, [C]): predicted cost per candidate (e.g. the previous generation's step counts): the candidates are then
+    cut into contiguous shards of equal cost rather than equal count (distributed.shard_bounds_by_cost).
     `solver` (tests only): a stand-in with batched.solve's signature, so the sharding / all-gather logic can run under
     gloo on a box without a GPU; the product default is the HIP solve and there is no CPU fallback.
     """
@@ -34,7 +36,9 @@ def population_sum_of_squares(candidates, protocols_v, data_i, t_eval, *, base_p
     C, P = cand.shape[0], np.asarray(protocols_v).shape[0]
     on = dist.is_available() and dist.is_initialized()
     rank, world = (dist.get_rank(group), dist.get_world_size(group)) if on else (0, 1)
-    lo, hi = distributed.shard_bounds(C, rank, world)
+    bounds = [distributed.shard_bounds(C, r, world) for r in range(world)] if cost is None \
+        else distributed.shard_bounds_by_cost(cost, world)
+    lo, hi = bounds[rank]
     dev = batched._dev(device) if solver is None else torch.device(device or "cpu")
     solve = batched.solve if solver is None else solver
     sse = torch.full((hi - lo,), float("inf"), dtype=torch.float64, device=dev)
@@ -59,10 +63,9 @@ def population_sum_of_squares(candidates, protocols_v, data_i, t_eval, *, base_p
     if world == 1:
         return sse
     # all-gather of unequal shards: pad to the largest shard
-    m = (C + world - 1) // world
+    m = max(b[1] - b[0] for b in bounds)
     pad = torch.full((m,), float("inf"), dtype=torch.float64, device=dev)
     pad[: hi - lo] = sse
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad, group=group)
-    return torch.cat([parts[r][: distributed.shard_bounds(C, r, world)[1] - distributed.shard_bounds(C, r, world)[0]]
-                      for r in range(world)])
+    return torch.cat([parts[r][: bounds[r][1] - bounds[r][0]] for r in range(world)])

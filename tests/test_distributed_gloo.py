@@ -112,7 +112,7 @@ def _oracle_solver(oracle):
     return solve
 
 
-def _objective_worker(rank, world, port, q):
+def _objective_worker(rank, world, port, q, cost=None):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -124,14 +124,15 @@ def _objective_worker(rank, world, port, q):
     d = dist_mod.init_process_group()
     cand, pv, te, data = _objective_problem()
     sse = obj.population_sum_of_squares(cand, pv, data, te, base_params=K.P_NN_D, prot_t0=0.0, prot_dt=1.0,
-                                        solver=_oracle_solver(oracle), device="cpu")
+                                        solver=_oracle_solver(oracle), device="cpu", cost=cost)
     q.put((rank, sse.numpy().tolist()))
     d.barrier()
     d.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-def test_population_objective_all_gather_of_unequal_shards(oracle):
+@pytest.mark.parametrize("cost", [None, [1.0, 1.0, 1.0, 5.0, 1.0]])   # equal-count shards 3 + 2; equal-cost shards 4 + 1
+def test_population_objective_all_gather_of_unequal_shards(oracle, cost):
     obj = importlib.import_module("neural-ode-ion-channels_amd.objective")
     cand, pv, te, data = _objective_problem()
     want = obj.population_sum_of_squares(cand, pv, data, te, base_params=K.P_NN_D, prot_t0=0.0, prot_dt=1.0,
@@ -140,7 +141,7 @@ def test_population_objective_all_gather_of_unequal_shards(oracle):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_objective_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_objective_worker, args=(r, 2, port, q, cost)) for r in range(2)]
     for p in procs:
         p.start()
     got = dict(q.get(timeout=240) for _ in range(2))

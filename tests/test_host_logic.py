@@ -171,6 +171,16 @@ def test_shard_bounds(ion):
             assert all(cuts[i][1] == cuts[i + 1][0] for i in range(w - 1))
             sizes = [hi - lo for lo, hi in cuts]
             assert max(sizes) - min(sizes) <= 1
+    # equal-cost shards: contiguous, covering, and no shard heavier than the ideal share plus its own heaviest item
+    rng = np.random.default_rng(0)
+    for n, w in ((1, 2), (5, 2), (1000, 8), (4097, 3)):
+        cost = rng.uniform(1.0, 3.0, n)
+        cuts = dist.shard_bounds_by_cost(cost, w)
+        assert cuts[0][0] == 0 and cuts[-1][1] == n and all(cuts[i][1] == cuts[i + 1][0] for i in range(w - 1))
+        for lo, hi in cuts:
+            assert cost[lo:hi].sum() <= cost.sum() / w + cost.max() + 1e-9
+    assert dist.shard_bounds_by_cost([1.0, 1.0, 1.0, 5.0, 1.0], 2) == [(0, 4), (4, 5)]
+    assert dist.shard_bounds_by_cost([0.0, 0.0, 0.0], 2) == [(0, 2), (2, 3)]           # no information: equal counts
 
 
 def test_lpt_order_is_a_stable_descending_permutation(ion):
