@@ -189,3 +189,38 @@ def test_gradient_of_unsupported_shapes_is_refused(ion, gpu):
                               torch.tensor([[0.0, 1.0]], dtype=torch.float64, device=gpu),
                               torch.arange(10, dtype=torch.float64, device=gpu), mlp_layers=5, mlp_width=500)
         y.sum().backward()
+
+
+def test_config5_share_at_full_size_gradient_is_additive(ion, gpu):
+    """BASELINE configs[4], one GPU's share at full size (1024 of the 8192 trajectories, fp32 state, 100 001 samples): no
+    checker runs at this size, but the loss is a sum over trajectories, so dL/dW of the whole share must equal the sum of the
+    two half-shares' gradients (different chunking, different split-K order: fp32 accumulation tolerance 2e-5), the forward
+    states must be the ordinary forward's bits, and the gradient must be finite and non-trivial."""
+    P = ion.protocols
+    B, Nt = 1024, 100001
+    pv = P.sinewave(P.sinewave_scales(0, B), n_samples=Nt, dt=0.1, xp=torch, device=gpu)
+    te = torch.arange(Nt, dtype=torch.float64, device=gpu) * 0.1
+    vobs = pv + 86.0
+    weights = K.load_weights("s1")
+    params = torch.from_numpy(np.tile(K.P_HH, (B, 1))).to(gpu)
+    y0 = torch.tensor([[0.0, 1.0]], dtype=torch.float32, device=gpu).repeat(B, 1)
+
+    def grad_of(lo, hi):
+        w = torch.from_numpy(weights.copy()).to(gpu).requires_grad_(True)
+        y, status = ion.grad.solve(K.MODEL_NNF, w, params[lo:hi], pv[lo:hi], y0[lo:hi], te, mlp_layers=5, mlp_width=200,
+                                   prot_t0=0.0, prot_dt=0.1, t_eval_hint=(0.0, 0.1))
+        assert bool((status == 0).all())
+        ((y[..., 0] * y[..., 1]).double() * vobs[lo:hi]).abs().sum().backward()      # sum_b sum_k |i_bk|  (train-s1.py:329 x N)
+        probe = y[:4, ::1000].detach().clone()
+        del y
+        torch.cuda.empty_cache()
+        return w.grad.double(), probe
+
+    g_all, probe = grad_of(0, B)
+    g_a, _ = grad_of(0, B // 2)
+    g_b, _ = grad_of(B // 2, B)
+    assert bool(torch.isfinite(g_all).all()) and float(g_all.norm()) > 0
+    assert float((g_all - (g_a + g_b)).norm() / g_all.norm()) < 2e-5
+    plain = ion.solve(K.MODEL_NNF, params[:4], pv[:4], y0[:4], te, weights=weights, mlp_layers=5, mlp_width=200, prot_t0=0.0,
+                      prot_dt=0.1, t_eval_hint=(0.0, 0.1))
+    assert torch.equal(plain.y[:, ::1000], probe)
