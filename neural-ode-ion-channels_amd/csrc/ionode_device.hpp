@@ -665,6 +665,68 @@ __device__ __forceinline__ void rhs(const KArgs &a, const double *p, double v, b
   }
 }
 
+// Closed-form models, split form of rhs(): the rate constants depend on the stage VOLTAGE only, and the last two stages of a
+// dopri5 attempt share their time (alpha = 1, 1), so the integrator evaluates them once for both (4 of 24 exp per attempt for
+// the 2-state model, 12 of 72 for the 6-state model).  Same expressions as rhs(), same bits.
+template <int MODEL> struct ClosedRates {
+  static constexpr int NR = (MODEL == IONODE_MODEL_MARKOV6) ? 6 : 4;
+  double k[NR];
+  float kf[NR];
+  bool oob32;
+};
+template <int MODEL, typename S>
+__device__ __forceinline__ void closed_rates(const KArgs &a, const double *p, double v, bool inrange, ClosedRates<MODEL> &R) {
+  constexpr int NR = ClosedRates<MODEL>::NR;
+  R.oob32 = (sizeof(S) == 4) && !inrange;
+  if (R.oob32) {
+    const float vf = (float)a.v_oob;  // int64 tensor([-80]): `p * v` is float32 and exp runs in fp32
+#pragma unroll
+    for (int i = 0; i < NR; ++i) R.kf[i] = (float)p[2 * i] * det_expf((float)((i & 1) ? -p[2 * i + 1] : p[2 * i + 1]) * vf);
+  } else {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) R.k[i] = p[2 * i] * det_exp(((i & 1) ? -p[2 * i + 1] : p[2 * i + 1]) * v);
+  }
+}
+template <int MODEL, typename S>
+__device__ __forceinline__ void closed_rhs(const ClosedRates<MODEL> &R, const S *y, S *f) {
+  if constexpr (MODEL == IONODE_MODEL_MARKOV6) {
+    if (R.oob32) {
+      const float a1 = R.kf[0], b1 = R.kf[1], bh = R.kf[2], ah = R.kf[3], a2 = R.kf[4], b2 = R.kf[5];
+      const float c1 = y[0], c2 = y[1], i_ = y[2], ic1 = y[3], ic2 = y[4], o = y[5];
+      f[0] = a1 * c2 + ah * ic1 + b2 * o - (b1 + bh + a2) * c1;
+      f[1] = b1 * c1 + ah * ic2 - (a1 + bh) * c2;
+      f[2] = a2 * ic1 + bh * o - (b2 + ah) * i_;
+      f[3] = a1 * ic2 + bh * c1 + b2 * i_ - (b1 + ah + a2) * ic1;
+      f[4] = b1 * ic1 + bh * c2 - (ah + a1) * ic2;
+      f[5] = a2 * c1 + ah * i_ - (b2 + bh) * o;
+      return;
+    }
+    const double a1 = R.k[0], b1 = R.k[1], bh = R.k[2], ah = R.k[3], a2 = R.k[4], b2 = R.k[5];
+    const double c1 = y[0], c2 = y[1], i_ = y[2], ic1 = y[3], ic2 = y[4], o = y[5];
+    f[0] = (S)(a1 * c2 + ah * ic1 + b2 * o - (b1 + bh + a2) * c1);
+    f[1] = (S)(b1 * c1 + ah * ic2 - (a1 + bh) * c2);
+    f[2] = (S)(a2 * ic1 + bh * o - (b2 + ah) * i_);
+    f[3] = (S)(a1 * ic2 + bh * c1 + b2 * i_ - (b1 + ah + a2) * ic1);
+    f[4] = (S)(b1 * ic1 + bh * c2 - (ah + a1) * ic2);
+    f[5] = (S)(a2 * c1 + ah * i_ - (b2 + bh) * o);
+  } else {
+    const S av = y[0], rv = y[1];
+    if (R.oob32) {
+      const float af = (float)av, rf = (float)rv;
+      const float drdt = -R.kf[2] * rf + R.kf[3] * (1.0f - rf);
+      const float dadt = R.kf[0] * (1.0f - af) - R.kf[1] * af;
+      f[0] = (S)dadt;
+      f[1] = (S)drdt;
+      return;
+    }
+    const S one_m_a = (S)1 - av, one_m_r = (S)1 - rv;
+    const double drdt = -R.k[2] * (double)rv + R.k[3] * (double)one_m_r;
+    const double dadt = R.k[0] * (double)one_m_a - R.k[1] * (double)av;
+    f[0] = (S)dadt;
+    f[1] = (S)drdt;
+  }
+}
+
 template <typename S, int D> __device__ __forceinline__ S rms_norm(const S *x) {
   S s = x[0] * x[0];
 #pragma unroll
@@ -908,6 +970,7 @@ __global__ void __launch_bounds__(64 * G, IONODE_CF_WAVES(MODEL, G)) ionode_dopr
     for (int d = 0; d < D; ++d) k[0][d] = f[d];
     // stage voltages: pure functions of (t0, dt), so all protocol loads are issued ahead of the stages
     if constexpr (!CARRY_V) lookup_stages(t0, dt);
+    ClosedRates<MT::MLP ? IONODE_MODEL_HH2 : MODEL> cr;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       S bd[6];
@@ -920,7 +983,11 @@ __global__ void __launch_bounds__(64 * G, IONODE_CF_WAVES(MODEL, G)) ionode_dopr
         for (int jx = 1; jx <= i; ++jx) s = s + k[jx][d] * bd[jx];
         yi[d] = y[d] + s;
       }
-      rhs<MODEL, S>(a, p, vst[i < 4 ? i : 4], inst[i < 4 ? i : 4], yi, k[i + 1], mlp);
+      if constexpr (MT::MLP) rhs<MODEL, S>(a, p, vst[i < 4 ? i : 4], inst[i < 4 ? i : 4], yi, k[i + 1], mlp);
+      else {
+        if (i < 5) closed_rates<MODEL, S>(a, p, vst[i], inst[i], cr);  // i == 5: same stage time as i == 4, same rates
+        closed_rhs<MODEL, S>(cr, yi, k[i + 1]);
+      }
     }
     // y1 = y_5 (c_sol == beta[5] + [0]); error estimate; _compute_error_ratio
     S tmp[D];
