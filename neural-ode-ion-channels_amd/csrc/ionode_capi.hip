@@ -49,9 +49,12 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false) {
   if (!(d->rtol > 0) || !(d->atol >= 0) || !(d->prot_dt > 0)) { set_err("rtol/atol/prot_dt must be positive"); return IONODE_ERR_ARG; }
   const int f32 = d->state_f32 ? 1 : 0;
   if (!mlp) {
-    // small batches: 16 trajectories per wavefront (4x the wavefronts); >= 2 wavefronts per SIMD at 64 per wavefront
-    // needs 131072 trajectories.  tile_waves = 64 / 16 forces a choice (tests).
-    const int tpw = (d->tile_waves == 64 || d->tile_waves == 16) ? d->tile_waves : (d->n_traj >= 131072 ? 64 : 16);
+    // small batches: 16 trajectories per wavefront (lanes replicated 4x, 4x the wavefronts) until the chip's resident
+    // wavefront slots (3 per SIMD for the 2-state, 1 for the 6-state kernel) are well over-subscribed; measured crossovers
+    // (tools/ab_tpw.sh, 20 001 samples): 2-state between 65 536 and 98 304 trajectories, 6-state between 32 768 and 65 536
+    // (65 536: 58.9 ms at 64 per wavefront against 93.4 ms at 16).  tile_waves = 64 / 16 forces a choice (tests).
+    const int tpw64_from = (D == 6) ? 40960 : 81920;
+    const int tpw = (d->tile_waves == 64 || d->tile_waves == 16) ? d->tile_waves : (d->n_traj >= tpw64_from ? 64 : 16);
     // deferred aligned emission (2-state models): the output grid must be VERIFIED uniform and no current trace requested
     // ... or, with a current trace / fused objective and the protocol-at-outputs table given, the table variant (hint path)
     const int defer = (want_current && d->v_at_outputs && d->t_eval_dt_hint > 0.0 && d->n_out > 1) ? 2

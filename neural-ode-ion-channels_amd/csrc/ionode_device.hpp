@@ -736,11 +736,13 @@ template <typename S, int D> __device__ __forceinline__ S rms_norm(const S *x) {
 }
 template <typename S> __device__ __forceinline__ S abs_(S x) { return x < 0 ? -x : x; }
 
-// Closed-form kernels are latency/issue bound at 64 trajectories per wavefront: the register budget is set for 4 (2-state)
-// or 2 (6-state) wavefronts per SIMD, so that the 4096 wavefronts of a 262 144-trajectory launch are all resident at once
-// (at 3 per SIMD a quarter of them ran in a second, nearly empty round).  MLP tiles: 1 per SIMD (512 registers).
+// Closed-form kernels are fp64-issue bound at 64 trajectories per wavefront.  2-state: the register budget is set for 3
+// wavefronts per SIMD (168 VGPRs, 4-12 spilled dwords) -- best from ~160 k trajectories up (2 per SIMD, 238 VGPRs and no spill,
+// wins by 20 % at 131 072 and loses by 25 % at 196 608; 4 per SIMD spills 43 dwords and loses).  6-state: ONE wavefront per
+// SIMD (the whole 512-register file): at 2 per SIMD it spilled 48 dwords into scratch inside the stage loop and ran 1.6x
+// (65 536 trajectories) to 2x (16 384) slower; from 131 072 trajectories the two are equal.  MLP tiles: 1 per SIMD.
 #ifndef IONODE_CF_WAVES
-#define IONODE_CF_WAVES(MODEL, G) ((G) > 1 ? 1 : ((MODEL) == IONODE_MODEL_HH2 ? 3 : ((MODEL) == IONODE_MODEL_MARKOV6 ? 2 : 1)))
+#define IONODE_CF_WAVES(MODEL, G) ((G) > 1 ? 1 : ((MODEL) == IONODE_MODEL_HH2 ? 3 : 1))
 #endif
 
 template <typename S, int D> __device__ __forceinline__ void store_state(S *dst, const S *v) {

@@ -27,6 +27,7 @@ ap.add_argument("--model", default="hh", choices=["hh", "m6", "nnf"])
 ap.add_argument("--width", type=int, default=10, help="nnf: MLP width N")
 ap.add_argument("--layers", type=int, default=5, help="nnf: hidden layers L")
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--tpw", type=int, default=0, help="closed-form: trajectories per wavefront, 64 or 16 (0 = dispatcher default)")
 ap.add_argument("--protocol-major", action="store_true", help="trajectories of one protocol adjacent (lanes of a wavefront share it)")
 a = ap.parse_args()
 
@@ -62,7 +63,7 @@ sse_ref = torch.zeros((a.prot, Nt), dtype=torch.float64, device=dev) if a.sse el
 for rep in range(a.reps + 1):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    r = ion.capi.dopri5(model, params, pv, y0t, te, prot_t0=0.0, prot_dt=0.1, prot_of_traj=pot, current=a.current,
+    r = ion.capi.dopri5(model, params, pv, y0t, te, prot_t0=0.0, prot_dt=0.1, prot_of_traj=pot, current=a.current, tile_waves=a.tpw,
                         mlp_packed=packed, mlp_layers=a.layers if packed is not None else 0,
                         mlp_width=a.width if packed is not None else 0, t_eval_hint=(0.0, 0.1), out=None if a.sse else out,
                         sse_ref=sse_ref, states=not a.sse)
