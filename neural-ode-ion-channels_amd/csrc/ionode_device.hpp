@@ -924,7 +924,7 @@ __global__ void __launch_bounds__(64 * G, IONODE_CF_WAVES(MODEL, G)) ionode_dopr
 #ifndef IONODE_CARRY_V_MLP
 #define IONODE_CARRY_V_MLP 0  // tried for the MLP kernels too: +1 % time (372.6 -> 376.2 ms same box), kept off
 #endif
-  constexpr bool CARRY_V = (!MT::MLP && D == 2) || (MT::MLP && IONODE_CARRY_V_MLP);  // (the 6-state kernel has no registers to spare for it: +50 % time when tried)
+  constexpr bool CARRY_V = (!MT::MLP && D == 2) || (MT::MLP && IONODE_CARRY_V_MLP);  // (6-state: +50 % at 2 wavefronts per SIMD, no change at 1 per SIMD -- 38.0 vs 37.9 ms)
   if constexpr (CARRY_V) lookup_stages(t, dt);
 
   for (;;) {
