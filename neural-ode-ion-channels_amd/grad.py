@@ -172,7 +172,7 @@ class _Solve(torch.autograd.Function):
 
 def solve(model, weights_flat, params, prot_v, y0, t_eval, *, mlp_layers, mlp_width, prot_t=None, prot_t0=0.0,
           prot_dt=1.0, prot_of_traj=None, rtol=1e-7, atol=1e-9, v_oob=-80.0, max_steps=0, max_total_steps=0, max_step=0.0,
-          ckpt_cap=None, record_budget_bytes=None, weights_key=None, t_eval_hint="auto"):
+          ckpt_cap=None, record_budget_bytes=None, weights_key=None, t_eval_hint="auto", order=None):
     """Differentiable batched solve.  weights_flat [n] fp32 (reference state-dict order), params [B, 8] fp64, y0 [B, 2]
     fp32 | fp64 (the state dtype) -- device tensors, any of which may require grad; prot_v [P, Np], t_eval [Nt] fp64 device
     tensors.  Returns (y [B, Nt, 2], status [B]): gradients of failed trajectories (status != 0) are zero.
@@ -181,11 +181,24 @@ def solve(model, weights_flat, params, prot_v, y0, t_eval, *, mlp_layers, mlp_wi
     outside its stability region (the error estimate of a state AT equilibrium is ~0); the forward solve copes through
     rejections, but the exact derivative of those accepted-but-unstable steps multiplies the adjoint by |R(h*lambda)| >> 1
     per step (measured on the 10 s sine-wave protocol, fp32 state: |dL/dp| ~ 1e36 while dL/dW, whose state `a` is not
-    stiff, stays O(100)).  max_step < 3.3 / lambda_max -- 10 ms for the reference's rate constants -- keeps it bounded."""
+    stiff, stays O(100)).  max_step < 3.3 / lambda_max -- 10 ms for the reference's rate constants -- keeps it bounded.
+
+    order (optional permutation of range(B), schedule.lpt_order): launch slot k integrates trajectory order[k] (homogeneous
+    tiles, expensive tiles first -- pays from two tiles per compute unit, B > 4096); y and status are then in LAUNCH order
+    (row k = trajectory order[k]), and the gradients still arrive at params / y0 in the caller's order (the gather is part of
+    the autograd graph)."""
     if model not in (capi.MODEL_NNF, capi.MODEL_NND):
         raise NotImplementedError("gradients through the solve are built for the NN-f / NN-d right-hand sides")
     if not (isinstance(y0, torch.Tensor) and y0.is_cuda):
         raise capi.IonodeError("no HIP tensors: the integrator and its backward sweep have no CPU path")
+    if order is not None:
+        order = torch.as_tensor(order, dtype=torch.int64, device=y0.device)
+        B = y0.shape[0]
+        if order.shape != (B,):
+            raise capi.IonodeError(f"order must be a permutation of range({B})")
+        params, y0 = params.index_select(0, order), y0.index_select(0, order)
+        pot = prot_of_traj if prot_of_traj is not None else (torch.arange(B, device=y0.device) % prot_v.shape[0]).to(torch.int32)
+        prot_of_traj = torch.as_tensor(pot, device=y0.device).index_select(0, order).to(torch.int32).contiguous()
     cfg = dict(model=model, mlp_layers=int(mlp_layers), mlp_width=int(mlp_width), prot_v=prot_v, prot_t=prot_t,
                prot_t0=float(prot_t0), prot_dt=float(prot_dt), prot_of_traj=prot_of_traj, t_eval=t_eval, rtol=float(rtol),
                atol=float(atol), v_oob=float(v_oob), max_steps=int(max_steps), max_total_steps=int(max_total_steps),

@@ -224,3 +224,29 @@ def test_config5_share_at_full_size_gradient_is_additive(ion, gpu):
     plain = ion.solve(K.MODEL_NNF, params[:4], pv[:4], y0[:4], te, weights=weights, mlp_layers=5, mlp_width=200, prot_t0=0.0,
                       prot_dt=0.1, t_eval_hint=(0.0, 0.1))
     assert torch.equal(plain.y[:, ::1000], probe)
+
+
+def test_launch_order_leaves_gradients_in_the_callers_order(ion, gpu):
+    """grad.solve(order=perm): states come back in launch order, gradients at params / y0 / weights in the caller's order
+    (bit-identical per trajectory for dL/dp and dL/dy0, which are accumulated per trajectory; dL/dW sums over trajectories in
+    a different order: 1e-5)."""
+    pv, te, params, pot, y0, coef = F.problem("s1")
+    B = params.shape[0]
+    order = torch.from_numpy(np.random.default_rng(4).permutation(B)).to(gpu)
+
+    def run(order_):
+        w = torch.from_numpy(K.load_weights("s1").copy()).to(gpu).requires_grad_(True)
+        p = torch.from_numpy(params).to(gpu).requires_grad_(True)
+        y0t = torch.from_numpy(y0).to(gpu).requires_grad_(True)
+        y, status = ion.grad.solve(F.CASES["s1"], w, p, torch.from_numpy(pv).to(gpu), y0t, torch.from_numpy(te).to(gpu),
+                                   mlp_layers=K.MLP_L, mlp_width=K.MLP_N, prot_t0=0.0, prot_dt=1.0,
+                                   prot_of_traj=torch.from_numpy(pot).to(gpu), order=order_)
+        c = torch.from_numpy(coef).to(gpu)
+        (y.double() * (c if order_ is None else c.index_select(0, order_))).sum().backward()
+        return y.detach(), w.grad.double(), p.grad, y0t.grad
+
+    ya, gwa, gpa, gya = run(None)
+    yb, gwb, gpb, gyb = run(order)
+    assert torch.equal(yb, ya.index_select(0, order))
+    assert torch.equal(gpa, gpb) and torch.equal(gya, gyb)
+    assert float((gwa - gwb).norm() / gwa.norm()) < 1e-5
