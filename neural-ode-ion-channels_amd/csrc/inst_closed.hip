@@ -15,6 +15,13 @@ static const Variant kTab[] = {
     IONODE_VARIANT(1, double, 0, 1, 0, 0, 0, 2),  IONODE_VARIANT(1, float, 1, 1, 0, 0, 0, 2),
     IONODE_VARIANT(0, double, 0, 1, 16, 0, 0, 2), IONODE_VARIANT(0, float, 1, 1, 16, 0, 0, 2),
     IONODE_VARIANT(1, double, 0, 1, 16, 0, 0, 2), IONODE_VARIANT(1, float, 1, 1, 16, 0, 0, 2),
+    // NT slot 2: the 2-state kernels again at 2 wavefronts per SIMD (no register spill), dispatched when the launch is at most 2048 wavefronts
+    IONODE_VARIANT(0, double, 0, 1, 0, 2, 0, 0),  IONODE_VARIANT(0, float, 1, 1, 0, 2, 0, 0),
+    IONODE_VARIANT(0, double, 0, 1, 16, 2, 0, 0), IONODE_VARIANT(0, float, 1, 1, 16, 2, 0, 0),
+    IONODE_VARIANT(0, double, 0, 1, 0, 2, 0, 1),  IONODE_VARIANT(0, float, 1, 1, 0, 2, 0, 1),
+    IONODE_VARIANT(0, double, 0, 1, 16, 2, 0, 1), IONODE_VARIANT(0, float, 1, 1, 16, 2, 0, 1),
+    IONODE_VARIANT(0, double, 0, 1, 0, 2, 0, 2),  IONODE_VARIANT(0, float, 1, 1, 0, 2, 0, 2),
+    IONODE_VARIANT(0, double, 0, 1, 16, 2, 0, 2), IONODE_VARIANT(0, float, 1, 1, 16, 2, 0, 2),
 };
 const Variant *variants_closed(int *n) { *n = sizeof(kTab) / sizeof(kTab[0]); return kTab; }
 }  // namespace ionode

@@ -59,7 +59,12 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false) {
     // ... or, with a current trace / fused objective and the protocol-at-outputs table given, the table variant (hint path)
     const int defer = (want_current && d->v_at_outputs && d->t_eval_dt_hint > 0.0 && d->n_out > 1) ? 2
                       : ((D == 2 && d->t_eval_exact && d->t_eval_dt_hint > 0.0 && d->n_out > 1 && !want_current) ? 1 : 0);
-    pl->v = find_variant(d->model, f32, 1, 0, tpw == 64 ? 0 : 16, defer);
+    // 2-state model: the 2-wavefronts-per-SIMD build (NT slot 2: 238 VGPRs, no spill) whenever the launch fits ONE residency
+    // round at 2 per SIMD (2048 wavefronts), else the 3-per-SIMD build (tools/ab_hh.sh, ab_hh2.sh: 131 072 trajectories at 64
+    // per wavefront 19.3 against 24.3 ms; beyond one round the 2-per-SIMD build loses, e.g. 163 839: 32.8 against 24.6 ms)
+    const long long waves = ((long long)d->n_traj + tpw - 1) / tpw;
+    const int wslot = (d->model == IONODE_MODEL_HH2 && waves <= 2048) ? 2 : 0;
+    pl->v = find_variant(d->model, f32, 1, wslot, tpw == 64 ? 0 : 16, defer);
     pl->grid = (unsigned)((d->n_traj + tpw - 1) / tpw);
     pl->block = 64;
     // one interpolant row per lane (dense-output broadcast through LDS) + one tail buffer per trajectory (2-state models)

@@ -736,14 +736,17 @@ template <typename S, int D> __device__ __forceinline__ S rms_norm(const S *x) {
 }
 template <typename S> __device__ __forceinline__ S abs_(S x) { return x < 0 ? -x : x; }
 
-// Closed-form kernels are fp64-issue bound at 64 trajectories per wavefront.  2-state: the register budget is set for 3
-// wavefronts per SIMD (168 VGPRs, 4-12 spilled dwords) -- best from ~160 k trajectories up (2 per SIMD, 238 VGPRs and no spill,
-// wins by 20 % at 131 072 and loses by 25 % at 196 608; 4 per SIMD spills 43 dwords and loses).  6-state: ONE wavefront per
+// Closed-form kernels are fp64-issue bound at 64 trajectories per wavefront.  2-state: 3 wavefronts per SIMD (168 VGPRs, 4-12
+// spilled dwords) for launches beyond one residency round, 2 per SIMD (238 VGPRs, no spill) for launches of at most 2048
+// wavefronts (+20 % at 131 072 trajectories; -25 % at 196 608); 4 per SIMD spills 43 dwords and loses.  6-state: ONE wavefront per
 // SIMD (the whole 512-register file): at 2 per SIMD it spilled 48 dwords into scratch inside the stage loop and ran 1.6x
 // (65 536 trajectories) to 2x (16 384) slower; from 131 072 trajectories the two are equal.  MLP tiles: 1 per SIMD.
 #ifndef IONODE_CF_WAVES
 #define IONODE_CF_WAVES(MODEL, G) ((G) > 1 ? 1 : ((MODEL) == IONODE_MODEL_HH2 ? 3 : 1))
 #endif
+// Closed-form kernels do not use the NT slot of the template: a non-zero value there is an explicit wavefronts-per-SIMD
+// budget (the 2-state kernel is also instantiated at 2: 238 VGPRs, no spill -- the faster build below ~160 k trajectories)
+#define IONODE_WAVES_PER_SIMD(MODEL, G, NT) (((MODEL) == IONODE_MODEL_HH2 && (NT) > 0) ? (NT) : IONODE_CF_WAVES(MODEL, G))
 
 template <typename S, int D> __device__ __forceinline__ void store_state(S *dst, const S *v) {
   if constexpr (D == 2 && sizeof(S) == 8) {
@@ -763,7 +766,7 @@ template <typename S, int D> __device__ __forceinline__ void store_state(S *dst,
 // The integrator.  One workgroup = one tile of TPW trajectories (G wavefronts for MLP models).
 // ---------------------------------------------------------------------------------------------
 template <int MODEL, typename S, int G, int RT, int NT, int PD, int TAIL>
-__global__ void __launch_bounds__(64 * G, IONODE_CF_WAVES(MODEL, G)) ionode_dopri5_kernel(const KArgs a) {
+__global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT)) ionode_dopri5_kernel(const KArgs a) {
   using MT = ModelTraits<MODEL>;
   using R = Real<S>;
   constexpr int D = MT::D, NPAR = MT::NPAR;
