@@ -266,7 +266,9 @@ def closed_form_legs(ion, dev, weights):
                                         # 262 144 is 1.33 rounds (the last third runs on a third-full chip), 393 216 is 2.0
                                         ("hh2_two_full_rounds", capi.MODEL_HH2, P_HH, [0.0, 1.0], 393216, None),
                                         ("markov6", capi.MODEL_MARKOV6, p_m6, [0.0, 1.0, 0, 0, 0, 0], 65536, None),
-                                        ("nnf_s03_5x10", capi.MODEL_NNF, P_HH, [0.0, 1.0], 65536, (w10, L10, N10))):
+                                        ("nnf_s03_5x10", capi.MODEL_NNF, P_HH, [0.0, 1.0], 65536, (w10, L10, N10)),
+                                        # from 73 728 trajectories the N <= 16 nets run one trajectory per lane (64 per wavefront)
+                                        ("nnf_s03_5x10_262144", capi.MODEL_NNF, P_HH, [0.0, 1.0], 262144, (w10, L10, N10))):
         D = len(y0)
         params = torch.from_numpy(p0[None, :] * rng.uniform(0.8, 1.25, (B, p0.size))).to(dev)
         y0t = torch.tensor([y0], dtype=torch.float64, device=dev).repeat(B, 1).contiguous()

@@ -74,7 +74,8 @@ typedef struct ionode_desc {
   double obs_g;        /* observation epilogue i = g * gate * (V(t_k) - obs_e); gate = y0*y1 or y[D-1] */
   double obs_e;
   int32_t obs_open_state_only; /* 1: gate = last state (6-state O, train-d1.py:299) */
-  int32_t tile_waves;  /* tuning, 0 = auto.  MLP models: wavefronts cooperating on one 16-trajectory tile (1, 4).
+  int32_t tile_waves;  /* tuning, 0 = auto.  MLP models: wavefronts cooperating on one 16-trajectory tile (1, 4); N <= 16 nets
+                          also 64 = one trajectory per lane, 64 per wavefront (auto from 73728 trajectories).
                           Closed-form models: trajectories per wavefront (64 or 16; auto = 16 below 81920 (2-state) / 40960 (6-state) trajectories) */
   double *step_log;    /* optional DEVICE buffer [step_log_cap][4] fp64: (t0, dt, error ratio, accepted) of every
                           step attempt of trajectory 0 -- the per-step trace parity tests compare; NULL = off */

@@ -7,6 +7,10 @@
 
 #include "ionode_launch.hpp"
 
+#ifndef IONODE_TINY64_FROM
+#define IONODE_TINY64_FROM 73728  // 16 per wavefront: 32 768 trajectories per residency round of 12.8 ms; 64 per wavefront: 131 072 per round of 30 ms
+#endif
+
 namespace {
 
 thread_local char g_err[256] = "";
@@ -73,17 +77,26 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false) {
     if (d->mlp_width < 1 || d->mlp_layers < 0) { set_err("bad MLP shape"); return IONODE_ERR_ARG; }
     if (d->mlp_width <= 16 && d->mlp_layers > 10) { set_err("N <= 16 kernels keep at most 10 hidden layers resident"); return IONODE_ERR_UNSUPPORTED; }
     const int NP = np_of(d->mlp_width), NT = NP / 16;
-    if (d->tile_waves != 0 && d->tile_waves != 1 && d->tile_waves != 4) { set_err("tile_waves must be 0, 1 or 4 for MLP models"); return IONODE_ERR_UNSUPPORTED; }
-    pl->v = find_variant(d->model, f32, d->tile_waves, NT);
+    if (d->tile_waves != 0 && d->tile_waves != 1 && d->tile_waves != 4 && !(d->tile_waves == 64 && NT == 1)) {
+      set_err("tile_waves must be 0, 1 or 4 for MLP models (64: the N <= 16 kernel at 64 trajectories per wavefront)");
+      return IONODE_ERR_UNSUPPORTED;
+    }
+    // N <= 16 (architectures s03-s05): from IONODE_TINY64_FROM trajectories on, one trajectory per lane (64 per wavefront, four
+    // MFMA column tiles per evaluation) instead of 16 per wavefront with the scalar integrator work replicated over 4 lane groups
+    const bool t64 = NT == 1 && (d->tile_waves == 64 || (d->tile_waves == 0 && d->n_traj >= IONODE_TINY64_FROM));
+    // (deferred aligned emission as for the 2-state closed-form kernels: verified uniform output grid, no current / objective)
+    const int t64defer = (t64 && d->t_eval_exact && d->t_eval_dt_hint > 0.0 && d->n_out > 1 && !want_current) ? 1 : 0;
+    pl->v = t64 ? find_variant(d->model, f32, 1, NT, 64, t64defer) : find_variant(d->model, f32, d->tile_waves, NT, NT == 1 ? 1 : -1);
     if (!pl->v) {
       set_err("MLP width outside the compiled kernel variants: N must pad to 16, 112, 208 or 512 "
               "(architectures s00-s11: N = 10, 100, 200, 500)");
       return IONODE_ERR_UNSUPPORTED;
     }
-    pl->grid = (unsigned)((d->n_traj + 15) / 16);
+    pl->grid = t64 ? (unsigned)((d->n_traj + 63) / 64) : (unsigned)((d->n_traj + 15) / 16);
     pl->block = 64u * pl->v->G;
     const int Gv = pl->v->G, Rv = NT - Gv * (NT / Gv);  // remainder row tiles: K-split partial sums in LDS
     pl->lds = ((size_t)2 * (NT + Gv - 1) * 64 + (size_t)2 * Rv * Gv * 64 + NP) * 16 + ((size_t)d->mlp_layers * NP + NP + 4) * 4;
+    if (t64) pl->lds = ((pl->lds + 15) & ~(size_t)15) + (size_t)64 * (4 + 5 * 2) * 8 + (size_t)64 * 64;  // + interpolant rows + tails
   }
   if (!pl->v) { set_err("no kernel variant compiled for this descriptor"); return IONODE_ERR_UNSUPPORTED; }
   return IONODE_OK;

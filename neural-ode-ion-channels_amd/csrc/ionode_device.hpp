@@ -414,6 +414,54 @@ struct MlpTile {
     return (pair + __shfl_xor(pair, 32)) + wlS[NP];
   }
 
+  // N <= 16 at 64 trajectories per wavefront (one per lane, no replicated scalar work): four 16-column tiles share the
+  // resident weights.  Tile c holds trajectories 16c..16c+15; its layer-0 inputs are gathered from the owning lanes with
+  // ds_bpermute, and its result for column n is the value of lane 16c + n.  Per tile this is eval_tiny() -- same canonical
+  // order, same bits -- and the four tiles' MFMA chains are independent, so they fill each other's latency.
+  __device__ __forceinline__ float eval_tiny64(float x0, float x1) {
+    const int q = lane >> 4, n = lane & 15;
+    f32x4 w0[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w0[r] = W0s[4 * q + r];
+    f32x4 h[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float a0 = __shfl(x0, 16 * c + n), a1 = __shfl(x1, 16 * c + n);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[c][r] = lrelu(fmaf(w0[r][2], a1, fmaf(w0[r][1], a0, w0[r][0])));
+    }
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) {
+      if (l < L) {
+        const f32x4 bias = *reinterpret_cast<const f32x4 *>(biasS + l * NP + 4 * q);
+        f32x4 acc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = bias;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wres[l][r], h[c][r], acc[c], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h[c][r] = lrelu(acc[c][r]);
+      }
+    }
+    const f32x4 w = *reinterpret_cast<const f32x4 *>(wlS + 4 * q);
+    const float bl = wlS[NP];
+    float res = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float part = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part = fmaf(w[r], h[c][r], part);
+      const float pair = part + __shfl_xor(part, 16);
+      const float out = (pair + __shfl_xor(pair, 32)) + bl;
+      if (c == q) res = out;
+    }
+    return res;
+  }
+
   __device__ __forceinline__ float eval(float x0, float x1) {
     if constexpr (TINY) return eval_tiny(x0, x1);
     const int q = lane >> 4;
@@ -579,7 +627,7 @@ struct NoMlp {
 // func.forward(t, y) of the reference, per lane.  The protocol voltage at the stage time (and whether
 // the time was inside the protocol's range) is looked up by the caller, ahead of the stage.
 // ---------------------------------------------------------------------------------------------
-template <int MODEL, typename S, typename MLP>
+template <int MODEL, typename S, bool WIDE = false, typename MLP>
 __device__ __forceinline__ void rhs(const KArgs &a, const double *p, double v, bool inrange, const S *y, S *f,
                                     MLP &mlp) {
   using MT = ModelTraits<MODEL>;
@@ -628,7 +676,8 @@ __device__ __forceinline__ void rhs(const KArgs &a, const double *p, double v, b
     if constexpr (MT::MLP) {
       const float vf = (float)a.v_oob;
       const float nv = oob32 ? vf / 100.0f : (float)(v / 100.0);  // v / self.vrange, then .float()
-      net = mlp.eval(nv, (float)av) / 1000.0f;                     // / self.netscale
+      if constexpr (WIDE) net = mlp.eval_tiny64(nv, (float)av) / 1000.0f;  // 64 trajectories per wavefront (N <= 16)
+      else net = mlp.eval(nv, (float)av) / 1000.0f;                // / self.netscale
     }
 
     if (oob32) {
@@ -746,7 +795,11 @@ template <typename S> __device__ __forceinline__ S abs_(S x) { return x < 0 ? -x
 #endif
 // Closed-form kernels do not use the NT slot of the template: a non-zero value there is an explicit wavefronts-per-SIMD
 // budget (the 2-state kernel is also instantiated at 2: 238 VGPRs, no spill -- the faster build below ~160 k trajectories)
-#define IONODE_WAVES_PER_SIMD(MODEL, G, NT) (((MODEL) == IONODE_MODEL_HH2 && (NT) > 0) ? (NT) : IONODE_CF_WAVES(MODEL, G))
+#ifndef IONODE_T64_WAVES
+#define IONODE_T64_WAVES 1
+#endif
+#define IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT) \
+  (((MODEL) == IONODE_MODEL_HH2 && (NT) > 0) ? (NT) : (((MODEL) >= IONODE_MODEL_NNF && (RT) == 64) ? IONODE_T64_WAVES : IONODE_CF_WAVES(MODEL, G)))
 
 template <typename S, int D> __device__ __forceinline__ void store_state(S *dst, const S *v) {
   if constexpr (D == 2 && sizeof(S) == 8) {
@@ -766,13 +819,20 @@ template <typename S, int D> __device__ __forceinline__ void store_state(S *dst,
 // The integrator.  One workgroup = one tile of TPW trajectories (G wavefronts for MLP models).
 // ---------------------------------------------------------------------------------------------
 template <int MODEL, typename S, int G, int RT, int NT, int PD, int TAIL>
-__global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT)) ionode_dopri5_kernel(const KArgs a) {
+__global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT)) ionode_dopri5_kernel(const KArgs a) {
   using MT = ModelTraits<MODEL>;
   using R = Real<S>;
   constexpr int D = MT::D, NPAR = MT::NPAR;
   // trajectories per wavefront: 16 for MLP tiles (MFMA column count); closed-form kernels: 64 (one per lane), or RT
   // (16: lanes replicated 4x) for small batches, where 4x more wavefronts matter more than lane efficiency
-  constexpr int TPW = MT::MLP ? 16 : (RT > 0 ? RT : 64);
+  // N <= 16 nets also at 64 per wavefront: RT slot == 64 of an MLP kernel (MlpTile::eval_tiny64).  Such a kernel is
+  // "lane-wise" (LW) like the closed-form ones -- one trajectory per lane -- and shares their dense-output machinery:
+  // interpolant rows in LDS (behind the MlpTile region), arithmetic output times, carried stage voltages, deferred aligned
+  // emission (TAIL == 1).
+  constexpr bool T64 = MT::MLP && RT == 64;
+  static_assert(!T64 || (G == 1 && NT == 1), "64 trajectories per wavefront is the resident-weights (N <= 16) path");
+  constexpr bool LW = !MT::MLP || T64;
+  constexpr int TPW = MT::MLP ? (T64 ? 64 : 16) : (RT > 0 ? RT : 64);
   static_assert(MT::MLP || G == 1, "closed-form models use one wavefront per tile");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -785,8 +845,13 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT)) i
   const bool valid = traj_raw < a.B;
   const int traj = valid ? traj_raw : a.B - 1;
 
-  typename std::conditional<MT::MLP, MlpTile<G, (RT > 0 ? RT : 1), (NT > 0 ? NT : 1), (PD > 0 ? PD : 1), TAIL>, NoMlp>::type mlp;
+  using MlpT = MlpTile<G, (T64 ? 1 : (RT > 0 ? RT : 1)), (NT > 0 ? NT : 1), (PD > 0 ? PD : 1), 0>;
+  typename std::conditional<MT::MLP, MlpT, NoMlp>::type mlp;
   if constexpr (MT::MLP) mlp.init(a, smem, wave, lane);
+  // lane-wise kernels: interpolant rows + tail buffers; behind the MlpTile region when there is one
+  size_t lw_off = 0;
+  if constexpr (T64) lw_off = (MlpT::lds_bytes(a.L) + 15) & ~(size_t)15;
+  unsigned char *const lsm = smem + lw_off;
   STAMP_DECL
 #ifdef IONODE_STAMPS
   if constexpr (MT::MLP) mlp.sp = &stamps_;
@@ -811,7 +876,7 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT)) i
   {
     double v0;
     const bool in0 = protocol_v(a, pv, (double)(S)t, v0);
-    rhs<MODEL, S>(a, p, v0, in0, y, f, mlp);  // f0 = func(t[0], y0)
+    rhs<MODEL, S, T64>(a, p, v0, in0, y, f, mlp);  // f0 = func(t[0], y0)
   }
 
   // _select_initial_step (order argument 4), all in the state dtype
@@ -835,7 +900,7 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT)) i
     {
       double v1;
       const bool in1 = protocol_v(a, pv, (double)(t0s + h0), v1);
-      rhs<MODEL, S>(a, p, v1, in1, y1, f1, mlp);
+      rhs<MODEL, S, T64>(a, p, v1, in1, y1, f1, mlp);
     }
 #pragma unroll
     for (int d = 0; d < D; ++d) tmp[d] = (f1[d] - f[d]) / scale[d];
@@ -862,7 +927,7 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT)) i
   //   * stores are whole 64-byte sectors inside 1 KiB-aligned blocks of the row: samples behind the last sector boundary wait
   //     in an LDS tail buffer (< 4 samples per trajectory in fp64) for the next step -- no partial-sector write, no
   //     read-for-ownership.  (64 B, not the 128-B line: 8 KiB of LDS per wavefront instead of 14 keeps 12 wavefronts per CU.)
-  constexpr bool CF2 = !MT::MLP && D == 2;
+  constexpr bool CF2 = LW && D == 2;
   constexpr int LS = 64 / (D * (int)sizeof(S));                      // samples per 64-byte sector, the unit of an L2 -> HBM
                                                                      // write request (TCC_EA0_WRREQ_64B): D == 2: 4 or 8
   constexpr int TAILB = (((LS - 1) * D * (int)sizeof(S)) + 15) & ~15;  // bytes of one trajectory's tail buffer
@@ -874,7 +939,7 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT)) i
   // by the dispatcher when ionode_desc.v_at_outputs is given); a compile-time variant so that neither variant carries the
   // other's code and registers
   constexpr bool VTAB = !MT::MLP && TAIL == 2;
-  unsigned char *const tails = smem + 64 * ROWB;
+  unsigned char *const tails = lsm + 64 * ROWB;
   int ow = 1;  // defer: next sample index of MY trajectory not yet written to HBM (ow <= oi, oi - ow < LS)
   if constexpr (CF2 && defer) {
     ow = 0;
@@ -927,7 +992,7 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT)) i
 #ifndef IONODE_CARRY_V_MLP
 #define IONODE_CARRY_V_MLP 0  // tried for the MLP kernels too: +1 % time (372.6 -> 376.2 ms same box), kept off
 #endif
-  constexpr bool CARRY_V = (!MT::MLP && D == 2) || (MT::MLP && IONODE_CARRY_V_MLP);  // (6-state: +50 % at 2 wavefronts per SIMD, no change at 1 per SIMD -- 38.0 vs 37.9 ms)
+  constexpr bool CARRY_V = (LW && D == 2) || (MT::MLP && IONODE_CARRY_V_MLP);  // (6-state: +50 % at 2 wavefronts per SIMD, no change at 1 per SIMD -- 38.0 vs 37.9 ms)
   if constexpr (CARRY_V) lookup_stages(t, dt);
 
   for (;;) {
@@ -988,7 +1053,7 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT)) i
         for (int jx = 1; jx <= i; ++jx) s = s + k[jx][d] * bd[jx];
         yi[d] = y[d] + s;
       }
-      if constexpr (MT::MLP) rhs<MODEL, S>(a, p, vst[i < 4 ? i : 4], inst[i < 4 ? i : 4], yi, k[i + 1], mlp);
+      if constexpr (MT::MLP) rhs<MODEL, S, T64>(a, p, vst[i < 4 ? i : 4], inst[i < 4 ? i : 4], yi, k[i + 1], mlp);
       else {
         if (i < 5) closed_rates<MODEL, S>(a, p, vst[i], inst[i], cr);  // i == 5: same stage time as i == 4, same rates
         closed_rhs<MODEL, S>(cr, yi, k[i + 1]);
@@ -1067,8 +1132,8 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT)) i
     // the wavefront then reads the emitting trajectory's row at a uniform address (7 broadcast ds_read_b128 for D = 2)
     // instead of ~29 v_readlane per emitting trajectory.  The workgroup is one wavefront: LDS is in order, no barrier.
     constexpr int ROW = 4 + 5 * D;  // doubles per row, 16-byte aligned rows
-    if constexpr (!MT::MLP) {
-      double2 *row = reinterpret_cast<double2 *>(smem) + lane * (ROW / 2);
+    if constexpr (LW) {
+      double2 *row = reinterpret_cast<double2 *>(lsm) + lane * (ROW / 2);
       row[0] = make_double2(t0, den);
       row[1] = make_double2(rden, 0.0);
       if constexpr (D % 2 == 0) {
@@ -1107,7 +1172,7 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT)) i
           emd &= emd - 1;
           const int o = __builtin_amdgcn_readlane(oi, jj), n = __builtin_amdgcn_readlane(n_out, jj);
           const int w = __builtin_amdgcn_readlane(ow, jj), tr = __builtin_amdgcn_readlane(traj, jj);
-          const double2 *rj = reinterpret_cast<const double2 *>(smem) + jj * (ROW / 2);
+          const double2 *rj = reinterpret_cast<const double2 *>(lsm) + jj * (ROW / 2);
           const double2 h0 = rj[0], h1 = rj[1];
           const double t0b = h0.x, denb = h0.y, rdenb = h1.x;
           S cb[5][D];
@@ -1167,7 +1232,7 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT)) i
       int jj = em ? __builtin_ctzll(em) : 0;
       int o = __builtin_amdgcn_readlane(oi, jj);
       // closed-form kernels on a verified uniform output grid form t_k arithmetically (bit-equal to the t_eval entry)
-      const bool arith_t = !MT::MLP && a.te_exact;
+      const bool arith_t = LW && a.te_exact;
       double tk_nxt = (em && o + lane < Nt) ? (arith_t ? te_at(o + lane) : a.t_eval[o + lane]) : 0.0;
       // table variant: V(t_k) and the reference current of the next trajectory's first chunk are in flight as well
       double vk_nxt = 0.0, rf_nxt = 0.0;
@@ -1192,8 +1257,8 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT)) i
         const int n = __builtin_amdgcn_readlane(n_out, jj);
         double t0b, denb, rdenb;
         S cb[5][D];
-        if constexpr (!MT::MLP) {
-          const double2 *rj = reinterpret_cast<const double2 *>(smem) + jj * (ROW / 2);
+        if constexpr (LW) {
+          const double2 *rj = reinterpret_cast<const double2 *>(lsm) + jj * (ROW / 2);
           const double2 h0 = rj[0], h1 = rj[1];
           t0b = h0.x; denb = h0.y; rdenb = h1.x;
 #pragma unroll
@@ -1217,7 +1282,7 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT)) i
         if (a.i_out || a.sse_out) {
           if (a.i_out) io = a.i_out + (size_t)tr * Nt;
           int pj;
-          if constexpr (!MT::MLP) pj = __builtin_amdgcn_readlane(pidx, jj);  // no dependent global load per emitting trajectory
+          if constexpr (LW) pj = __builtin_amdgcn_readlane(pidx, jj);  // no dependent global load per emitting trajectory
           else pj = a.prot_of_traj ? a.prot_of_traj[tr] : (tr % a.P);
           pvb = a.prot_v + (size_t)pj * a.Np;
           if (a.sse_out) refb = a.sse_ref + (size_t)pj * Nt;
@@ -1254,7 +1319,7 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT)) i
           }
         }
         if (a.sse_out) {  // fused objective: the step's squared residuals of trajectory jj, summed over the wavefront
-          if constexpr (!MT::MLP) sacc = wave_sum_f64(sacc);
+          if constexpr (LW) sacc = wave_sum_f64(sacc);
           else {
 #pragma unroll
             for (int msk = 32; msk >= 1; msk >>= 1) sacc += __shfl_xor(sacc, msk);

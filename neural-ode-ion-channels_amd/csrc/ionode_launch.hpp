@@ -34,6 +34,8 @@ hipError_t launch(const KArgs &a, unsigned grid, size_t lds, hipStream_t s) {
 // the MLP shapes of the reference's architectures/s00-s11.py: N = 10, 100, 200, 500
 #define IONODE_MLP_VARIANTS(MODEL, S, F32)                                                      \
   IONODE_VARIANT(MODEL, S, F32, 1, 1, 1, 1, 0), IONODE_VARIANT(MODEL, S, F32, 4, 4, 7, 7, 0),        \
+      /* N <= 16 at 64 trajectories per wavefront (RT slot 64), plain and with the deferred aligned emission (TAIL 1) */ \
+      IONODE_VARIANT(MODEL, S, F32, 1, 64, 1, 1, 0), IONODE_VARIANT(MODEL, S, F32, 1, 64, 1, 1, 1),      \
       IONODE_VARIANT(MODEL, S, F32, 4, 4, 13, 13, 0), IONODE_VARIANT(MODEL, S, F32, 4, 8, 32, 4, 0)
 
 // one table per translation unit (they compile in parallel)

@@ -344,3 +344,38 @@ def test_protocol_at_outputs_table(ion, gpu, oracle, explicit_grid):
     assert torch.allclose(with_tab["sse"], without["sse"], rtol=1e-13, atol=0)
     again = capi.dopri5(K.MODEL_HH2, params, pv_t, y0, te_t, v_at_outputs=with_tab["v_at_outputs"], **common)   # a caller-kept table
     assert torch.equal(again["i"], with_tab["i"])
+
+
+@pytest.mark.parametrize("model", [K.MODEL_NNF, K.MODEL_NND])
+@pytest.mark.parametrize("L,N,f32", [(5, 10, False), (1, 10, True), (10, 10, False), (3, 16, True)])
+def test_tiny_nets_at_64_trajectories_per_wavefront(ion, gpu, oracle, model, L, N, f32):
+    """N <= 16 (architectures s03-s05): the kernel variant with one trajectory per lane (tile_waves = 64; chosen by itself
+    for large batches) -- four MFMA column tiles per evaluation, inputs gathered with ds_bpermute -- returns the bits of
+    the 16-per-wavefront kernel and of the oracle: ragged batch, per-trajectory protocols, one failing trajectory, fused current."""
+    rng = np.random.default_rng(7 * L + N)
+    B = 150
+    w = rng.normal(0, 0.3, 2 * N + N + L * (N * N + N) + N + 1).astype(np.float32)
+    pv = np.stack([K.atau(30)[1], K.atau(300)[1], K.activation(20)[1][: K.atau(30)[1].size]])
+    te = K.atau(30)[2][:1201]
+    params = np.tile(K.P_NN_D if model == K.MODEL_NND else K.P_HH, (B, 1)) * rng.uniform(0.85, 1.2, (B, 8))
+    y0 = np.tile(K.NN_Y0, (B, 1)).astype(np.float64)
+    y0[77, 0] = np.nan
+    pot = rng.integers(0, 3, B).astype(np.int32)
+    kw = dict(prot_t0=0.0, prot_dt=1.0, prot_of_traj=pot, max_total_steps=20000)
+    o = oracle.solve(model, params, pv, y0, te, weights=w, mlp_layers=L, mlp_width=N, state_f32=f32, nthreads=4, **kw)
+    assert o["status"][77] != 0 and (np.delete(o["status"], 77) == 0).all()
+    geo = {}
+    for tw in (64, 1):
+        g = run_gpu(ion, gpu, model, params, pv, y0, te, weights=w, L=L, N=N, f32=f32, current=True, tile_waves=tw, **kw)
+        assert np.array_equal(g["status"], o["status"]) and np.array_equal(g["stats"], o["stats"])
+        assert np.array_equal(g["y"], o["y"], equal_nan=True)
+        geo[tw] = g
+    ok = o["status"] == 0
+    assert np.array_equal(geo[64]["i"][ok], geo[1]["i"][ok])
+    d = ion.capi.make_desc(model=model, state_f32=int(f32), n_state=2, n_out=te.size, n_traj=B, n_prot=3, prot_n=pv.shape[1],
+                           mlp_layers=L, mlp_width=N, n_params=8, prot_dt=1.0, rtol=1e-7, atol=1e-9, tile_waves=64)
+    assert ion.capi.launch_geometry(d)["grid"] == 3 and ", 1, 64, 1, 1, " in ion.capi.kernel_name(d)
+    d.tile_waves, d.n_traj = 0, 160000
+    assert ion.capi.launch_geometry(d)["grid"] == 2500 and ", 1, 64, 1, 1, " in ion.capi.kernel_name(d)     # chosen by itself
+    d.n_traj = 30000
+    assert ion.capi.launch_geometry(d)["grid"] == 1875 and ", 1, 1, 1, 1, 0>" in ion.capi.kernel_name(d)
