@@ -72,7 +72,8 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false) {
     pl->grid = (unsigned)((d->n_traj + tpw - 1) / tpw);
     pl->block = 64;
     // one interpolant row per lane (dense-output broadcast through LDS) + one tail buffer per trajectory (2-state models)
-    pl->lds = (size_t)64 * (4 + 5 * D) * 8 + (D == 2 ? (size_t)64 * 64 : 0);
+    // (the 4 KiB behind the rows: tail buffers of the deferred emission, or the fused objective's partial sums)
+    pl->lds = (size_t)64 * (4 + 5 * D) * 8 + (size_t)64 * 64;
   } else {
     if (d->mlp_width < 1 || d->mlp_layers < 0) { set_err("bad MLP shape"); return IONODE_ERR_ARG; }
     if (d->mlp_width <= 16 && d->mlp_layers > 10) { set_err("N <= 16 kernels keep at most 10 hidden layers resident"); return IONODE_ERR_UNSUPPORTED; }

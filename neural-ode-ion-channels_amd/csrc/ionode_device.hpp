@@ -200,21 +200,19 @@ template <typename S> __device__ __forceinline__ S bcast(S x, int src);
 template <> __device__ __forceinline__ double bcast<double>(double x, int src) { return bcast_f64(x, src); }
 template <> __device__ __forceinline__ float bcast<float>(float x, int src) { return bcast_f32(x, src); }
 
-// Sum of x over the 64 lanes with DPP row operations (VALU speed; __shfl_xor would take 12 LDS-crossbar round trips for a
-// double).  Fixed order: ((quad) + half-row + row) then rows (2 + 3) + (0 + 1); the total is returned to every lane.
+// x moved across lanes by a DPP row operation (VALU speed; __shfl_xor takes two LDS-crossbar round trips for a double)
 template <int CTRL, int ROWMASK> __device__ __forceinline__ double dpp_f64(double x) {
   const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROWMASK, 0xf, false);
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROWMASK, 0xf, false);
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wave_sum_f64(double x) {
+
+// Sum over each group of 8 consecutive lanes (3 DPP steps); every lane of the group holds the group's sum.
+__device__ __forceinline__ double group8_sum_f64(double x) {
   x = x + dpp_f64<0xB1, 0xf>(x);   // quad_perm [1,0,3,2]
   x = x + dpp_f64<0x4E, 0xf>(x);   // quad_perm [2,3,0,1]
   x = x + dpp_f64<0x141, 0xf>(x);  // row_half_mirror
-  x = x + dpp_f64<0x140, 0xf>(x);  // row_mirror: every lane of a row holds the row's sum
-  x = x + dpp_f64<0x142, 0xa>(x);  // row_bcast:15 into rows 1 and 3
-  x = x + dpp_f64<0x143, 0xc>(x);  // row_bcast:31 into rows 2 and 3: row 3 holds the total
-  return bcast_f64(x, 63);
+  return x;
 }
 
 // interp1d(t, v) (linear) with the reference's out-of-range rule (train-s1.py:218-229, :234-237).
@@ -940,6 +938,13 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
   // other's code and registers
   constexpr bool VTAB = !MT::MLP && TAIL == 2;
   unsigned char *const tails = lsm + 64 * ROWB;
+  double *const ssep = reinterpret_cast<double *>(tails);  // [64][8] partial sums of the fused objective (never together with defer)
+  if constexpr (LW) {
+    if (a.sse_out != nullptr) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) ssep[lane * 8 + m] = 0.0;
+    }
+  }
   int ow = 1;  // defer: next sample index of MY trajectory not yet written to HBM (ow <= oi, oi - ow < LS)
   if constexpr (CF2 && defer) {
     ow = 0;
@@ -1318,13 +1323,18 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
             }
           }
         }
-        if (a.sse_out) {  // fused objective: the step's squared residuals of trajectory jj, summed over the wavefront
-          if constexpr (LW) sacc = wave_sum_f64(sacc);
-          else {
+        if (a.sse_out) {  // fused objective: the step's squared residuals of trajectory jj
+          if constexpr (LW) {
+            // lane-wise kernels: a full wavefront reduction per emitting trajectory (6 DPP steps + broadcast) was a quarter of
+            // the epilogue's instructions.  Reduce over groups of 8 lanes only and keep 8 partial sums per trajectory in LDS
+            // (the tail-buffer region, which only the deferred-emission variant uses); they are added up once, at the end.
+            const double g8 = group8_sum_f64(sacc);
+            if ((lane & 7) == 0) ssep[jj * 8 + (lane >> 3)] += g8;
+          } else {
 #pragma unroll
             for (int msk = 32; msk >= 1; msk >>= 1) sacc += __shfl_xor(sacc, msk);
+            if (j == jj) sse += sacc;
           }
-          if (j == jj) sse += sacc;
         }
         jj = jn;
         o = on;
@@ -1437,6 +1447,12 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
   if (blockIdx.x == 0 && threadIdx.x == 0 && a.step_log != nullptr && a.step_log_cap >= 4)
     for (int i_ = 0; i_ < 16; ++i_) a.step_log[i_] = (double)stamps_.acc[i_];
 #endif
+  if constexpr (LW) {
+    if (a.sse_out != nullptr) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) sse += ssep[j * 8 + m];
+    }
+  }
   if (a.sse_out != nullptr && valid && lane < TPW && (G == 1 || (lane % G) == wave))
     a.sse_out[traj] = (status == IONODE_STATUS_OK) ? sse : __builtin_inf();  // the reference's time-limit rule: inf (train-d0.py:430-431)
   if (valid && primary) {
