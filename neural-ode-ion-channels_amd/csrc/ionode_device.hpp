@@ -1110,42 +1110,55 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
     if constexpr (CARRY_V) lookup_stages(acc_now ? t1 : t0, (active || acc_now) ? dt_capped : dt);
 
     // ---- _interp_fit + cooperative dense output ----
-    S ic[5][D];  // e, d, c, b, a
+    // x = (t_k - t0) / (t1 - t0) of every dense-output sample: ONE division per attempt (the reciprocal of the step length),
+    // then div_by() per sample -- the same correctly rounded quotient
+    const double den = t1 - t0;
+    const double rden = 1.0 / den;
+    constexpr int ROW = 4 + 5 * D;  // doubles per LDS row, 16-byte aligned rows
+    S ic[LW ? 1 : 5][LW ? 1 : D];   // e, d, c, b, a -- tile kernels keep them in registers (broadcast by v_readlane)
     {
       S bm[7];
 #pragma unroll
       for (int jx = 0; jx < 7; ++jx) bm[jx] = dts * (S)kCmid[jx];
-#pragma unroll
-      for (int d = 0; d < D; ++d) {
+      auto fit = [&](int d, S *c5) {
         S s = k[0][d] * bm[0];
 #pragma unroll
         for (int jx = 1; jx < 7; ++jx) s = s + k[jx][d] * bm[jx];
         const S YM = y[d] + s;
         const S F0 = k[0][d], F1 = k[6][d], Y0 = y[d], Y1 = yi[d];
-        ic[4][d] = ((S)2 * dts) * (F1 - F0) - (S)8 * (Y1 + Y0) + (S)16 * YM;
-        ic[3][d] = dts * ((S)5 * F0 - (S)3 * F1) + (S)18 * Y0 + (S)14 * Y1 - (S)32 * YM;
-        ic[2][d] = dts * (F1 - (S)4 * F0) - (S)11 * Y0 - (S)5 * Y1 + (S)16 * YM;
-        ic[1][d] = dts * F0;
-        ic[0][d] = Y0;
-      }
-    }
-    // x = (t_k - t0) / (t1 - t0) of every dense-output sample: ONE division per attempt (the reciprocal of the step length),
-    // then div_by() per sample -- the same correctly rounded quotient
-    const double den = t1 - t0;
-    const double rden = 1.0 / den;
-    // Closed-form kernels: a lane's interpolant (t0, step length, its reciprocal, 5 x D coefficients) goes to its LDS row;
-    // the wavefront then reads the emitting trajectory's row at a uniform address (7 broadcast ds_read_b128 for D = 2)
-    // instead of ~29 v_readlane per emitting trajectory.  The workgroup is one wavefront: LDS is in order, no barrier.
-    constexpr int ROW = 4 + 5 * D;  // doubles per row, 16-byte aligned rows
-    if constexpr (LW) {
-      double2 *row = reinterpret_cast<double2 *>(lsm) + lane * (ROW / 2);
-      row[0] = make_double2(t0, den);
-      row[1] = make_double2(rden, 0.0);
-      if constexpr (D % 2 == 0) {
+        c5[4] = ((S)2 * dts) * (F1 - F0) - (S)8 * (Y1 + Y0) + (S)16 * YM;
+        c5[3] = dts * ((S)5 * F0 - (S)3 * F1) + (S)18 * Y0 + (S)14 * Y1 - (S)32 * YM;
+        c5[2] = dts * (F1 - (S)4 * F0) - (S)11 * Y0 - (S)5 * Y1 + (S)16 * YM;
+        c5[1] = dts * F0;
+        c5[0] = Y0;
+      };
+      if constexpr (LW) {
+        // Lane-wise kernels: a lane's interpolant (t0, step length, its reciprocal, 5 x D coefficients) goes to its LDS row;
+        // the wavefront then reads the emitting trajectory's row at a uniform address (7 broadcast ds_read_b128 for D = 2)
+        // instead of ~29 v_readlane per emitting trajectory.  The workgroup is one wavefront: LDS is in order, no barrier.
+        // The coefficients are fitted and stored two components at a time, so that at most 10 of the 5 x D are live
+        // (6-state model: 60 registers fewer at the kernel's pressure peak).
+        double2 *row = reinterpret_cast<double2 *>(lsm) + lane * (ROW / 2);
+        row[0] = make_double2(t0, den);
+        row[1] = make_double2(rden, 0.0);
+        static_assert(D % 2 == 0, "rows hold component pairs");
 #pragma unroll
-        for (int c = 0; c < 5; ++c)
+        for (int d = 0; d < D; d += 2) {
+          S ca[5], cb2[5];
+          fit(d, ca);
+          fit(d + 1, cb2);
 #pragma unroll
-          for (int d = 0; d < D; d += 2) row[2 + (c * D + d) / 2] = make_double2((double)ic[c][d], (double)ic[c][d + 1]);
+          for (int c = 0; c < 5; ++c) row[2 + (c * D + d) / 2] = make_double2((double)ca[c], (double)cb2[c]);
+          if constexpr (D > 2) __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          S c5[5];
+          fit(d, c5);
+#pragma unroll
+          for (int c = 0; c < 5; ++c) ic[c][d] = c5[c];
+        }
       }
     }
     if (a.te_dt > 0.0) {
@@ -1357,11 +1370,24 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
         double *__restrict__ io = nullptr;
         const double *__restrict__ pvb = nullptr;
         if (owner) {
-          t0b = bcast_f64(t0, jj); denb = bcast_f64(den, jj); rdenb = bcast_f64(rden, jj);
+          if constexpr (LW) {
+            const double2 *rj = reinterpret_cast<const double2 *>(lsm) + jj * (ROW / 2);
+            const double2 h0 = rj[0], h1 = rj[1];
+            t0b = h0.x; denb = h0.y; rdenb = h1.x;
 #pragma unroll
-          for (int c = 0; c < 5; ++c)
+            for (int c = 0; c < 5; ++c)
 #pragma unroll
-            for (int d = 0; d < D; ++d) cb[c][d] = bcast<S>(ic[c][d], jj);
+              for (int d = 0; d < D; d += 2) {
+                const double2 cc = rj[2 + (c * D + d) / 2];
+                cb[c][d] = (S)cc.x; cb[c][d + 1] = (S)cc.y;
+              }
+          } else {
+            t0b = bcast_f64(t0, jj); denb = bcast_f64(den, jj); rdenb = bcast_f64(rden, jj);
+#pragma unroll
+            for (int c = 0; c < 5; ++c)
+#pragma unroll
+              for (int d = 0; d < D; ++d) cb[c][d] = bcast<S>(ic[c][d], jj);
+          }
           const int tr = __builtin_amdgcn_readlane(traj, jj);
           yo = reinterpret_cast<S *>(a.y_out) + (size_t)tr * Nt * D;
           if (a.i_out) {
