@@ -224,7 +224,8 @@ def main():
         out.clear()
         torch.cuda.empty_cache()
         for key, fn in (("roofline_closed_form", closed_form_legs), ("gradient_config5", gradient_leg),
-                        ("regression_step", regression_leg), ("launch_order_16384", launch_order_leg)):
+                        ("regression_step", regression_leg), ("launch_order_16384", launch_order_leg),
+                        ("objective_config4_share", objective_leg)):
             try:
                 res[key] = fn(ion, dev, weights)
             except Exception as e:  # informational legs only
@@ -340,6 +341,44 @@ def gradient_leg(ion, dev, weights):
     return {"workload": "configs[4]: dL/dW through odeint, NN-f s00, 1024 trajectories (1/8 of the 8192-trajectory batch), "
                         "fp32 state, sine-wave protocols, N_t = N_p = 100001", "forward_with_checkpoints_s": fwd, "backward_s": bwd,
             "trajectories_per_s_fwd_bwd": B / (fwd + bwd), "grad_w_norm": gnorm, "ok": int((status == 0).sum().item())}
+
+
+def objective_leg(ion, dev, weights):
+    """BASELINE.json configs[3], one GPU's share: 8192 of the 65 536 candidate parameter sets on every Pr3 / Pr4 / Pr5 sweep
+    (7 + 16 + 9 protocols at the 0.1 ms data grid = 262 144 solves), fp32 state as train-d0.py:405, sum of squares against a
+    (synthetic) recorded current per sweep, fused in the kernel: what one CMA-ES generation costs per GPU.  Two populations:
+    the optimiser's own first generation (log-normal, sigma0 = 0.1 around p0: train-d0.py:527-531) and samples of the whole
+    prior box p0 x LogUniform(0.1, 10), where about half of the candidates are too stiff for an explicit solver
+    and end at the step budget (the reference bounds those with a 600 s alarm, train-d0.py:309-318; here 20 000 attempts)."""
+    P = ion.protocols
+    obj = importlib.import_module("neural-ode-ion-channels_amd.objective")
+    rng = np.random.default_rng(7)
+    C = 8192
+    p0 = np.array([1.13e-4, 7.45e-2, 3.60e-5, 4.49e-2])                                             # train-d0.py:325-328
+    pops = {"cmaes_first_generation": p0 * np.exp(rng.normal(0.0, 0.1, (C, 4))),
+            "prior_box": p0 * 10.0 ** rng.uniform(-1, 1, (C, 4))}
+    fams = {"pr3": np.stack([P.activation_pr3(v) for v in P.PR3_STEPS]),
+            "pr4": np.stack([P.pr4_synthetic(k) for k in range(16)]),
+            "pr5": np.stack([P.deactivation_pr5(v) for v in P.PR5_STEPS])}
+    out = {"candidates": C, "step_budget": 20000,
+           "note": "host wall time per protocol family incl. parameter upload; nothing but one double per solve leaves the kernel"}
+    for pname, cand in pops.items():
+        res, total_ms, total_solves, total_samples = {}, 0.0, 0, 0
+        for name, pv in fams.items():
+            S, Np = pv.shape
+            te = np.arange(Np) * 0.1
+            data = np.zeros((S, Np))
+            args = dict(base_params=P_HH, prot_t0=0.0, prot_dt=0.1, max_total_steps=20000, device=dev)
+            obj.population_sum_of_squares(cand[:64], pv, data, te, **args)        # warm-up (uploads, allocator)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            sse = obj.population_sum_of_squares(cand, pv, data, te, **args)
+            torch.cuda.synchronize(); ms = (time.perf_counter() - t0) * 1e3
+            res[name] = {"sweeps": S, "samples_per_sweep": Np, "solves": C * S, "ms": ms, "finite": int(torch.isfinite(sse).sum())}
+            total_ms += ms; total_solves += C * S; total_samples += C * S * Np
+        res.update({"ms_per_generation_share": total_ms, "candidates_per_s": C / total_ms * 1e3,
+                    "solves_per_s": total_solves / total_ms * 1e3, "samples_per_s": total_samples / total_ms * 1e3})
+        out[pname] = res
+    return out
 
 
 def launch_order_leg(ion, dev, weights):
