@@ -225,7 +225,7 @@ def main():
         torch.cuda.empty_cache()
         for key, fn in (("roofline_closed_form", closed_form_legs), ("gradient_config5", gradient_leg),
                         ("regression_step", regression_leg), ("launch_order_16384", launch_order_leg),
-                        ("objective_config4_share", objective_leg)):
+                        ("objective_config4_share", objective_leg), ("config3_nnd_staircase_16384", config3_leg)):
             try:
                 res[key] = fn(ion, dev, weights)
             except Exception as e:  # informational legs only
@@ -341,6 +341,42 @@ def gradient_leg(ion, dev, weights):
     return {"workload": "configs[4]: dL/dW through odeint, NN-f s00, 1024 trajectories (1/8 of the 8192-trajectory batch), "
                         "fp32 state, sine-wave protocols, N_t = N_p = 100001", "forward_with_checkpoints_s": fwd, "backward_s": bwd,
             "trajectories_per_s_fwd_bwd": B / (fwd + bwd), "grad_w_norm": gnorm, "ok": int((status == 0).sum().item())}
+
+
+def config3_leg(ion, dev, weights):
+    """BASELINE.json configs[2]: NN-d (the train-d2 discrepancy model, d2 weights when the fixture is there) on the 15 s
+    staircase protocol (150 001 samples at 0.1 ms), 16 384 trajectories with rate parameters x U(0.9, 1.1), fp64 state:
+    index order, then the previous solve's counters as the launch order."""
+    capi, P, S = ion.capi, ion.protocols, ion.schedule
+    B, Nt = 16384, 150001
+    wp = os.path.join(ROOT, "tests", "golden", "weights_d2.f32")
+    w = np.fromfile(wp, dtype="<f4") if os.path.exists(wp) else weights
+    p_nnd = np.concatenate([P_HH[:4], np.array([9.62243079990877703e+01, 2.26404683824047979e+01, 8.00924780462999131e+00,
+                                                  2.43749808069009823e+01]) * 1e-3])     # train-d2.py:221-232
+    params = torch.from_numpy(np.tile(p_nnd, (B, 1)) * np.random.default_rng(7).uniform(0.9, 1.1, (B, 8))).to(dev)
+    pv = torch.from_numpy(P.staircase()).to(dev)
+    y0 = torch.tensor([[0.0, 1.0]], dtype=torch.float64)
+    te = torch.arange(Nt, dtype=torch.float64, device=dev) * 0.1
+
+    def run(order):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        sol = ion.solve(capi.MODEL_NND, params, pv, y0, te, weights=w, mlp_layers=MLP_L, mlp_width=MLP_N, weights_key="bench-d2",
+                        prot_t0=0.0, prot_dt=0.1, t_eval_hint=(0.0, 0.1), order=order)
+        e1.record()
+        torch.cuda.synchronize()
+        nfe = sol.to_original(sol.stats[:, 2]).double()
+        return e0.elapsed_time(e1), nfe, int((sol.status == 0).sum())
+
+    def line(ms, nfe, ok):
+        return {"ms": ms, "trajectories_per_s": B / (ms * 1e-3), "mean_nfe": float(nfe.mean()), "max_nfe": float(nfe.max()),
+                "frac_of_fp32_peak": float(nfe.sum()) * (F_MLP + F_RHS_OTHER) / (ms * 1e-3) / (PEAK_FP32_TFLOPS * 1e12), "ok": ok}
+
+    run(None)
+    ms0, nfe0, ok0 = run(None)
+    ms1, nfe1, ok1 = run(S.lpt_order(nfe0))
+    return {"workload": "NN-d, 16384 staircase trajectories x 150001 samples, fp64 state", "index_order": line(ms0, nfe0, ok0),
+            "previous_nfe_order": line(ms1, nfe1, ok1)}
 
 
 def objective_leg(ion, dev, weights):
