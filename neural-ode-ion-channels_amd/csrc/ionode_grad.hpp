@@ -328,9 +328,12 @@ struct GradMlp {
 
 template <int MODEL, typename S, int NT>
 __global__ void __launch_bounds__(256) ionode_dopri5_backward_kernel(const GArgs a) {
-  static_assert(MODEL == IONODE_MODEL_NNF || MODEL == IONODE_MODEL_NND, "backward sweep: MLP models");
+  static_assert(MODEL == IONODE_MODEL_NNF || MODEL == IONODE_MODEL_NND || MODEL == IONODE_MODEL_HH2, "backward sweep: 2-state models");
   constexpr int D = 2;
-  constexpr bool NND = MODEL == IONODE_MODEL_NND;
+  // HH 2-state (train-s1.py:161-177): the same sweep without the MLP collective -- da/dt = k1 (1 - a) - k2 a is the closed-form
+  // a-term of NN-d, so the kernel only skips the vector-Jacobian product and the record stream (NT is 1 and unused)
+  constexpr bool HAS_MLP = MODEL != IONODE_MODEL_HH2;
+  constexpr bool NND = MODEL == IONODE_MODEL_NND || MODEL == IONODE_MODEL_HH2;  // closed-form a-gate terms
   using R = Real<S>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -343,8 +346,11 @@ __global__ void __launch_bounds__(256) ionode_dopri5_backward_kernel(const GArgs
   const bool writer = valid && wave == 0 && lane < 16;
 
   GradMlp<NT> mlp;
-  mlp.init(a, smem, wave, lane);
-  double *__restrict__ Gs = mlp.gs();
+  double *__restrict__ Gs = reinterpret_cast<double *>(smem);  // [16][10] fp64 scratch
+  if constexpr (HAS_MLP) {
+    mlp.init(a, smem, wave, lane);
+    Gs = mlp.gs();
+  }
 
   double p[8];
 #pragma unroll
@@ -482,7 +488,8 @@ __global__ void __launch_bounds__(256) ionode_dopri5_backward_kernel(const GArgs
       const double av = Yi[0], rv = Yi[1];
       const float x0 = (float)(v / 100.0), x1 = (float)av;
       const float seedf = (float)(seed[0] / 1000.0);
-      const float dx1 = mlp.vjp(x0, x1, seedf, rec_it ? rec_it + (size_t)e * a.record_floats : nullptr);
+      float dx1 = 0.0f;
+      if constexpr (HAS_MLP) dx1 = mlp.vjp(x0, x1, seedf, rec_it ? rec_it + (size_t)e * a.record_floats : nullptr);
       // closed-form terms of the RHS and their parameter gradients
       const double e3 = det_exp(p[5] * v), e4 = det_exp(-p[7] * v);
       const double k3 = p[4] * e3, k4 = p[6] * e4;
@@ -518,6 +525,7 @@ __global__ void __launch_bounds__(256) ionode_dopri5_backward_kernel(const GArgs
 #pragma unroll
       for (int d = 0; d < D; ++d) { lam[d] = aY0[d]; mu[d] = ak[0][d]; }
     }
+    if constexpr (!HAS_MLP) __syncthreads();  // the next iteration rewrites Gs (the MLP variants pass barriers inside vjp)
   }
 
   if (writer) {

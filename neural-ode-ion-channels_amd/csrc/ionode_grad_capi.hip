@@ -98,18 +98,20 @@ int ionode_dopri5_backward(const ionode_desc *d, int32_t it_begin, int32_t it_en
                            const double *t_eval, const int32_t *n_accepted, const void *grad_y, double *state,
                            float *records, double *grad_params, double *grad_y0, void *stream) {
   if (!d) { gerr("null descriptor"); return IONODE_ERR_ARG; }
-  if (d->model != IONODE_MODEL_NNF && d->model != IONODE_MODEL_NND) { gerr("backward sweep: NN-f / NN-d only"); return IONODE_ERR_UNSUPPORTED; }
+  const bool hh2 = d->model == IONODE_MODEL_HH2;
+  if (d->model != IONODE_MODEL_NNF && d->model != IONODE_MODEL_NND && !hh2) { gerr("backward sweep: NN-f / NN-d / HH 2-state only"); return IONODE_ERR_UNSUPPORTED; }
   if (d->n_state != 2 || d->n_traj < 1 || d->n_out < 1 || d->n_prot < 1 || d->prot_n < 2 || d->n_params < 8 || !(d->prot_dt > 0)) {
     gerr("inconsistent descriptor"); return IONODE_ERR_ARG;
   }
-  if (!grad_image || !params || !prot_v || !t_eval || !n_accepted || !grad_y || !state || !grad_params || !grad_y0 || !d->ckpt || d->ckpt_cap < 1) {
+  if ((!grad_image && !hh2) || !params || !prot_v || !t_eval || !n_accepted || !grad_y || !state || !grad_params || !grad_y0 || !d->ckpt || d->ckpt_cap < 1) {
     gerr("ionode_dopri5_backward: required buffer is NULL (ckpt / ckpt_cap come from the descriptor)"); return IONODE_ERR_ARG;
   }
   if (it_begin < 0 || it_end <= it_begin || it_end > n_iter) { gerr("bad iteration range"); return IONODE_ERR_ARG; }
-  if (d->mlp_layers < 1 || d->mlp_width < 1) { gerr("bad MLP shape"); return IONODE_ERR_ARG; }
-  const int NP = np_of(d->mlp_width), NT = NP / 16, L = d->mlp_layers;
-  SweepFn fn = find_sweep(d->model, d->state_f32 ? 1 : 0, NT);
-  const size_t lds = ionode::grad_lds_bytes(L, NT);
+  if (!hh2 && (d->mlp_layers < 1 || d->mlp_width < 1)) { gerr("bad MLP shape"); return IONODE_ERR_ARG; }
+  const int NP = hh2 ? 16 : np_of(d->mlp_width), NT = NP / 16, L = hh2 ? 0 : d->mlp_layers;
+  SweepFn fn = hh2 ? (d->state_f32 ? &launch_sweep<IONODE_MODEL_HH2, float, 1> : &launch_sweep<IONODE_MODEL_HH2, double, 1>)
+                   : find_sweep(d->model, d->state_f32 ? 1 : 0, NT);
+  const size_t lds = hh2 ? (size_t)16 * 10 * 8 : ionode::grad_lds_bytes(L, NT);
   if (!fn || lds > 160 * 1024) {
     gerr("backward sweep: (L, N) outside the compiled variants (N pads to 16, 112 or 208 and (L + 3) * N * 64 B must fit 160 KB of LDS)");
     return IONODE_ERR_UNSUPPORTED;
@@ -121,7 +123,7 @@ int ionode_dopri5_backward(const ionode_desc *d, int32_t it_begin, int32_t it_en
   a.k.L = L; a.k.N = d->mlp_width; a.k.NP = NP; a.k.NT = NT;
   a.k.prot_t0 = d->prot_t0; a.k.prot_dt = d->prot_dt; a.k.prot_rdt = 1.0 / d->prot_dt; a.k.v_oob = d->v_oob;
   a.img = grad_image; a.ckpt = d->ckpt; a.ckpt_cap = d->ckpt_cap; a.nacc = n_accepted; a.grad_y = grad_y; a.state = state;
-  a.records = records; a.grad_params = grad_params; a.grad_y0 = grad_y0;
+  a.records = hh2 ? nullptr : records; a.grad_params = grad_params; a.grad_y0 = grad_y0;
   a.it_begin = it_begin; a.it_end = it_end; a.n_iter = n_iter;
   a.record_floats = ionode::grad_record_floats(L, NT);
   fn(a, (unsigned)((d->n_traj + 15) / 16), lds, reinterpret_cast<hipStream_t>(stream));

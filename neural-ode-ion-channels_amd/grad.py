@@ -81,9 +81,11 @@ class _Solve(torch.autograd.Function):
         L, N = cfg["mlp_layers"], cfg["mlp_width"]
         B = y0.shape[0]
         cap = int(cfg.get("ckpt_cap") or DEFAULT_CKPT_CAP)
-        w_np = weights_flat.detach().to(torch.float32).cpu().numpy()
-        from . import batched  # packed forward image: shared cache with the plain solve
-        packed = batched.packed_weights(w_np, L, N, dev, key=cfg.get("weights_key"))
+        w_np, packed = None, None
+        if weights_flat is not None:   # (None: the closed-form HH 2-state model)
+            w_np = weights_flat.detach().to(torch.float32).cpu().numpy()
+            from . import batched  # packed forward image: shared cache with the plain solve
+            packed = batched.packed_weights(w_np, L, N, dev, key=cfg.get("weights_key"))
         while True:
             ckpt = torch.empty((B, cap, 20), dtype=torch.float64, device=dev)
             r = capi.dopri5(cfg["model"], params.detach(), cfg["prot_v"], y0.detach(), cfg["t_eval"], mlp_packed=packed,
@@ -110,19 +112,19 @@ class _Solve(torch.autograd.Function):
         dev = params.device
         L, N = cfg["mlp_layers"], cfg["mlp_width"]
         B, Nt = desc.n_traj, desc.n_out
-        need_w = ctx.needs_input_grad[0]
+        need_w = ctx.needs_input_grad[0] and ctx.w_np is not None
         lib = capi.lib()
         sdt = torch.float32 if desc.state_f32 else torch.float64
         gy = gy.to(sdt).contiguous()
         n_acc = torch.where(status == 0, stats[:, 0], torch.zeros_like(stats[:, 0])).to(torch.int32).contiguous()
         n_iter = int(n_acc.max().item()) + 1
-        image = grad_image(ctx.w_np, L, N, dev, key=cfg.get("weights_key"))
+        image = grad_image(ctx.w_np, L, N, dev, key=cfg.get("weights_key")) if ctx.w_np is not None else None
         state = torch.empty((B, 12), dtype=torch.float64, device=dev)
         g_params = torch.zeros((B, 8), dtype=torch.float64, device=dev)
         g_y0 = torch.zeros((B, 2), dtype=torch.float64, device=dev)
         tiles = (B + 15) // 16
-        recf = lib.ionode_grad_record_floats(L, N)
-        partf = lib.ionode_grad_partial_floats(L, N)
+        recf = lib.ionode_grad_record_floats(L, N) if need_w else 0
+        partf = lib.ionode_grad_partial_floats(L, N) if need_w else 0
         budget = int(cfg.get("record_budget_bytes") or DEFAULT_RECORD_BUDGET)
         chunk = n_iter if not need_w else max(1, min(n_iter, budget // (tiles * 6 * recf * 4)))
         acc = torch.zeros(partf, dtype=torch.float64, device=dev) if need_w else None
@@ -170,7 +172,7 @@ class _Solve(torch.autograd.Function):
         return g_w, (g_params if ctx.needs_input_grad[1] else None), (g_y0.to(sdt) if ctx.needs_input_grad[2] else None), None
 
 
-def solve(model, weights_flat, params, prot_v, y0, t_eval, *, mlp_layers, mlp_width, prot_t=None, prot_t0=0.0,
+def solve(model, weights_flat, params, prot_v, y0, t_eval, *, mlp_layers=0, mlp_width=0, prot_t=None, prot_t0=0.0,
           prot_dt=1.0, prot_of_traj=None, rtol=1e-7, atol=1e-9, v_oob=-80.0, max_steps=0, max_total_steps=0, max_step=0.0,
           ckpt_cap=None, record_budget_bytes=None, weights_key=None, t_eval_hint="auto", order=None):
     """Differentiable batched solve.  weights_flat [n] fp32 (reference state-dict order), params [B, 8] fp64, y0 [B, 2]
@@ -187,8 +189,13 @@ def solve(model, weights_flat, params, prot_v, y0, t_eval, *, mlp_layers, mlp_wi
     tiles, expensive tiles first -- pays from two tiles per compute unit, B > 4096); y and status are then in LAUNCH order
     (row k = trajectory order[k]), and the gradients still arrive at params / y0 in the caller's order (the gather is part of
     the autograd graph)."""
-    if model not in (capi.MODEL_NNF, capi.MODEL_NND):
-        raise NotImplementedError("gradients through the solve are built for the NN-f / NN-d right-hand sides")
+    if model == capi.MODEL_HH2:
+        # closed-form 2-state model (train-s1.py:161-177): gradients w.r.t. p1..p8 and y0; there are no weights
+        if weights_flat is not None:
+            raise capi.IonodeError("the HH 2-state model has no MLP: pass weights_flat=None")
+        mlp_layers = mlp_width = 0
+    elif model not in (capi.MODEL_NNF, capi.MODEL_NND):
+        raise NotImplementedError("gradients through the solve are built for the NN-f / NN-d / HH 2-state right-hand sides")
     if not (isinstance(y0, torch.Tensor) and y0.is_cuda):
         raise capi.IonodeError("no HIP tensors: the integrator and its backward sweep have no CPU path")
     if order is not None:

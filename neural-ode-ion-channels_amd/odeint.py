@@ -92,13 +92,15 @@ def _wants_grad(func, y0):
 
 def _odeint_with_grad(func, y0, t, spec, rtol, atol, options):
     """Differentiable call: same forward kernel (plus accepted-step checkpoints), backward sweep on demand."""
-    if spec.model not in (capi.MODEL_NNF, capi.MODEL_NND):
+    if spec.model not in (capi.MODEL_NNF, capi.MODEL_NND, capi.MODEL_HH2):
         raise NotImplementedError(
-            "odeint: a gradient was requested through a closed-form RHS module (HH / 6-state); the backward sweep is built "
-            "for the NN-f / NN-d modules.  Call under torch.no_grad() (as the reference does) for forward values.")
+            "odeint: a gradient was requested through the 6-state RHS module; the backward sweep is built for the NN-f / NN-d / "
+            "HH 2-state modules.  Call under torch.no_grad() (as the reference does) for forward values.")
     dev = batched._dev()
-    lin = [m for m in func.net if isinstance(m, torch.nn.Linear)]
-    flat = torch.cat([x.reshape(-1) for m in lin for x in (m.weight, m.bias)]).to(dev)
+    flat = None
+    if spec.model != capi.MODEL_HH2:
+        lin = [m for m in func.net if isinstance(m, torch.nn.Linear)]
+        flat = torch.cat([x.reshape(-1) for m in lin for x in (m.weight, m.bias)]).to(dev)
     rates = _rate_tensors(func)
     if any(isinstance(p, torch.Tensor) and p.requires_grad for p in rates):
         cols = [(p.reshape(()).to(device=dev, dtype=torch.float64) if isinstance(p, torch.Tensor)

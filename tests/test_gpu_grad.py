@@ -123,10 +123,31 @@ def test_dropin_odeint_gives_module_gradients(ion, gpu, adjoint):
 
 def test_unsupported_gradient_requests_raise(ion, gpu):
     from torchdiffeq import odeint
-    truth = M.HodgkinHuxley(K.P_HH)
+    truth = M.Markov6(K.P_M6)
     truth.set_fixed_form_voltage_protocol(*K.activation(20)[:2])
-    with pytest.raises(NotImplementedError, match="closed-form"):
-        odeint(truth, torch.tensor([[0.0, 1.0]], requires_grad=True), torch.linspace(0.0, 100.0, 11))
+    with pytest.raises(NotImplementedError, match="6-state"):
+        odeint(truth, torch.tensor([[0.0, 1.0, 0.0, 0.0, 0.0, 0.0]], requires_grad=True), torch.linspace(0.0, 100.0, 11))
+
+
+def test_dropin_odeint_differentiates_the_hh_module(ion, gpu):
+    """`odeint(Lambda(), y0, t)` with y0 requiring grad (train-s1.py:161-177 module): d(sum of the trace)/dy0 equals central
+    finite differences of the same call (fp64 state; the step sequence is frozen in the derivative, free in the differences:
+    agreement to the integrator's tolerance)."""
+    from torchdiffeq import odeint
+    truth = M.HodgkinHuxley(K.P_HH)
+    tp, vp, _ = K.activation(20)
+    truth.set_fixed_form_voltage_protocol(tp, vp)
+    t = torch.linspace(0.0, 600.0, 61, dtype=torch.float64)
+    y0 = torch.tensor([[0.05, 0.9]], dtype=torch.float64, requires_grad=True)
+    out = odeint(truth, y0, t)
+    assert out.requires_grad and out.shape == (61, 1, 2)
+    out.sum().backward()
+    g = y0.grad.clone()
+    with torch.no_grad():
+        for d in range(2):
+            e = torch.zeros_like(y0); e[0, d] = 1e-5
+            fd = (odeint(truth, (y0 + e).detach(), t).sum() - odeint(truth, (y0 - e).detach(), t).sum()) / 2e-5
+            assert abs(float(fd) - float(g[0, d])) <= 2e-4 * max(1.0, abs(float(fd)))
 
 
 def _rand_weights(L, N, seed):
@@ -250,3 +271,55 @@ def test_launch_order_leaves_gradients_in_the_callers_order(ion, gpu):
     assert torch.equal(yb, ya.index_select(0, order))
     assert torch.equal(gpa, gpb) and torch.equal(gya, gyb)
     assert float((gwa - gwb).norm() / gwa.norm()) < 1e-5
+
+
+@pytest.mark.parametrize("f32", [False, True])
+def test_hh2_closed_form_gradients_against_the_checker(ion, gpu, oracle, f32):
+    """The backward sweep of the HH 2-state model (train-s1.py:161-177; the same kernel without the MLP collective): dL/dp1..p8
+    and dL/dy0 of every trajectory against autograd through the torch replay of the oracle's accepted steps (evaluated here);
+    ragged batch, uniform and explicit protocol grids, one failing trajectory, chunked sweep.  fp32 state: the replay is
+    anchored on the forward's own states (as for the fixtures), times formed in fp32."""
+    import grad_check as G
+    rng = np.random.default_rng(41 + int(f32))
+    B = 37
+    pv = np.stack([K.atau(30)[1][900:1300], K.atau(100)[1][900:1300], K.activation(20)[1][:400]])
+    te = np.arange(0.0, 140.0, 1.0)
+    params = np.tile(K.P_HH, (B, 1)) * rng.uniform(0.8, 1.25, (B, 8))
+    pot = rng.integers(0, 3, B).astype(np.int32)
+    y0 = np.stack([rng.uniform(0.0, 0.3, B), rng.uniform(0.6, 1.0, B)], 1)
+    if f32:
+        y0 = y0.astype(np.float32).astype(np.float64)
+    y0[11, 1] = np.nan
+    coef = rng.normal(size=(B, te.size, 2))
+    sdt = torch.float32 if f32 else torch.float64
+    for pt in (None, np.arange(400, dtype=np.float64) + np.concatenate([[0.0], rng.uniform(-1e-7, 1e-7, 399)])):
+        p = torch.from_numpy(params).to(gpu).requires_grad_(True)
+        y0t = torch.from_numpy(y0).to(gpu).to(sdt).requires_grad_(True)
+        y, status = ion.grad.solve(K.MODEL_HH2, None, p, torch.from_numpy(pv).to(gpu), y0t, torch.from_numpy(te).to(gpu),
+                                   prot_t=None if pt is None else torch.from_numpy(pt).to(gpu), prot_t0=0.0, prot_dt=1.0,
+                                   prot_of_traj=torch.from_numpy(pot).to(gpu), ckpt_cap=16)        # too small: regrown
+        st = status.cpu().numpy()
+        assert st[11] != 0 and (np.delete(st, 11) == 0).all()
+        ok = torch.from_numpy(st == 0).to(gpu)
+        (torch.nan_to_num(y.double()) * torch.from_numpy(coef).to(gpu) * ok[:, None, None]).sum().backward()
+        gp, gy0 = p.grad.cpu().numpy(), y0t.grad.double().cpu().numpy()
+        assert np.all(gp[11] == 0) and np.all(gy0[11] == 0)
+        ptx = np.arange(400, dtype=np.float64) if pt is None else pt
+        worst = 0.0
+        for b in [b for b in range(B) if b != 11][::3]:
+            o = oracle.solve(K.MODEL_HH2, params[b], pv[pot[b]], y0[b], te, prot_t=pt, prot_t0=0.0, prot_dt=1.0, state_f32=f32,
+                             step_log_cap=8192)
+            assert np.array_equal(y[b].detach().double().cpu().numpy(), o["y"][0])      # the differentiable forward is the forward
+            steps = G.accepted_steps(o["step_log"])
+            pb = torch.tensor(params[b], dtype=torch.float64, requires_grad=True)
+            yb = torch.tensor(y0[b], dtype=torch.float64, requires_grad=True)
+            anchors = None
+            if f32:   # end states of the accepted steps, from a second oracle run that reports every step end
+                ends = np.array([t0 + dt for t0, dt in steps])
+                anchors = oracle.solve(K.MODEL_HH2, params[b], pv[pot[b]], y0[b], np.concatenate([[te[0]], ends]), prot_t=pt,
+                                       prot_t0=0.0, prot_dt=1.0, state_f32=True)["y"][0][1:]
+            yr = G.replay(K.MODEL_HH2, None, 0, 0, pb, yb, ptx, pv[pot[b]], te, steps, f32_times=f32, anchors=anchors)
+            (yr * torch.from_numpy(coef[b])).sum().backward()
+            worst = max(worst, _rel(gp[b], pb.grad.numpy()), _rel(gy0[b], yb.grad.numpy()))
+        print(f"HH2 {'f32' if f32 else 'f64'} {'explicit' if pt is not None else 'uniform'} grid: worst rel-L2 vs checker {worst:.2e}")
+        assert worst <= GRAD_REL_TOL
