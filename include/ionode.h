@@ -190,13 +190,14 @@ size_t ionode_grad_record_floats(int32_t mlp_layers, int32_t mlp_width);
 /*
  * Backward sweep, asynchronous on `stream`.  d: the forward launch's descriptor (model, state dtype, sizes, protocol grid,
  * v_oob, ckpt, ckpt_cap).
- *   grad_image   device, ionode_grad_image_floats() floats
+ *   (D = n_state, NPAR = 8, or 12 for the 6-state model)
+ *   grad_image   device, ionode_grad_image_floats() floats (NULL for the closed-form models)
  *   n_accepted   device, [B] int32: accepted steps to replay per trajectory (0 = contributes nothing)
- *   grad_y       device, [B][n_out][2] dL/dy_out in the state dtype
- *   state        device, [B][12] fp64 scratch carried between chunk launches (need not be initialised for it_begin == 0)
+ *   grad_y       device, [B][n_out][D] dL/dy_out in the state dtype
+ *   state        device, [B][2 D + NPAR] fp64 scratch carried between chunk launches (need not be initialised for it_begin == 0)
  *   records      device, [ceil(B/16)][it_end - it_begin][6][record floats] fp32, or NULL to skip the weight-gradient stream
- *   grad_params  device, [B][8] fp64 dL/dp1..p8      (written by the launch with it_end == n_iter)
- *   grad_y0      device, [B][2] fp64 dL/dy0
+ *   grad_params  device, [B][NPAR] fp64 dL/dp      (written by the launch with it_end == n_iter)
+ *   grad_y0      device, [B][D] fp64 dL/dy0
  */
 int ionode_dopri5_backward(const ionode_desc *d, int32_t it_begin, int32_t it_end, int32_t n_iter, const float *grad_image,
                            const double *params, const double *prot_v, const double *prot_t, const int32_t *prot_of_traj,

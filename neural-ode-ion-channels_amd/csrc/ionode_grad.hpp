@@ -328,11 +328,11 @@ struct GradMlp {
 
 template <int MODEL, typename S, int NT>
 __global__ void __launch_bounds__(256) ionode_dopri5_backward_kernel(const GArgs a) {
-  static_assert(MODEL == IONODE_MODEL_NNF || MODEL == IONODE_MODEL_NND || MODEL == IONODE_MODEL_HH2, "backward sweep: 2-state models");
-  constexpr int D = 2;
+  constexpr int D = ModelTraits<MODEL>::D, NPAR = ModelTraits<MODEL>::NPAR;
+  constexpr bool M6 = MODEL == IONODE_MODEL_MARKOV6;  // 6-state model (train-d1.py:165-187): f = M(rates(V)) y, closed form
   // HH 2-state (train-s1.py:161-177): the same sweep without the MLP collective -- da/dt = k1 (1 - a) - k2 a is the closed-form
   // a-term of NN-d, so the kernel only skips the vector-Jacobian product and the record stream (NT is 1 and unused)
-  constexpr bool HAS_MLP = MODEL != IONODE_MODEL_HH2;
+  constexpr bool HAS_MLP = ModelTraits<MODEL>::MLP;
   constexpr bool NND = MODEL == IONODE_MODEL_NND || MODEL == IONODE_MODEL_HH2;  // closed-form a-gate terms
   using R = Real<S>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -346,15 +346,15 @@ __global__ void __launch_bounds__(256) ionode_dopri5_backward_kernel(const GArgs
   const bool writer = valid && wave == 0 && lane < 16;
 
   GradMlp<NT> mlp;
-  double *__restrict__ Gs = reinterpret_cast<double *>(smem);  // [16][10] fp64 scratch
+  double *__restrict__ Gs = reinterpret_cast<double *>(smem);  // [16][5 * D] fp64 scratch
   if constexpr (HAS_MLP) {
     mlp.init(a, smem, wave, lane);
     Gs = mlp.gs();
   }
 
-  double p[8];
+  double p[NPAR];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) p[i] = a.k.params[(size_t)traj * a.k.n_params + i];
+  for (int i = 0; i < NPAR; ++i) p[i] = a.k.params[(size_t)traj * a.k.n_params + i];
   const int pidx = a.k.prot_of_traj ? a.k.prot_of_traj[traj] : (traj % a.k.P);
   const double *__restrict__ pv = a.k.prot_v + (size_t)pidx * a.k.Np;
   const int nst = valid ? a.nacc[traj] : 0;
@@ -363,13 +363,14 @@ __global__ void __launch_bounds__(256) ionode_dopri5_backward_kernel(const GArgs
   const S *__restrict__ gy = reinterpret_cast<const S *>(a.grad_y) + (size_t)traj * a.k.Nt * D;
   const int Nt = a.k.Nt;
 
-  double lam[D], mu[D], gp[8];
+  constexpr int STATE = 2 * D + NPAR;  // adjoint state carried between chunk launches (== GRAD_STATE for the 2-state models)
+  double lam[D], mu[D], gp[NPAR];
   {
-    const double *st = a.state + (size_t)traj * GRAD_STATE;
+    const double *st = a.state + (size_t)traj * STATE;
 #pragma unroll
-    for (int d = 0; d < D; ++d) { lam[d] = a.it_begin > 0 ? st[d] : 0.0; mu[d] = a.it_begin > 0 ? st[2 + d] : 0.0; }
+    for (int d = 0; d < D; ++d) { lam[d] = a.it_begin > 0 ? st[d] : 0.0; mu[d] = a.it_begin > 0 ? st[D + d] : 0.0; }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) gp[i] = a.it_begin > 0 ? st[4 + i] : 0.0;
+    for (int i = 0; i < NPAR; ++i) gp[i] = a.it_begin > 0 ? st[2 * D + i] : 0.0;
   }
 
   for (int it = a.it_begin; it < a.it_end; ++it) {
@@ -435,7 +436,7 @@ __global__ void __launch_bounds__(256) ionode_dopri5_backward_kernel(const GArgs
 #pragma unroll
         for (int c = 0; c < 5; ++c)
 #pragma unroll
-          for (int d = 0; d < D; ++d) Gs[jj * 10 + c * D + d] = P[c][d];
+          for (int d = 0; d < D; ++d) Gs[jj * (5 * D) + c * D + d] = P[c][d];
       }
     }
     __syncthreads();
@@ -443,7 +444,7 @@ __global__ void __launch_bounds__(256) ionode_dopri5_backward_kernel(const GArgs
 #pragma unroll
     for (int c = 0; c < 5; ++c)
 #pragma unroll
-      for (int d = 0; d < D; ++d) Gc[c][d] = Gs[j * 10 + c * D + d];
+      for (int d = 0; d < D; ++d) Gc[c][d] = Gs[j * (5 * D) + c * D + d];
 
     // ---- interpolant adjoint -> (Y0, Y1, k1..k7); FSAL carry (tests/grad_check.py manual_adjoint) ----
     double aY0[D], aY1[D], ak[7][D];
@@ -485,6 +486,34 @@ __global__ void __launch_bounds__(256) ionode_dopri5_backward_kernel(const GArgs
       }
       double v;
       protocol_v(a.k, pv, tq, v);
+      double w[D];
+      if constexpr (M6) {
+        // f = M(rates) y (train-d1.py:165-187): w = M^T seed; rate_i = p[2i] exp(+-p[2i+1] V), g_i = seed . df/drate_i
+        double ex[6], r[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { ex[q] = det_exp(((q & 1) ? -p[2 * q + 1] : p[2 * q + 1]) * v); r[q] = p[2 * q] * ex[q]; }
+        const double a1 = r[0], b1 = r[1], bh = r[2], ah = r[3], a2 = r[4], b2 = r[5];
+        const double c1 = Yi[0], c2 = Yi[1], in = Yi[2], ic1 = Yi[3], ic2 = Yi[4], o = Yi[5];
+        const double s0 = seed[0], s1 = seed[1], s2 = seed[2], s3 = seed[3], s4 = seed[4], s5 = seed[5];
+        w[0] = -(b1 + bh + a2) * s0 + b1 * s1 + bh * s3 + a2 * s5;
+        w[1] = a1 * s0 - (a1 + bh) * s1 + bh * s4;
+        w[2] = -(b2 + ah) * s2 + b2 * s3 + ah * s5;
+        w[3] = ah * s0 + a2 * s2 - (b1 + ah + a2) * s3 + b1 * s4;
+        w[4] = ah * s1 + a1 * s3 - (ah + a1) * s4;
+        w[5] = b2 * s0 + bh * s2 - (b2 + bh) * s5;
+        double g[6];
+        g[0] = (s0 - s1) * c2 + (s3 - s4) * ic2;                                    // a1
+        g[1] = (s1 - s0) * c1 + (s4 - s3) * ic1;                                    // b1
+        g[2] = (s3 - s0) * c1 + (s4 - s1) * c2 + (s2 - s5) * o;                     // bh
+        g[3] = (s0 - s3) * ic1 + (s1 - s4) * ic2 + (s5 - s2) * in;                  // ah
+        g[4] = (s5 - s0) * c1 + (s2 - s3) * ic1;                                    // a2
+        g[5] = (s0 - s5) * o + (s3 - s2) * in;                                      // b2
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          gp[2 * q] += g[q] * ex[q];
+          gp[2 * q + 1] += g[q] * r[q] * ((q & 1) ? -v : v);
+        }
+      } else {
       const double av = Yi[0], rv = Yi[1];
       const float x0 = (float)(v / 100.0), x1 = (float)av;
       const float seedf = (float)(seed[0] / 1000.0);
@@ -493,7 +522,6 @@ __global__ void __launch_bounds__(256) ionode_dopri5_backward_kernel(const GArgs
       // closed-form terms of the RHS and their parameter gradients
       const double e3 = det_exp(p[5] * v), e4 = det_exp(-p[7] * v);
       const double k3 = p[4] * e3, k4 = p[6] * e4;
-      double w[D];
       w[0] = (double)dx1;
       w[1] = -seed[1] * (k3 + k4);
       gp[4] += seed[1] * (-e3 * rv);
@@ -508,6 +536,7 @@ __global__ void __launch_bounds__(256) ionode_dopri5_backward_kernel(const GArgs
         gp[1] += seed[0] * (k1 * v * (1.0 - av));
         gp[2] += seed[0] * (-e2 * av);
         gp[3] += seed[0] * (k2 * v * av);
+      }
       }
       if (step) {
 #pragma unroll
@@ -529,14 +558,14 @@ __global__ void __launch_bounds__(256) ionode_dopri5_backward_kernel(const GArgs
   }
 
   if (writer) {
-    double *st = a.state + (size_t)traj * GRAD_STATE;
+    double *st = a.state + (size_t)traj * STATE;
 #pragma unroll
-    for (int d = 0; d < D; ++d) { st[d] = lam[d]; st[2 + d] = mu[d]; }
+    for (int d = 0; d < D; ++d) { st[d] = lam[d]; st[D + d] = mu[d]; }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) st[4 + i] = gp[i];
+    for (int i = 0; i < NPAR; ++i) st[2 * D + i] = gp[i];
     if (a.it_end >= a.n_iter) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) a.grad_params[(size_t)traj * 8 + i] = gp[i];
+      for (int i = 0; i < NPAR; ++i) a.grad_params[(size_t)traj * NPAR + i] = gp[i];
 #pragma unroll
       for (int d = 0; d < D; ++d) a.grad_y0[(size_t)traj * D + d] = lam[d] + (double)gy[d];  // solution[0] = y0
     }

@@ -98,9 +98,10 @@ int ionode_dopri5_backward(const ionode_desc *d, int32_t it_begin, int32_t it_en
                            const double *t_eval, const int32_t *n_accepted, const void *grad_y, double *state,
                            float *records, double *grad_params, double *grad_y0, void *stream) {
   if (!d) { gerr("null descriptor"); return IONODE_ERR_ARG; }
-  const bool hh2 = d->model == IONODE_MODEL_HH2;
-  if (d->model != IONODE_MODEL_NNF && d->model != IONODE_MODEL_NND && !hh2) { gerr("backward sweep: NN-f / NN-d / HH 2-state only"); return IONODE_ERR_UNSUPPORTED; }
-  if (d->n_state != 2 || d->n_traj < 1 || d->n_out < 1 || d->n_prot < 1 || d->prot_n < 2 || d->n_params < 8 || !(d->prot_dt > 0)) {
+  const bool m6 = d->model == IONODE_MODEL_MARKOV6;
+  const bool hh2 = d->model == IONODE_MODEL_HH2 || m6;  // closed-form models: no MLP image, no records
+  if (d->model < 0 || d->model > 3) { gerr("backward sweep: unknown model"); return IONODE_ERR_UNSUPPORTED; }
+  if (d->n_state != (m6 ? 6 : 2) || d->n_traj < 1 || d->n_out < 1 || d->n_prot < 1 || d->prot_n < 2 || d->n_params < (m6 ? 12 : 8) || !(d->prot_dt > 0)) {
     gerr("inconsistent descriptor"); return IONODE_ERR_ARG;
   }
   if ((!grad_image && !hh2) || !params || !prot_v || !t_eval || !n_accepted || !grad_y || !state || !grad_params || !grad_y0 || !d->ckpt || d->ckpt_cap < 1) {
@@ -109,9 +110,10 @@ int ionode_dopri5_backward(const ionode_desc *d, int32_t it_begin, int32_t it_en
   if (it_begin < 0 || it_end <= it_begin || it_end > n_iter) { gerr("bad iteration range"); return IONODE_ERR_ARG; }
   if (!hh2 && (d->mlp_layers < 1 || d->mlp_width < 1)) { gerr("bad MLP shape"); return IONODE_ERR_ARG; }
   const int NP = hh2 ? 16 : np_of(d->mlp_width), NT = NP / 16, L = hh2 ? 0 : d->mlp_layers;
-  SweepFn fn = hh2 ? (d->state_f32 ? &launch_sweep<IONODE_MODEL_HH2, float, 1> : &launch_sweep<IONODE_MODEL_HH2, double, 1>)
-                   : find_sweep(d->model, d->state_f32 ? 1 : 0, NT);
-  const size_t lds = hh2 ? (size_t)16 * 10 * 8 : ionode::grad_lds_bytes(L, NT);
+  SweepFn fn = m6 ? (d->state_f32 ? &launch_sweep<IONODE_MODEL_MARKOV6, float, 1> : &launch_sweep<IONODE_MODEL_MARKOV6, double, 1>)
+               : hh2 ? (d->state_f32 ? &launch_sweep<IONODE_MODEL_HH2, float, 1> : &launch_sweep<IONODE_MODEL_HH2, double, 1>)
+                     : find_sweep(d->model, d->state_f32 ? 1 : 0, NT);
+  const size_t lds = hh2 ? (size_t)16 * 5 * (m6 ? 6 : 2) * 8 : ionode::grad_lds_bytes(L, NT);
   if (!fn || lds > 160 * 1024) {
     gerr("backward sweep: (L, N) outside the compiled variants (N pads to 16, 112 or 208 and (L + 3) * N * 64 B must fit 160 KB of LDS)");
     return IONODE_ERR_UNSUPPORTED;

@@ -87,7 +87,7 @@ class _Solve(torch.autograd.Function):
             from . import batched  # packed forward image: shared cache with the plain solve
             packed = batched.packed_weights(w_np, L, N, dev, key=cfg.get("weights_key"))
         while True:
-            ckpt = torch.empty((B, cap, 20), dtype=torch.float64, device=dev)
+            ckpt = torch.empty((B, cap, 4 + 8 * y0.shape[1]), dtype=torch.float64, device=dev)
             r = capi.dopri5(cfg["model"], params.detach(), cfg["prot_v"], y0.detach(), cfg["t_eval"], mlp_packed=packed,
                             mlp_layers=L, mlp_width=N, prot_t=cfg.get("prot_t"), prot_t0=cfg["prot_t0"], prot_dt=cfg["prot_dt"],
                             prot_of_traj=cfg.get("prot_of_traj"), rtol=cfg["rtol"], atol=cfg["atol"], v_oob=cfg["v_oob"],
@@ -119,9 +119,10 @@ class _Solve(torch.autograd.Function):
         n_acc = torch.where(status == 0, stats[:, 0], torch.zeros_like(stats[:, 0])).to(torch.int32).contiguous()
         n_iter = int(n_acc.max().item()) + 1
         image = grad_image(ctx.w_np, L, N, dev, key=cfg.get("weights_key")) if ctx.w_np is not None else None
-        state = torch.empty((B, 12), dtype=torch.float64, device=dev)
-        g_params = torch.zeros((B, 8), dtype=torch.float64, device=dev)
-        g_y0 = torch.zeros((B, 2), dtype=torch.float64, device=dev)
+        D, npar = desc.n_state, (12 if desc.model == capi.MODEL_MARKOV6 else 8)
+        state = torch.empty((B, 2 * D + npar), dtype=torch.float64, device=dev)
+        g_params = torch.zeros((B, npar), dtype=torch.float64, device=dev)
+        g_y0 = torch.zeros((B, D), dtype=torch.float64, device=dev)
         tiles = (B + 15) // 16
         recf = lib.ionode_grad_record_floats(L, N) if need_w else 0
         partf = lib.ionode_grad_partial_floats(L, N) if need_w else 0
@@ -175,7 +176,8 @@ class _Solve(torch.autograd.Function):
 def solve(model, weights_flat, params, prot_v, y0, t_eval, *, mlp_layers=0, mlp_width=0, prot_t=None, prot_t0=0.0,
           prot_dt=1.0, prot_of_traj=None, rtol=1e-7, atol=1e-9, v_oob=-80.0, max_steps=0, max_total_steps=0, max_step=0.0,
           ckpt_cap=None, record_budget_bytes=None, weights_key=None, t_eval_hint="auto", order=None):
-    """Differentiable batched solve.  weights_flat [n] fp32 (reference state-dict order), params [B, 8] fp64, y0 [B, 2]
+    """Differentiable batched solve.  weights_flat [n] fp32 (reference state-dict order; None for the closed-form HH 2-state
+    and 6-state models, whose params are [B, 8] / [B, 12] and y0 [B, 2] / [B, 6]), params [B, 8] fp64, y0 [B, 2]
     fp32 | fp64 (the state dtype) -- device tensors, any of which may require grad; prot_v [P, Np], t_eval [Nt] fp64 device
     tensors.  Returns (y [B, Nt, 2], status [B]): gradients of failed trajectories (status != 0) are zero.
 
@@ -189,13 +191,13 @@ def solve(model, weights_flat, params, prot_v, y0, t_eval, *, mlp_layers=0, mlp_
     tiles, expensive tiles first -- pays from two tiles per compute unit, B > 4096); y and status are then in LAUNCH order
     (row k = trajectory order[k]), and the gradients still arrive at params / y0 in the caller's order (the gather is part of
     the autograd graph)."""
-    if model == capi.MODEL_HH2:
-        # closed-form 2-state model (train-s1.py:161-177): gradients w.r.t. p1..p8 and y0; there are no weights
+    if model in (capi.MODEL_HH2, capi.MODEL_MARKOV6):
+        # closed-form models (train-s1.py:161-177, train-d1.py:165-187): gradients w.r.t. the rate parameters and y0; no weights
         if weights_flat is not None:
-            raise capi.IonodeError("the HH 2-state model has no MLP: pass weights_flat=None")
+            raise capi.IonodeError("the closed-form models have no MLP: pass weights_flat=None")
         mlp_layers = mlp_width = 0
     elif model not in (capi.MODEL_NNF, capi.MODEL_NND):
-        raise NotImplementedError("gradients through the solve are built for the NN-f / NN-d / HH 2-state right-hand sides")
+        raise NotImplementedError("unknown model")
     if not (isinstance(y0, torch.Tensor) and y0.is_cuda):
         raise capi.IonodeError("no HIP tensors: the integrator and its backward sweep have no CPU path")
     if order is not None:

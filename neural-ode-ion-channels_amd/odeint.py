@@ -78,8 +78,8 @@ def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, even
     return out.to(y0.device)
 
 
-def _rate_tensors(func):
-    return [getattr(func, f"p{i}", None) for i in range(1, 9)]
+def _rate_tensors(func, n=12):
+    return [getattr(func, f"p{i}", None) for i in range(1, n + 1)]
 
 
 def _wants_grad(func, y0):
@@ -92,16 +92,12 @@ def _wants_grad(func, y0):
 
 def _odeint_with_grad(func, y0, t, spec, rtol, atol, options):
     """Differentiable call: same forward kernel (plus accepted-step checkpoints), backward sweep on demand."""
-    if spec.model not in (capi.MODEL_NNF, capi.MODEL_NND, capi.MODEL_HH2):
-        raise NotImplementedError(
-            "odeint: a gradient was requested through the 6-state RHS module; the backward sweep is built for the NN-f / NN-d / "
-            "HH 2-state modules.  Call under torch.no_grad() (as the reference does) for forward values.")
     dev = batched._dev()
     flat = None
-    if spec.model != capi.MODEL_HH2:
+    if spec.model in (capi.MODEL_NNF, capi.MODEL_NND):
         lin = [m for m in func.net if isinstance(m, torch.nn.Linear)]
         flat = torch.cat([x.reshape(-1) for m in lin for x in (m.weight, m.bias)]).to(dev)
-    rates = _rate_tensors(func)
+    rates = _rate_tensors(func, 12 if spec.model == capi.MODEL_MARKOV6 else 8)
     if any(isinstance(p, torch.Tensor) and p.requires_grad for p in rates):
         cols = [(p.reshape(()).to(device=dev, dtype=torch.float64) if isinstance(p, torch.Tensor)
                  else torch.tensor(float(0.0 if p is None else p), dtype=torch.float64, device=dev)) for p in rates]

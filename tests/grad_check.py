@@ -60,8 +60,22 @@ def protocol_v(t, prot_t, prot_v, v_oob=-80.0):
     return float(np.interp(t, prot_t, prot_v))
 
 
+MODEL_MARKOV6 = 1
+
+
 def rhs(model, layers, p, v, y, net_dtype):
-    """func.forward(t, y) with V(t) already looked up.  y [2] fp64, p [8] fp64 tensors."""
+    """func.forward(t, y) with V(t) already looked up.  y [2] fp64, p [8] fp64 tensors (6-state: y [6], p [12])."""
+    if model == MODEL_MARKOV6:  # train-d1.py:165-187
+        a1, b1 = p[0] * torch.exp(p[1] * v), p[2] * torch.exp(-p[3] * v)
+        bh, ah = p[4] * torch.exp(p[5] * v), p[6] * torch.exp(-p[7] * v)
+        a2, b2 = p[8] * torch.exp(p[9] * v), p[10] * torch.exp(-p[11] * v)
+        c1, c2, i_, ic1, ic2, o = y[0], y[1], y[2], y[3], y[4], y[5]
+        return torch.stack([a1 * c2 + ah * ic1 + b2 * o - (b1 + bh + a2) * c1,
+                            b1 * c1 + ah * ic2 - (a1 + bh) * c2,
+                            a2 * ic1 + bh * o - (b2 + ah) * i_,
+                            a1 * ic2 + bh * c1 + b2 * i_ - (b1 + ah + a2) * ic1,
+                            b1 * ic1 + bh * c2 - (ah + a1) * ic2,
+                            a2 * c1 + ah * i_ - (b2 + bh) * o])
     a, r = y[0], y[1]
     k3 = p[4] * torch.exp(p[5] * v)
     k4 = p[6] * torch.exp(-p[7] * v)

@@ -121,33 +121,31 @@ def test_dropin_odeint_gives_module_gradients(ion, gpu, adjoint):
         assert not odeint(func, y0t, torch.from_numpy(te)).requires_grad
 
 
-def test_unsupported_gradient_requests_raise(ion, gpu):
+@pytest.mark.parametrize("which", ["hh", "markov6"])
+def test_dropin_odeint_differentiates_the_closed_form_modules(ion, gpu, which):
+    """`odeint(Lambda(), y0, t)` with y0 requiring grad (train-s1.py:161-177 / train-d1.py:165-187 modules): d(weighted sum of
+    the trace)/dy0 equals central finite differences of the same call (fp64 state; the step sequence is frozen in the
+    derivative, free in the differences: agreement to the integrator's tolerance)."""
     from torchdiffeq import odeint
-    truth = M.Markov6(K.P_M6)
-    truth.set_fixed_form_voltage_protocol(*K.activation(20)[:2])
-    with pytest.raises(NotImplementedError, match="6-state"):
-        odeint(truth, torch.tensor([[0.0, 1.0, 0.0, 0.0, 0.0, 0.0]], requires_grad=True), torch.linspace(0.0, 100.0, 11))
-
-
-def test_dropin_odeint_differentiates_the_hh_module(ion, gpu):
-    """`odeint(Lambda(), y0, t)` with y0 requiring grad (train-s1.py:161-177 module): d(sum of the trace)/dy0 equals central
-    finite differences of the same call (fp64 state; the step sequence is frozen in the derivative, free in the differences:
-    agreement to the integrator's tolerance)."""
-    from torchdiffeq import odeint
-    truth = M.HodgkinHuxley(K.P_HH)
+    if which == "hh":
+        truth, y0v = M.HodgkinHuxley(K.P_HH), [[0.05, 0.9]]
+    else:
+        truth, y0v = M.Markov6(K.P_M6), [[0.05, 0.8, 0.02, 0.03, 0.05, 0.05]]
     tp, vp, _ = K.activation(20)
     truth.set_fixed_form_voltage_protocol(tp, vp)
     t = torch.linspace(0.0, 600.0, 61, dtype=torch.float64)
-    y0 = torch.tensor([[0.05, 0.9]], dtype=torch.float64, requires_grad=True)
+    y0 = torch.tensor(y0v, dtype=torch.float64, requires_grad=True)
+    D = y0.shape[1]
+    cw = torch.linspace(0.5, 1.5, D, dtype=torch.float64)
     out = odeint(truth, y0, t)
-    assert out.requires_grad and out.shape == (61, 1, 2)
-    out.sum().backward()
+    assert out.requires_grad and out.shape == (61, 1, D)
+    (out * cw).sum().backward()
     g = y0.grad.clone()
     with torch.no_grad():
-        for d in range(2):
+        for d in range(D):
             e = torch.zeros_like(y0); e[0, d] = 1e-5
-            fd = (odeint(truth, (y0 + e).detach(), t).sum() - odeint(truth, (y0 - e).detach(), t).sum()) / 2e-5
-            assert abs(float(fd) - float(g[0, d])) <= 2e-4 * max(1.0, abs(float(fd)))
+            fd = ((odeint(truth, (y0 + e).detach(), t) * cw).sum() - (odeint(truth, (y0 - e).detach(), t) * cw).sum()) / 2e-5
+            assert abs(float(fd) - float(g[0, d])) <= 2e-4 * max(1.0, abs(float(fd))), (d, float(fd), float(g[0, d]))
 
 
 def _rand_weights(L, N, seed):
@@ -273,10 +271,11 @@ def test_launch_order_leaves_gradients_in_the_callers_order(ion, gpu):
     assert float((gwa - gwb).norm() / gwa.norm()) < 1e-5
 
 
+@pytest.mark.parametrize("model", [K.MODEL_HH2, K.MODEL_MARKOV6])
 @pytest.mark.parametrize("f32", [False, True])
-def test_hh2_closed_form_gradients_against_the_checker(ion, gpu, oracle, f32):
-    """The backward sweep of the HH 2-state model (train-s1.py:161-177; the same kernel without the MLP collective): dL/dp1..p8
-    and dL/dy0 of every trajectory against autograd through the torch replay of the oracle's accepted steps (evaluated here);
+def test_closed_form_gradients_against_the_checker(ion, gpu, oracle, f32, model):
+    """The backward sweep of the closed-form models (HH 2-state, train-s1.py:161-177, and 6-state, train-d1.py:165-187; the same
+    kernel without the MLP collective): dL/dp and dL/dy0 of every trajectory against autograd through the torch replay of the oracle's accepted steps (evaluated here);
     ragged batch, uniform and explicit protocol grids, one failing trajectory, chunked sweep.  fp32 state: the replay is
     anchored on the forward's own states (as for the fixtures), times formed in fp32."""
     import grad_check as G
@@ -284,18 +283,22 @@ def test_hh2_closed_form_gradients_against_the_checker(ion, gpu, oracle, f32):
     B = 37
     pv = np.stack([K.atau(30)[1][900:1300], K.atau(100)[1][900:1300], K.activation(20)[1][:400]])
     te = np.arange(0.0, 140.0, 1.0)
-    params = np.tile(K.P_HH, (B, 1)) * rng.uniform(0.8, 1.25, (B, 8))
+    m6 = model == K.MODEL_MARKOV6
+    D = 6 if m6 else 2
+    params = np.tile(K.P_M6 if m6 else K.P_HH, (B, 1)) * rng.uniform(0.8, 1.25, (B, 12 if m6 else 8))
     pot = rng.integers(0, 3, B).astype(np.int32)
     y0 = np.stack([rng.uniform(0.0, 0.3, B), rng.uniform(0.6, 1.0, B)], 1)
+    if m6:
+        y0 = np.concatenate([y0, rng.uniform(0.0, 0.1, (B, 4))], 1)
     if f32:
         y0 = y0.astype(np.float32).astype(np.float64)
     y0[11, 1] = np.nan
-    coef = rng.normal(size=(B, te.size, 2))
+    coef = rng.normal(size=(B, te.size, D))
     sdt = torch.float32 if f32 else torch.float64
     for pt in (None, np.arange(400, dtype=np.float64) + np.concatenate([[0.0], rng.uniform(-1e-7, 1e-7, 399)])):
         p = torch.from_numpy(params).to(gpu).requires_grad_(True)
         y0t = torch.from_numpy(y0).to(gpu).to(sdt).requires_grad_(True)
-        y, status = ion.grad.solve(K.MODEL_HH2, None, p, torch.from_numpy(pv).to(gpu), y0t, torch.from_numpy(te).to(gpu),
+        y, status = ion.grad.solve(model, None, p, torch.from_numpy(pv).to(gpu), y0t, torch.from_numpy(te).to(gpu),
                                    prot_t=None if pt is None else torch.from_numpy(pt).to(gpu), prot_t0=0.0, prot_dt=1.0,
                                    prot_of_traj=torch.from_numpy(pot).to(gpu), ckpt_cap=16)        # too small: regrown
         st = status.cpu().numpy()
@@ -307,7 +310,7 @@ def test_hh2_closed_form_gradients_against_the_checker(ion, gpu, oracle, f32):
         ptx = np.arange(400, dtype=np.float64) if pt is None else pt
         worst = 0.0
         for b in [b for b in range(B) if b != 11][::3]:
-            o = oracle.solve(K.MODEL_HH2, params[b], pv[pot[b]], y0[b], te, prot_t=pt, prot_t0=0.0, prot_dt=1.0, state_f32=f32,
+            o = oracle.solve(model, params[b], pv[pot[b]], y0[b], te, prot_t=pt, prot_t0=0.0, prot_dt=1.0, state_f32=f32,
                              step_log_cap=8192)
             assert np.array_equal(y[b].detach().double().cpu().numpy(), o["y"][0])      # the differentiable forward is the forward
             steps = G.accepted_steps(o["step_log"])
@@ -316,10 +319,10 @@ def test_hh2_closed_form_gradients_against_the_checker(ion, gpu, oracle, f32):
             anchors = None
             if f32:   # end states of the accepted steps, from a second oracle run that reports every step end
                 ends = np.array([t0 + dt for t0, dt in steps])
-                anchors = oracle.solve(K.MODEL_HH2, params[b], pv[pot[b]], y0[b], np.concatenate([[te[0]], ends]), prot_t=pt,
+                anchors = oracle.solve(model, params[b], pv[pot[b]], y0[b], np.concatenate([[te[0]], ends]), prot_t=pt,
                                        prot_t0=0.0, prot_dt=1.0, state_f32=True)["y"][0][1:]
-            yr = G.replay(K.MODEL_HH2, None, 0, 0, pb, yb, ptx, pv[pot[b]], te, steps, f32_times=f32, anchors=anchors)
+            yr = G.replay(model, None, 0, 0, pb, yb, ptx, pv[pot[b]], te, steps, f32_times=f32, anchors=anchors)
             (yr * torch.from_numpy(coef[b])).sum().backward()
             worst = max(worst, _rel(gp[b], pb.grad.numpy()), _rel(gy0[b], yb.grad.numpy()))
-        print(f"HH2 {'f32' if f32 else 'f64'} {'explicit' if pt is not None else 'uniform'} grid: worst rel-L2 vs checker {worst:.2e}")
+        print(f"model {model} {'f32' if f32 else 'f64'} {'explicit' if pt is not None else 'uniform'} grid: worst rel-L2 vs checker {worst:.2e}")
         assert worst <= GRAD_REL_TOL
