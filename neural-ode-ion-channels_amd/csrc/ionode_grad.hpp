@@ -49,7 +49,8 @@ constexpr int GRAD_STATE = 12;
 // floats of one tile-evaluation record: H_0..H_L, D_0..D_L (NT tiles of 64 lanes x float4 each) + 64 scalars (x0, x1, seed, pad) x 16
 __host__ __device__ constexpr int64_t grad_record_floats(int L, int NT) { return (int64_t)2 * (L + 1) * NT * 256 + 64; }
 __host__ __device__ constexpr size_t grad_lds_bytes(int L, int NT) {
-  return ((size_t)(L + 3) * NT * 64 + (size_t)2 * (NT % 4) * 4 * 64 + 16 * NT) * 16 + ((size_t)L * 16 * NT + 16 * NT + 4) * 4 + 16 * 10 * 8;
+  // two activation buffers + two gradient buffers (ping-pong over the layers, whatever L is) + remainder partial sums + small vectors
+  return ((size_t)4 * NT * 64 + (size_t)2 * (NT % 4) * 4 * 64 + 16 * NT) * 16 + ((size_t)L * 16 * NT + 16 * NT + 4) * 4 + 16 * 10 * 8;
 }
 // image offsets (floats): rows of layer 0 {b0, w00, w01, 0} | hidden biases | wl, bl | forward fragments | transposed fragments
 __host__ __device__ constexpr size_t grad_img_bias(int NT) { return (size_t)4 * 16 * NT; }
@@ -77,7 +78,8 @@ struct GradMlp {
   // k-tile waited for its own loads: 18 us per product instead of the 6.7k-cycle MFMA floor (measured).
   f32x4 ringF[NT][FP];
   f32x4 ringR[NOWN][RP];
-  f32x4 *Hs;          // LDS [L+1][NT*64]   activations after LeakyReLU, accumulator layout
+  f32x4 *Hs;          // LDS [2][NT*64]     activations after LeakyReLU, accumulator layout, ping-pong over layers (layer l in
+                      //                    buffer l & 1); the backward pass needs only their signs, kept as bits in registers
   f32x4 *Ds;          // LDS [2][NT*64]     pre-activation gradients, ping-pong over layers
   f32x4 *Ps;          // LDS [2][R][G][64]  partial sums of the remainder row tiles, ping-pong over products
   const f32x4 *W0s;   // LDS [NP] {b0, w00, w01, 0}
@@ -90,7 +92,7 @@ struct GradMlp {
   __device__ __forceinline__ void init(const GArgs &a, unsigned char *smem, int wave_, int lane_) {
     L = a.k.L; wave = wave_; lane = lane_;
     Hs = reinterpret_cast<f32x4 *>(smem);
-    Ds = Hs + (size_t)(L + 1) * NT * 64;
+    Ds = Hs + (size_t)2 * NT * 64;
     Ps = Ds + 2 * NT * 64;
     f32x4 *w0 = Ps + 2 * R * G * 64;
     float *bs = reinterpret_cast<float *>(w0 + NP);
@@ -109,6 +111,28 @@ struct GradMlp {
   }
   __device__ __forceinline__ int ktile(int s) const { return (s + wave) % NT; }  // wave-uniform (scalar ALU)
   __device__ __forceinline__ int own_kt(int u) const { const int k = wave + G * u; return k < NT ? k : NT - 1; }  // clamped: never read past the layer
+  // LeakyReLU'(h) per layer as bits: 4 per owned full tile, then 4 per remainder tile; 16 bits per layer, layers 0..15
+  static constexpr int MAXL = 15;
+  static __device__ __forceinline__ unsigned bits_of(const f32x4 &h) {
+    return (h[0] > 0.0f ? 1u : 0u) | (h[1] > 0.0f ? 2u : 0u) | (h[2] > 0.0f ? 4u : 0u) | (h[3] > 0.0f ? 8u : 0u);
+  }
+  struct Signs {  // four 64-bit words, 16 bits per layer; scalar members (no indexed array: that would live in scratch)
+    unsigned long long w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+    __device__ __forceinline__ void put(int l, unsigned b16) {
+      const int sh = (l & 3) * 16;
+      const unsigned long long m = ~(0xffffull << sh), v = (unsigned long long)b16 << sh;
+      const int k = l >> 2;
+      w0 = (k == 0) ? ((w0 & m) | v) : w0;
+      w1 = (k == 1) ? ((w1 & m) | v) : w1;
+      w2 = (k == 2) ? ((w2 & m) | v) : w2;
+      w3 = (k == 3) ? ((w3 & m) | v) : w3;
+    }
+    __device__ __forceinline__ unsigned get(int l) const {
+      const int k = l >> 2;
+      const unsigned long long w = (k == 0) ? w0 : ((k == 1) ? w1 : ((k == 2) ? w2 : w3));
+      return (unsigned)(w >> ((l & 3) * 16)) & 0xffffu;
+    }
+  };
   __device__ __forceinline__ void refill_all(unsigned sec, int l) {
 #pragma unroll
     for (int s = 0; s < NT; ++s)
@@ -195,20 +219,41 @@ struct GradMlp {
     f32x4 *__restrict__ recD = recH + (size_t)(L + 1) * NT * 64;
     constexpr int pstride = R * G * 64;
     int par = 0;  // partial-sum buffer of the running product
-    // ---- forward recompute, every layer's activations stay in LDS.  Layer 0: row tile rt by wavefront rt % 4 ----
+    // ---- forward recompute.  The activations of layer l live in LDS buffer l & 1 (the next layer's B operand) and go to the
+    // record stream as they are produced; what the backward pass needs of them afterwards is the sign, kept here ----
+    Signs mk;
+    auto layer0 = [&](int rt) {
+      f32x4 h;
 #pragma unroll
-    for (int i = 0; i < (NT + G - 1) / G; ++i) {
-      const int rt = wave + i * G;
-      if (rt < NT) {
-        f32x4 h;
+      for (int r = 0; r < 4; ++r) {
+        const f32x4 w = W0s[16 * rt + 4 * q + r];
+        h[r] = lrelu(fmaf(w[2], x1, fmaf(w[1], x0, w[0])));
+      }
+      return h;
+    };
+    {
+      // Layer 0: full-tile slots rt = wave + 4 i by their owner; remainder tiles evaluated by EVERY wavefront (all of them need
+      // the signs when they fold d_0), stored by wavefront j
+      unsigned b16 = 0u;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const f32x4 w = W0s[16 * rt + 4 * q + r];
-          h[r] = lrelu(fmaf(w[2], x1, fmaf(w[1], x0, w[0])));
-        }
+      for (int i = 0; i < F; ++i) {
+        const int rt = wave + G * i;
+        const f32x4 h = layer0(rt);
+        b16 |= bits_of(h) << (4 * i);
         Hs[rt * 64 + lane] = h;
         if (rec) rec_store(recH + rt * 64, h);
       }
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const int rt = G * F + j;
+        const f32x4 h = layer0(rt);
+        b16 |= bits_of(h) << (4 * (F + j));
+        if (wave == j) {
+          Hs[rt * 64 + lane] = h;
+          if (rec) rec_store(recH + rt * 64, h);
+        }
+      }
+      mk.put(0, b16);
     }
     __syncthreads();
     for (int l = 1; l <= L; ++l) {
@@ -220,14 +265,17 @@ struct GradMlp {
         const f32x4 bz = *reinterpret_cast<const f32x4 *>(biasS + (l - 1) * NP + 16 * (G * F + j) + 4 * q);
         accR[j] = (wave == 0) ? bz : f32x4{0, 0, 0, 0};  // partial sum 0 carries the bias
       }
-      product(l < L ? fwd0 : bwd0, l < L ? l : L - 1, Hs + (size_t)(l - 1) * NT * 64, accF, accR);
+      product(l < L ? fwd0 : bwd0, l < L ? l : L - 1, Hs + (size_t)((l - 1) & 1) * NT * 64, accF, accR);
+      f32x4 *__restrict__ Hl = Hs + (size_t)(l & 1) * NT * 64;
+      unsigned b16 = 0u;
 #pragma unroll
       for (int i = 0; i < F; ++i) {
         const int rt = wave + G * i;
         f32x4 h;
 #pragma unroll
         for (int r = 0; r < 4; ++r) h[r] = lrelu(accF[i][r]);
-        Hs[((size_t)l * NT + rt) * 64 + lane] = h;
+        b16 |= bits_of(h) << (4 * i);
+        Hl[rt * 64 + lane] = h;
         if (rec) rec_store(recH + ((size_t)l * NT + rt) * 64, h);
       }
 #pragma unroll
@@ -241,9 +289,11 @@ struct GradMlp {
         f32x4 h;
 #pragma unroll
         for (int r = 0; r < 4; ++r) h[r] = lrelu(z[r]);
-        Hs[((size_t)l * NT + G * F + j) * 64 + lane] = h;
+        b16 |= bits_of(h) << (4 * (F + j));
+        Hl[(G * F + j) * 64 + lane] = h;
         if (rec && wave == 0) rec_store(recH + ((size_t)l * NT + G * F + j) * 64, h);
       }
+      mk.put(l, b16);
       par ^= 1;
     }
     // ---- net = wl . h_L + bl (four partial chains, one per lane group, as the forward kernel's last layer), then the seed ----
@@ -253,7 +303,7 @@ struct GradMlp {
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt) {
         const f32x4 w = *reinterpret_cast<const f32x4 *>(wlS + 16 * kt + 4 * q);
-        const f32x4 h = Hs[((size_t)L * NT + kt) * 64 + lane];
+        const f32x4 h = Hs[((size_t)(L & 1) * NT + kt) * 64 + lane];
 #pragma unroll
         for (int r = 0; r < 4; ++r) part = fmaf(w[r], h[r], part);
       }
@@ -265,7 +315,7 @@ struct GradMlp {
     for (int i = 0; i < (NT + G - 1) / G; ++i) {
       const int rt = wave + i * G;
       if (rt < NT) {
-        const f32x4 h = Hs[((size_t)L * NT + rt) * 64 + lane];
+        const f32x4 h = Hs[((size_t)(L & 1) * NT + rt) * 64 + lane];
         const f32x4 w = *reinterpret_cast<const f32x4 *>(wlS + 16 * rt + 4 * q);
         f32x4 d;
 #pragma unroll
@@ -282,13 +332,13 @@ struct GradMlp {
 #pragma unroll
       for (int j = 0; j < R; ++j) accR[j] = f32x4{0, 0, 0, 0};
       product(l > 1 ? bwd0 : fwd0, l > 1 ? l - 2 : 0, Ds + (size_t)(l & 1) * NT * 64, accF, accR);
+      const unsigned sg = mk.get(l - 1);  // signs of h_{l-1}: this wavefront's full tiles, then the remainder tiles
 #pragma unroll
       for (int i = 0; i < F; ++i) {
         const int rt = wave + G * i;
-        const f32x4 h = Hs[((size_t)(l - 1) * NT + rt) * 64 + lane];
         f32x4 d;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) d[r] = accF[i][r] * (h[r] > 0.0f ? 1.0f : 0.01f);
+        for (int r = 0; r < 4; ++r) d[r] = accF[i][r] * (((sg >> (4 * i + r)) & 1u) ? 1.0f : 0.01f);
         Ds[(((l - 1) & 1) * NT + rt) * 64 + lane] = d;
         if (rec) rec_store(recD + ((size_t)(l - 1) * NT + rt) * 64, d);
       }
@@ -298,10 +348,9 @@ struct GradMlp {
 #pragma unroll
       for (int j = 0; j < R; ++j) {
         const f32x4 z = fold(Ps + par * pstride, j);
-        const f32x4 h = Hs[((size_t)(l - 1) * NT + G * F + j) * 64 + lane];
         f32x4 d;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) d[r] = z[r] * (h[r] > 0.0f ? 1.0f : 0.01f);
+        for (int r = 0; r < 4; ++r) d[r] = z[r] * (((sg >> (4 * (F + j) + r)) & 1u) ? 1.0f : 0.01f);
         Ds[(((l - 1) & 1) * NT + G * F + j) * 64 + lane] = d;
         if (rec && wave == 0) rec_store(recD + ((size_t)(l - 1) * NT + G * F + j) * 64, d);
       }
@@ -464,8 +513,7 @@ __global__ void __launch_bounds__(256) ionode_dopri5_backward_kernel(const GArgs
         ? a.records + ((size_t)blockIdx.x * (a.it_end - a.it_begin) + (it - a.it_begin)) * 6 * a.record_floats : nullptr;
 
     // ---- stages 6..1 (k[i+1] = f(t_i, Y_i)), one collective MLP vector-Jacobian product each ----
-#pragma unroll 1
-    for (int e = 0; e < 6; ++e) {
+    auto stage = [&](const int e) {
       const int i = 5 - e;
       double Yi[D], seed[D];
       double tq;
@@ -549,6 +597,13 @@ __global__ void __launch_bounds__(256) ionode_dopri5_backward_kernel(const GArgs
 #pragma unroll
         for (int d = 0; d < D; ++d) lam[d] += w[d];
       }
+    };
+    if constexpr (HAS_MLP) {
+#pragma unroll 1
+      for (int e = 0; e < 6; ++e) stage(e);   // one instance of the MLP collective in the code
+    } else {
+#pragma unroll
+      for (int e = 0; e < 6; ++e) stage(e);   // closed form: unrolled, so that k[jx][d] / ak[jx][d] are register-indexed
     }
     if (step) {
 #pragma unroll

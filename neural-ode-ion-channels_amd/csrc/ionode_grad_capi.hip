@@ -114,8 +114,8 @@ int ionode_dopri5_backward(const ionode_desc *d, int32_t it_begin, int32_t it_en
                : hh2 ? (d->state_f32 ? &launch_sweep<IONODE_MODEL_HH2, float, 1> : &launch_sweep<IONODE_MODEL_HH2, double, 1>)
                      : find_sweep(d->model, d->state_f32 ? 1 : 0, NT);
   const size_t lds = hh2 ? (size_t)16 * 5 * (m6 ? 6 : 2) * 8 : ionode::grad_lds_bytes(L, NT);
-  if (!fn || lds > 160 * 1024) {
-    gerr("backward sweep: (L, N) outside the compiled variants (N pads to 16, 112 or 208 and (L + 3) * N * 64 B must fit 160 KB of LDS)");
+  if (!fn || lds > 160 * 1024 || L > 15) {
+    gerr("backward sweep: (L, N) outside the compiled variants (N pads to 16, 112 or 208; at most 15 hidden layers)");
     return IONODE_ERR_UNSUPPORTED;
   }
   ionode::GArgs a;
@@ -151,7 +151,7 @@ int ionode_regress_step(int32_t L, int32_t N, const float *grad_image, const flo
     gerr("ionode_regress_step: bad argument"); return IONODE_ERR_ARG;
   }
   const int NT = np_of(N) / 16;
-  if (ionode::grad_lds_bytes(L, NT) > 160 * 1024) { gerr("ionode_regress_step: (L, N) does not fit the LDS of one CU"); return IONODE_ERR_UNSUPPORTED; }
+  if (ionode::grad_lds_bytes(L, NT) > 160 * 1024 || L > 15) { gerr("ionode_regress_step: (L, N) outside the compiled variants (at most 15 hidden layers)"); return IONODE_ERR_UNSUPPORTED; }
   ionode::RArgs a;
   memset(&a, 0, sizeof a);
   a.img = grad_image; a.x = x; a.y = y; a.offset = offset; a.records = records; a.loss_part = loss_partials;

@@ -154,10 +154,10 @@ def _rand_weights(L, N, seed):
 
 
 @pytest.mark.parametrize("L,N,model", [(2, 10, K.MODEL_NNF), (10, 10, K.MODEL_NND), (3, 100, K.MODEL_NND), (10, 100, K.MODEL_NNF),
-                                       (1, 200, K.MODEL_NNF)])
+                                       (1, 200, K.MODEL_NNF), (10, 200, K.MODEL_NND), (15, 100, K.MODEL_NNF)])
 def test_other_widths_and_depths_against_the_checker(ion, gpu, oracle, L, N, model):
     """The NT = 1 (N = 10) and NT = 7 (N = 100) instantiations of the sweep / reduce kernels and other depths of the N = 200
-    one (architectures s01, s03-s05, s09-s11), ragged batch (19 trajectories = 2 tiles), explicit protocol time grid, one
+    one (architectures s01, s02, s03-s05, s09-s11; 15 hidden layers is the sweep's limit), ragged batch (19 trajectories = 2 tiles), explicit protocol time grid, one
     trajectory that fails (NaN start: zero gradient) -- the checker (tests/grad_check.py) is evaluated in the test."""
     import grad_check as G
     w = _rand_weights(L, N, 11 * L + N)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Dev tool (GPU box): gradient sweep and regression step with every library under variants/*/
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
-for d in neural-ode-ion-channels_amd/variants/*/; do
+for d in neural-ode-ion-channels_amd/variants/*/ neural-ode-ion-channels_amd/; do
   n=$(basename $d)
   IONODE_LIB=$GRAFT_REPO_ROOT/$d/libionode.so python3 tools/bench_grad.py --batch 1024 --nt 100001 --reps 2 2>/dev/null | python3 -c "
 import sys,json
