@@ -130,7 +130,7 @@ def main():
                         mlp_width=MLP_N, prot_t0=0.0, prot_dt=0.1, current=True, obs_g=1.0, obs_e=-86.0,
                         tile_waves=args.tile_waves, t_eval_hint=(0.0, 0.1), t_eval_exact=True, out=out)
         out.update({k: r[k] for k in ("y", "i", "status", "stats")})
-        part = torch.stack([(r["i"] - i_ref).abs().sum(), torch.tensor(float(B * Nt), dtype=torch.float64, device=dev)])
+        part = torch.stack([torch.nn.functional.l1_loss(r["i"], i_ref, reduction="sum"), torch.tensor(float(B * Nt), dtype=torch.float64, device=dev)])
         part = allreduce(part)  # the path's only collective: 16 bytes
         return r, part[0] / part[1]
 
@@ -150,7 +150,7 @@ def main():
                         mlp_width=MLP_N, prot_t0=0.0, prot_dt=0.1, current=True, obs_g=1.0, obs_e=-86.0,
                         tile_waves=args.tile_waves, t_eval_hint=(0.0, 0.1), t_eval_exact=True, out=out)
         ev[k][1].record()
-        part = torch.stack([(r["i"] - i_ref).abs().sum(), torch.tensor(float(B * Nt), dtype=torch.float64, device=dev)])
+        part = torch.stack([torch.nn.functional.l1_loss(r["i"], i_ref, reduction="sum"), torch.tensor(float(B * Nt), dtype=torch.float64, device=dev)])
         part = allreduce(part)
         loss = part[0] / part[1]
     barrier()
