@@ -119,7 +119,8 @@ def solve(model, params, prot_v, y0, t_eval, *, weights=None, mlp_layers=0, mlp_
     order_t = None
     if order is not None:
         order_t = _to(order, torch.int64, dev)
-        if order_t.shape != (B,):
+        if order_t.shape != (B,) or int(order_t.min()) < 0 or int(order_t.max()) >= B or \
+                not bool(torch.bincount(order_t, minlength=B).eq(1).all()):
             raise capi.IonodeError(f"order must be a permutation of range({B})")
         params_t = params_t.index_select(0, order_t)
         y0_t = y0_t.index_select(0, order_t)

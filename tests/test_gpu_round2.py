@@ -294,6 +294,8 @@ def test_launch_order_changes_the_tiling_never_the_results(ion, gpu, model):
         assert (np.diff(c) <= 0).all()
     with pytest.raises(ion.IonodeError):
         ion.solve(model, params, pv, torch.from_numpy(y0), te, order=np.arange(B - 1), **kw)
+    with pytest.raises(ion.IonodeError):
+        ion.solve(model, params, pv, torch.from_numpy(y0), te, order=np.zeros(B, dtype=np.int64), **kw)     # not a permutation
 
 
 def test_pilot_cost_ranks_the_trajectories(ion, gpu):
