@@ -203,7 +203,8 @@ def solve(model, weights_flat, params, prot_v, y0, t_eval, *, mlp_layers=0, mlp_
     if order is not None:
         order = torch.as_tensor(order, dtype=torch.int64, device=y0.device)
         B = y0.shape[0]
-        if order.shape != (B,):
+        if order.shape != (B,) or int(order.min()) < 0 or int(order.max()) >= B or \
+                not bool(torch.bincount(order, minlength=B).eq(1).all()):
             raise capi.IonodeError(f"order must be a permutation of range({B})")
         params, y0 = params.index_select(0, order), y0.index_select(0, order)
         pot = prot_of_traj if prot_of_traj is not None else (torch.arange(B, device=y0.device) % prot_v.shape[0]).to(torch.int32)
