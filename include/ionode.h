@@ -168,8 +168,10 @@ int32_t ionode_abi_version(void);
  * Gradients through the solve (BASELINE.json configs[4]).  Reference interface: `from torchdiffeq import odeint_adjoint as
  * odeint` (train-s1.py:29-32) -- the reference only switches this import and never differentiates (SURVEY.md finding 3),
  * so what is computed is defined here: the exact reverse-mode derivative of the discretisation the forward launch executed,
- * with its accepted steps (t0, dt) as constants; rejected attempts do not contribute.  NN-f / NN-d with N <= 208, and the HH 2-state model (no grad_image, no records:
- * gradients with respect to p1..p8 and y0 only).
+ * with its accepted steps (t0, dt) as constants; rejected attempts do not contribute.  NN-f / NN-d for the widths of
+ * architectures s00-s11 (N = 10, 100, 200, 500) with at most 15 hidden layers, and the closed-form HH 2-state and 6-state
+ * models (no grad_image, no records: gradients with respect to the rate parameters and y0 only; D = 6 and 12 parameters
+ * for the 6-state model).
  *
  * Flow (all pointers DEVICE unless noted):
  *   1. forward:  ionode_dopri5() with d->ckpt / d->ckpt_cap set; n_accepted[b] = stats[b][0] for status[b] == 0, else 0

@@ -76,7 +76,12 @@ struct GradMlp {
   // (forward layers 0..L-1, transposed layers L-1..0, then the next evaluation's layer 0): a fragment is re-loaded right behind
   // the MFMAs that read it, so an L2 round trip (~1 us under load, ~5 k-tiles of MFMA time) is covered.  Without the ring every
   // k-tile waited for its own loads: 18 us per product instead of the 6.7k-cycle MFMA floor (measured).
-  f32x4 ringF[NT][FP];
+  // N = 500 (NT = 32: 8 full row tiles per wavefront, no remainder) cannot hold a whole product's fragments (1024 registers):
+  // there the ring is PD = 4 k-tiles deep and is refilled from the SAME product until its last PD steps (the forward
+  // kernel's blocked ring for s06-s08).
+  static constexpr int PD = (NT <= 13) ? NT : 4;
+  static_assert(R == 0 || PD == NT, "remainder tiles need the full-product ring (static step index)");
+  f32x4 ringF[PD][FP];
   f32x4 ringR[NOWN][RP];
   f32x4 *Hs;          // LDS [2][NT*64]     activations after LeakyReLU, accumulator layout, ping-pong over layers (layer l in
                       //                    buffer l & 1); the backward pass needs only their signs, kept as bits in registers
@@ -111,31 +116,44 @@ struct GradMlp {
   }
   __device__ __forceinline__ int ktile(int s) const { return (s + wave) % NT; }  // wave-uniform (scalar ALU)
   __device__ __forceinline__ int own_kt(int u) const { const int k = wave + G * u; return k < NT ? k : NT - 1; }  // clamped: never read past the layer
-  // LeakyReLU'(h) per layer as bits: 4 per owned full tile, then 4 per remainder tile; 16 bits per layer, layers 0..15
+  // LeakyReLU'(h) per layer as bits
   static constexpr int MAXL = 15;
   static __device__ __forceinline__ unsigned bits_of(const f32x4 &h) {
     return (h[0] > 0.0f ? 1u : 0u) | (h[1] > 0.0f ? 2u : 0u) | (h[2] > 0.0f ? 4u : 0u) | (h[3] > 0.0f ? 8u : 0u);
   }
-  struct Signs {  // four 64-bit words, 16 bits per layer; scalar members (no indexed array: that would live in scratch)
-    unsigned long long w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-    __device__ __forceinline__ void put(int l, unsigned b16) {
-      const int sh = (l & 3) * 16;
-      const unsigned long long m = ~(0xffffull << sh), v = (unsigned long long)b16 << sh;
-      const int k = l >> 2;
+  // BITS per layer: 4 per owned full tile, then 4 per remainder tile (16 for N <= 208, 32 for N = 500); layers 0..15
+  static constexpr int BITS = (4 * (F + R) <= 16) ? 16 : 32;
+  static_assert(4 * (F + R) <= BITS, "sign bits of one layer");
+  struct Signs {  // 64-bit words, 64 / BITS layers each; scalar members (no indexed array: that would live in scratch)
+    static constexpr int PER = 64 / BITS;
+    unsigned long long w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0, w5 = 0, w6 = 0, w7 = 0;
+    __device__ __forceinline__ void put(int l, unsigned bits) {
+      const int sh = (l % PER) * BITS;
+      const unsigned long long full = (BITS == 32) ? 0xffffffffull : 0xffffull;
+      const unsigned long long m = ~(full << sh), v = (unsigned long long)bits << sh;
+      const int k = l / PER;
       w0 = (k == 0) ? ((w0 & m) | v) : w0;
       w1 = (k == 1) ? ((w1 & m) | v) : w1;
       w2 = (k == 2) ? ((w2 & m) | v) : w2;
       w3 = (k == 3) ? ((w3 & m) | v) : w3;
+      if constexpr (PER < 4) {
+        w4 = (k == 4) ? ((w4 & m) | v) : w4;
+        w5 = (k == 5) ? ((w5 & m) | v) : w5;
+        w6 = (k == 6) ? ((w6 & m) | v) : w6;
+        w7 = (k == 7) ? ((w7 & m) | v) : w7;
+      }
     }
     __device__ __forceinline__ unsigned get(int l) const {
-      const int k = l >> 2;
-      const unsigned long long w = (k == 0) ? w0 : ((k == 1) ? w1 : ((k == 2) ? w2 : w3));
-      return (unsigned)(w >> ((l & 3) * 16)) & 0xffffu;
+      const int k = l / PER;
+      unsigned long long w = (k == 0) ? w0 : ((k == 1) ? w1 : ((k == 2) ? w2 : w3));
+      if constexpr (PER < 4) w = (k == 4) ? w4 : ((k == 5) ? w5 : ((k == 6) ? w6 : ((k == 7) ? w7 : w)));
+      const unsigned long long full = (BITS == 32) ? 0xffffffffull : 0xffffull;
+      return (unsigned)((w >> ((l % PER) * BITS)) & full);
     }
   };
   __device__ __forceinline__ void refill_all(unsigned sec, int l) {
 #pragma unroll
-    for (int s = 0; s < NT; ++s)
+    for (int s = 0; s < PD; ++s)
 #pragma unroll
       for (int i = 0; i < F; ++i) ringF[s][i] = frag(sec, l, wave + G * i, ktile(s));
 #pragma unroll
@@ -164,10 +182,11 @@ struct GradMlp {
     __builtin_nontemporal_store(v[2], p + 8); __builtin_nontemporal_store(v[3], p + 12);
   }
 
-  // accF[i] += A(sec, l)[row tile wave + 4i][:] . B[:] over all k-tiles; accR[j] += the owned K-slice of remainder tile j.
+  // accF[i] += A(csec, cl)[row tile wave + 4i][:] . B[:] over all k-tiles; accR[j] += the owned K-slice of remainder tile j.
   // B is read from LDS in accumulator layout.  (nsec, nl): the product that follows -- its fragments replace this one's
-  // right behind the MFMAs that read them.
-  __device__ __forceinline__ void product(unsigned nsec, int nl, const f32x4 *__restrict__ B, f32x4 (&accF)[FP], f32x4 (&accR)[RP]) {
+  // right behind the MFMAs that read them (PD == NT); with the short ring the steps s + PD < NT of THIS product come first.
+  __device__ __forceinline__ void product(unsigned csec, int cl, unsigned nsec, int nl, const f32x4 *__restrict__ B,
+                                          f32x4 (&accF)[FP], f32x4 (&accR)[RP]) {
 #pragma unroll
     for (int s = 0; s < NT; ++s) {
       const int kt = ktile(s);
@@ -176,7 +195,7 @@ struct GradMlp {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int i = 0; i < F; ++i) accF[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ringF[s][i][r], b[r], accF[i], 0, 0, 0);
+        for (int i = 0; i < F; ++i) accF[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ringF[s % PD][i][r], b[r], accF[i], 0, 0, 0);
       if (R > 0 && s % G == 0) {
         if (s + G - 1 < NT || s + wave < NT) {  // static for every step but the last owned one (wave-uniform there)
 #pragma unroll
@@ -188,7 +207,10 @@ struct GradMlp {
         for (int j = 0; j < R; ++j) ringR[s / G][j] = frag(nsec, nl, G * F + j, own_kt(s / G));
       }
 #pragma unroll
-      for (int i = 0; i < F; ++i) ringF[s][i] = frag(nsec, nl, wave + G * i, kt);
+      for (int i = 0; i < F; ++i) {
+        if constexpr (PD == NT) ringF[s][i] = frag(nsec, nl, wave + G * i, kt);
+        else ringF[s % PD][i] = (s + PD < NT) ? frag(csec, cl, wave + G * i, ktile(s + PD)) : frag(nsec, nl, wave + G * i, ktile(s + PD - NT));
+      }
       __builtin_amdgcn_sched_barrier(0);  // keep the refills here (hipcc otherwise sinks them behind the product)
     }
   }
@@ -265,7 +287,7 @@ struct GradMlp {
         const f32x4 bz = *reinterpret_cast<const f32x4 *>(biasS + (l - 1) * NP + 16 * (G * F + j) + 4 * q);
         accR[j] = (wave == 0) ? bz : f32x4{0, 0, 0, 0};  // partial sum 0 carries the bias
       }
-      product(l < L ? fwd0 : bwd0, l < L ? l : L - 1, Hs + (size_t)((l - 1) & 1) * NT * 64, accF, accR);
+      product(fwd0, l - 1, l < L ? fwd0 : bwd0, l < L ? l : L - 1, Hs + (size_t)((l - 1) & 1) * NT * 64, accF, accR);
       f32x4 *__restrict__ Hl = Hs + (size_t)(l & 1) * NT * 64;
       unsigned b16 = 0u;
 #pragma unroll
@@ -331,7 +353,7 @@ struct GradMlp {
       for (int i = 0; i < F; ++i) accF[i] = f32x4{0, 0, 0, 0};
 #pragma unroll
       for (int j = 0; j < R; ++j) accR[j] = f32x4{0, 0, 0, 0};
-      product(l > 1 ? bwd0 : fwd0, l > 1 ? l - 2 : 0, Ds + (size_t)(l & 1) * NT * 64, accF, accR);
+      product(bwd0, l - 1, l > 1 ? bwd0 : fwd0, l > 1 ? l - 2 : 0, Ds + (size_t)(l & 1) * NT * 64, accF, accR);
       const unsigned sg = mk.get(l - 1);  // signs of h_{l-1}: this wavefront's full tiles, then the remainder tiles
 #pragma unroll
       for (int i = 0; i < F; ++i) {

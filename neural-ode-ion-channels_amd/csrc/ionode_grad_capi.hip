@@ -29,12 +29,13 @@ template <int NT> SweepFn pick_sweep(int model, int f32) {
   return f32 ? &launch_sweep<IONODE_MODEL_NND, float, NT> : &launch_sweep<IONODE_MODEL_NND, double, NT>;
 }
 
-// the widths of architectures/s00-s11.py whose activations fit the LDS of one CU: N = 10, 100, 200
+// the widths of architectures/s00-s11.py: N = 10, 100, 200, 500
 SweepFn find_sweep(int model, int f32, int NT) {
   switch (NT) {
     case 1: return pick_sweep<1>(model, f32);
     case 7: return pick_sweep<7>(model, f32);
     case 13: return pick_sweep<13>(model, f32);
+    case 32: return pick_sweep<32>(model, f32);
     default: return nullptr;
   }
 }
@@ -115,7 +116,7 @@ int ionode_dopri5_backward(const ionode_desc *d, int32_t it_begin, int32_t it_en
                      : find_sweep(d->model, d->state_f32 ? 1 : 0, NT);
   const size_t lds = hh2 ? (size_t)16 * 5 * (m6 ? 6 : 2) * 8 : ionode::grad_lds_bytes(L, NT);
   if (!fn || lds > 160 * 1024 || L > 15) {
-    gerr("backward sweep: (L, N) outside the compiled variants (N pads to 16, 112 or 208; at most 15 hidden layers)");
+    gerr("backward sweep: (L, N) outside the compiled variants (N pads to 16, 112, 208 or 512; at most 15 hidden layers)");
     return IONODE_ERR_UNSUPPORTED;
   }
   ionode::GArgs a;
@@ -161,7 +162,8 @@ int ionode_regress_step(int32_t L, int32_t N, const float *grad_image, const flo
     case 1: ionode::launch_regress<1>(a, (unsigned)n_workgroups, s); break;
     case 7: ionode::launch_regress<7>(a, (unsigned)n_workgroups, s); break;
     case 13: ionode::launch_regress<13>(a, (unsigned)n_workgroups, s); break;
-    default: gerr("ionode_regress_step: width outside the compiled variants (N pads to 16, 112 or 208)"); return IONODE_ERR_UNSUPPORTED;
+    case 32: ionode::launch_regress<32>(a, (unsigned)n_workgroups, s); break;
+    default: gerr("ionode_regress_step: width outside the compiled variants (N pads to 16, 112, 208 or 512)"); return IONODE_ERR_UNSUPPORTED;
   }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { gerr(hipGetErrorString(e)); return IONODE_ERR_LAUNCH; }

@@ -30,14 +30,23 @@ __global__ void __launch_bounds__(256) ionode_grad_reduce_kernel(const float *__
   constexpr int F = NT / 4;        // full row tiles per wavefront (rt = wave + 4i, every column tile)
   constexpr int R = NT - 4 * F;    // remainder row tiles, their column tiles dealt round-robin over the wavefronts
   constexpr int RC = (NT + 3) / 4;
-  constexpr int STG = (2 * NT * 64 + 255) / 256;  // float4 loads per thread per record (d tiles + h tiles)
+  // column block of a heavy job: the whole NP x NP accumulator for N <= 208; N = 500 (NT = 32: 1024 registers per wavefront)
+  // is cut into NCB = 4 jobs of CB = 8 column tiles each (256 registers), which stage the D_l tiles and their own H_{l-1} tiles
+  constexpr int CB = (NT <= 13) ? NT : 8;
+  constexpr int NCB = NT / CB;
+  static_assert(NT % CB == 0 && (NT - 4 * (NT / 4) == 0 || NCB == 1), "column blocks: whole tiles, no remainder row tiles");
+  constexpr int STE = (NT + CB) * 64;             // float4 elements staged per record: D_l tiles + this block's H_{l-1} tiles
+  constexpr int STG = (STE + 255) / 256;          // float4 loads per thread per record
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  f32x4 *buf = reinterpret_cast<f32x4 *>(smem);  // [2][2*NT*64]
+  f32x4 *buf = reinterpret_cast<f32x4 *>(smem);  // [2][STE]
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int job = blockIdx.x % (L + 2);
-  const int slab = blockIdx.x / (L + 2);
+  const int NJOB = L * NCB + 2;                   // job 0 | heavy jobs (layer, column block) | job NJOB - 1
+  const int jobx = blockIdx.x % NJOB;
+  const int slab = blockIdx.x / NJOB;
+  const int job = (jobx == 0) ? 0 : ((jobx == NJOB - 1) ? L + 1 : 1 + (jobx - 1) / NCB);   // 0 | layer 1..L | L + 1
+  const int cb0 = (jobx == 0 || jobx == NJOB - 1) ? 0 : ((jobx - 1) % NCB) * CB;           // first column tile of the block
   const int64_t r0 = n_records * slab / n_slabs, r1 = n_records * (slab + 1) / n_slabs;
   const int64_t RECF = grad_record_floats(L, NT);
   float *__restrict__ out = partials + (size_t)slab * grad_partial_floats(L, NT);
@@ -104,12 +113,12 @@ __global__ void __launch_bounds__(256) ionode_grad_reduce_kernel(const float *__
 
   // ---- heavy job l: dW_l += D_l . H_{l-1}^T over this slab's records ----
   const int l = job;
-  f32x4 acc[F > 0 ? F : 1][NT], accr[R > 0 ? R : 1][RC], dba[F > 0 ? F : 1], dbr[R > 0 ? R : 1];
+  f32x4 acc[F > 0 ? F : 1][CB], accr[R > 0 ? R : 1][RC], dba[F > 0 ? F : 1], dbr[R > 0 ? R : 1];
 #pragma unroll
   for (int i = 0; i < F; ++i) {
     dba[i] = f32x4{0, 0, 0, 0};
 #pragma unroll
-    for (int ct = 0; ct < NT; ++ct) acc[i][ct] = f32x4{0, 0, 0, 0};
+    for (int ct = 0; ct < CB; ++ct) acc[i][ct] = f32x4{0, 0, 0, 0};
   }
 #pragma unroll
   for (int j = 0; j < R; ++j) {
@@ -120,28 +129,28 @@ __global__ void __launch_bounds__(256) ionode_grad_reduce_kernel(const float *__
   // staging: element e of the record's {D_l tiles, H_{l-1} tiles} (2*NT*64 float4), thread tid takes e = tid + 256*u
   auto src_of = [&](int64_t rr, int e) -> const f32x4 * {
     const f32x4 *base = reinterpret_cast<const f32x4 *>(records + rr * RECF);
-    return (e < NT * 64) ? base + (size_t)((L + 1) + l) * NT * 64 + e              // D_l
-                         : base + (size_t)(l - 1) * NT * 64 + (e - NT * 64);        // H_{l-1}
+    return (e < NT * 64) ? base + (size_t)((L + 1) + l) * NT * 64 + e                          // D_l
+                         : base + ((size_t)(l - 1) * NT + cb0) * 64 + (e - NT * 64);            // H_{l-1}, this block's tiles
   };
   f32x4 stg[STG];
   if (r0 < r1) {
 #pragma unroll
     for (int u = 0; u < STG; ++u) {
       const int e = threadIdx.x + 256 * u;
-      if (e < 2 * NT * 64) buf[e] = *src_of(r0, e);
+      if (e < STE) buf[e] = *src_of(r0, e);
     }
   }
   __syncthreads();
   for (int64_t rr = r0; rr < r1; ++rr) {
     const int cur = (int)((rr - r0) & 1);
-    const f32x4 *__restrict__ Db = buf + (size_t)cur * 2 * NT * 64;
+    const f32x4 *__restrict__ Db = buf + (size_t)cur * STE;
     const f32x4 *__restrict__ Hb = Db + NT * 64;
     const bool more = rr + 1 < r1;
     if (more) {
 #pragma unroll
       for (int u = 0; u < STG; ++u) {
         const int e = threadIdx.x + 256 * u;
-        if (e < 2 * NT * 64) stg[u] = *src_of(rr + 1, e);
+        if (e < STE) stg[u] = *src_of(rr + 1, e);
       }
     }
     f32x4 af[F > 0 ? F : 1], ar[R > 0 ? R : 1];
@@ -150,7 +159,7 @@ __global__ void __launch_bounds__(256) ionode_grad_reduce_kernel(const float *__
 #pragma unroll
     for (int j = 0; j < R; ++j) { ar[j] = Db[(4 * F + j) * 64 + lane]; dbr[j] += ar[j]; }
 #pragma unroll
-    for (int ct = 0; ct < NT; ++ct) {
+    for (int ct = 0; ct < CB; ++ct) {
       const f32x4 b = Hb[ct * 64 + lane];
       // trajectory group c outer, row tile inner: consecutive MFMAs on different accumulators (issue 32 cycles, result 40)
 #pragma unroll
@@ -165,11 +174,11 @@ __global__ void __launch_bounds__(256) ionode_grad_reduce_kernel(const float *__
       }
     }
     if (more) {
-      f32x4 *nb = buf + (size_t)(cur ^ 1) * 2 * NT * 64;
+      f32x4 *nb = buf + (size_t)(cur ^ 1) * STE;
 #pragma unroll
       for (int u = 0; u < STG; ++u) {
         const int e = threadIdx.x + 256 * u;
-        if (e < 2 * NT * 64) nb[e] = stg[u];
+        if (e < STE) nb[e] = stg[u];
       }
     }
     __syncthreads();
@@ -181,12 +190,12 @@ __global__ void __launch_bounds__(256) ionode_grad_reduce_kernel(const float *__
   for (int i = 0; i < F; ++i) {
     const int rt = wave + 4 * i;
 #pragma unroll
-    for (int ct = 0; ct < NT; ++ct)
+    for (int ct = 0; ct < CB; ++ct)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) W[(size_t)(16 * rt + 4 * kk + r) * NP + 16 * ct + m] = acc[i][ct][r];
+      for (int r = 0; r < 4; ++r) W[(size_t)(16 * rt + 4 * kk + r) * NP + 16 * (cb0 + ct) + m] = acc[i][ct][r];
     float s = (dba[i][0] + dba[i][1]) + (dba[i][2] + dba[i][3]);
     s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
-    if (lane < 16) bvec[16 * rt + m] = s;
+    if (lane < 16 && cb0 == 0) bvec[16 * rt + m] = s;   // the bias gradient once per layer (column block 0)
   }
 #pragma unroll
   for (int j = 0; j < R; ++j) {
@@ -207,12 +216,19 @@ __global__ void __launch_bounds__(256) ionode_grad_reduce_kernel(const float *__
 
 inline hipError_t launch_grad_reduce(int L, int NT, const float *records, int64_t n_records, int n_slabs, float *partials,
                                      hipStream_t s) {
-  const unsigned grid = (unsigned)(n_slabs * (L + 2));
-  const size_t lds = (size_t)2 * 2 * NT * 64 * 16;
+  const int CB = (NT <= 13) ? NT : 8, NCB = NT / CB;
+  const unsigned grid = (unsigned)(n_slabs * (L * NCB + 2));
+  const size_t lds = (size_t)2 * (NT + CB) * 64 * 16;
   switch (NT) {
     case 1: hipLaunchKernelGGL(ionode_grad_reduce_kernel<1>, dim3(grid), dim3(256), lds, s, records, n_records, n_slabs, L, partials); break;
     case 7: hipLaunchKernelGGL(ionode_grad_reduce_kernel<7>, dim3(grid), dim3(256), lds, s, records, n_records, n_slabs, L, partials); break;
     case 13: hipLaunchKernelGGL(ionode_grad_reduce_kernel<13>, dim3(grid), dim3(256), lds, s, records, n_records, n_slabs, L, partials); break;
+    case 32: {
+      auto kern = ionode_grad_reduce_kernel<32>;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, records, n_records, n_slabs, L, partials);
+      break;
+    }
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -11,9 +11,9 @@ RHS modules (rhs.py) are integrated by the fused HIP kernel.  `func` is read at 
 Gradients.  Called with autograd enabled and a `func.net` parameter, a tensor-valued rate parameter or `y0` requiring
 grad, the result carries a graph: the backward sweep of grad.py (exact derivative of the executed discretisation, accepted
 steps as constants).  `odeint_adjoint` is the same function -- the reference's --adjoint flag only switches the import
-(train-s1.py:29-32) and never differentiates, so there is no separate adjoint behaviour to mirror.  Cases without a
-backward kernel (closed-form RHS modules, N = 500 nets) raise NotImplementedError instead of silently returning a
-graph-less tensor; wrap such calls in torch.no_grad() as the reference does.
+(train-s1.py:29-32) and never differentiates, so there is no separate adjoint behaviour to mirror.  All RHS families of the reference are covered (NN-f / NN-d for the widths of architectures
+s00-s11 with at most 15 hidden layers; HH 2-state and 6-state in closed form); other shapes raise instead of silently returning a
+graph-less tensor.
 
 Failures raise AssertionError with torchdiffeq's messages ('underflow in dt', 'non-finite values in state `y`',
 'max_num_steps exceeded').  There is no CPU fallback for recognised modules: without a HIP device the call raises.

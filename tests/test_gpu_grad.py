@@ -154,10 +154,11 @@ def _rand_weights(L, N, seed):
 
 
 @pytest.mark.parametrize("L,N,model", [(2, 10, K.MODEL_NNF), (10, 10, K.MODEL_NND), (3, 100, K.MODEL_NND), (10, 100, K.MODEL_NNF),
-                                       (1, 200, K.MODEL_NNF), (10, 200, K.MODEL_NND), (15, 100, K.MODEL_NNF)])
+                                       (1, 200, K.MODEL_NNF), (10, 200, K.MODEL_NND), (15, 100, K.MODEL_NNF), (1, 500, K.MODEL_NNF), (5, 500, K.MODEL_NND)])
 def test_other_widths_and_depths_against_the_checker(ion, gpu, oracle, L, N, model):
     """The NT = 1 (N = 10) and NT = 7 (N = 100) instantiations of the sweep / reduce kernels and other depths of the N = 200
-    one (architectures s01, s02, s03-s05, s09-s11; 15 hidden layers is the sweep's limit), ragged batch (19 trajectories = 2 tiles), explicit protocol time grid, one
+    one, and the N = 500 one with its short weight ring and the column-blocked reduce (architectures s01-s11; 15 hidden layers
+    is the sweep's limit), ragged batch (19 trajectories = 2 tiles), explicit protocol time grid, one
     trajectory that fails (NaN start: zero gradient) -- the checker (tests/grad_check.py) is evaluated in the test."""
     import grad_check as G
     w = _rand_weights(L, N, 11 * L + N)
@@ -201,13 +202,14 @@ def test_other_widths_and_depths_against_the_checker(ion, gpu, oracle, L, N, mod
 
 
 def test_gradient_of_unsupported_shapes_is_refused(ion, gpu):
-    w = torch.from_numpy(_rand_weights(5, 500, 1)).to(gpu).requires_grad_(True)   # s06: activations exceed one CU's LDS
     pv = torch.zeros((1, 100), dtype=torch.float64, device=gpu) - 80.0
-    with pytest.raises(ion.IonodeError, match="LDS|variants"):
-        y, _ = ion.grad.solve(K.MODEL_NNF, w, torch.from_numpy(K.P_HH[None]).to(gpu), pv,
-                              torch.tensor([[0.0, 1.0]], dtype=torch.float64, device=gpu),
-                              torch.arange(10, dtype=torch.float64, device=gpu), mlp_layers=5, mlp_width=500)
-        y.sum().backward()
+    for L, N in ((2, 300), (16, 100)):    # a width outside architectures s00-s11; more than 15 hidden layers
+        w = torch.from_numpy(_rand_weights(L, N, 1)).to(gpu).requires_grad_(True)
+        with pytest.raises(ion.IonodeError, match="variants|width"):
+            y, _ = ion.grad.solve(K.MODEL_NNF, w, torch.from_numpy(K.P_HH[None]).to(gpu), pv,
+                                  torch.tensor([[0.0, 1.0]], dtype=torch.float64, device=gpu),
+                                  torch.arange(10, dtype=torch.float64, device=gpu), mlp_layers=L, mlp_width=N)
+            y.sum().backward()
 
 
 def test_config5_share_at_full_size_gradient_is_additive(ion, gpu):

@@ -180,7 +180,7 @@ def test_resume_from_a_reference_style_checkpoint(ion, gpu, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("L,N", [(5, 10), (1, 100), (10, 100), (1, 200), (10, 200)])
+@pytest.mark.parametrize("L,N", [(5, 10), (1, 100), (10, 100), (1, 200), (10, 200), (1, 500), (5, 500), (10, 500)])
 def test_other_architectures_against_torch(ion, gpu, L, N):
     """The N = 10 (NT = 1) and N = 100 (NT = 7) instantiations of the regression / reduce kernels and other depths, rows not
     a multiple of 16, with and without the closed-form offset: loss + gradient + 5 Adam steps against torch."""
