@@ -124,6 +124,33 @@ __device__ __forceinline__ double det_exp(double x) {
 }
 __device__ __forceinline__ float det_expf(float x) { return (float)det_exp((double)x); }
 
+// The same function for the closed-form kernels' stage loop, where exp is a third of the issue work: the two power-of-two
+// multiplications (p * 2^k1) * 2^(k - k1) are one v_ldexp_f64.  Bit-identical: p * 2^k is exact while the result is normal,
+// and where it is subnormal or overflows both forms round exactly once (the first factor of the product form is always exact).
+__device__ __forceinline__ double det_exp_ldexp(double x) {
+  if (x != x) return x;
+  if (x > 709.782712893384) return __builtin_inf();
+  if (x < -745.1332191019412) return 0.0;
+  const double kf = rint(x * 0x1.71547652b82fep+0);
+  double r = fma(-kf, 0x1.62e42fee00000p-1, x);
+  r = fma(-kf, 0x1.a39ef35793c76p-33, r);
+  double p = 1.0 / 6227020800.0;
+  p = fma(p, r, 1.0 / 479001600.0);
+  p = fma(p, r, 1.0 / 39916800.0);
+  p = fma(p, r, 1.0 / 3628800.0);
+  p = fma(p, r, 1.0 / 362880.0);
+  p = fma(p, r, 1.0 / 40320.0);
+  p = fma(p, r, 1.0 / 5040.0);
+  p = fma(p, r, 1.0 / 720.0);
+  p = fma(p, r, 1.0 / 120.0);
+  p = fma(p, r, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return __builtin_ldexp(p, (int)kf);
+}
+
 // a / b when rb = RN(1 / b) is at hand: q0 = RN(a * rb) is a faithful quotient, and one correction step with the exact
 // remainder r = a - b*q0 (fma) gives RN(a / b) -- the correctly rounded IEEE quotient, bit for bit what `a / b` returns
 // (Markstein 1990; holds barring over/underflow: operands here are times in ms, voltages in mV and O(1) ratios).  Three
@@ -731,7 +758,7 @@ __device__ __forceinline__ void closed_rates(const KArgs &a, const double *p, do
     for (int i = 0; i < NR; ++i) R.kf[i] = (float)p[2 * i] * det_expf((float)((i & 1) ? -p[2 * i + 1] : p[2 * i + 1]) * vf);
   } else {
 #pragma unroll
-    for (int i = 0; i < NR; ++i) R.k[i] = p[2 * i] * det_exp(((i & 1) ? -p[2 * i + 1] : p[2 * i + 1]) * v);
+    for (int i = 0; i < NR; ++i) R.k[i] = p[2 * i] * det_exp_ldexp(((i & 1) ? -p[2 * i + 1] : p[2 * i + 1]) * v);
   }
 }
 template <int MODEL, typename S>
