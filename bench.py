@@ -414,6 +414,21 @@ def objective_leg(ion, dev, weights):
         res.update({"ms_per_generation_share": total_ms, "candidates_per_s": C / total_ms * 1e3,
                     "solves_per_s": total_solves / total_ms * 1e3, "samples_per_s": total_samples / total_ms * 1e3})
         out[pname] = res
+    # the same objective with the NN-f model (configs[3] reads "NN-f param-fit sweep"): s00 weights shared, p5..p8 per candidate;
+    # compute-bound by the MLP kernel, so a small population on the Pr5 sweeps
+    Cn, pv = 1024, fams["pr5"]
+    S, Np = pv.shape
+    cand = P_HH[4:8] * np.exp(rng.normal(0.0, 0.1, (Cn, 4)))
+    args = dict(base_params=P_HH, free=(4, 5, 6, 7), prot_t0=0.0, prot_dt=0.1, max_total_steps=200000, device=dev,
+                model=ion.capi.MODEL_NNF, weights=weights, mlp_layers=MLP_L, mlp_width=MLP_N, weights_key="bench-s00")
+    te, data = np.arange(Np) * 0.1, np.zeros((S, Np))
+    obj.population_sum_of_squares(cand[:16], pv, data, te, **args)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    sse = obj.population_sum_of_squares(cand, pv, data, te, **args)
+    torch.cuda.synchronize(); ms = (time.perf_counter() - t0) * 1e3
+    out["nnf_s00_candidates_pr5"] = {"candidates": Cn, "sweeps": S, "samples_per_sweep": Np, "solves": Cn * S, "ms": ms,
+                                     "candidates_per_s": Cn / ms * 1e3, "solves_per_s": Cn * S / ms * 1e3,
+                                     "finite": int(torch.isfinite(sse).sum())}
     return out
 
 

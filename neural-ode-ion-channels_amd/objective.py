@@ -16,7 +16,8 @@ from . import batched, capi, distributed
 
 def population_sum_of_squares(candidates, protocols_v, data_i, t_eval, *, base_params, free=(0, 1, 2, 3), prot_t0=0.0,
                               prot_dt=0.1, y0=(0.0, 1.0), state_dtype=torch.float32, obs_g=1.0, obs_e=-86.0,
-                              max_total_steps=1_000_000, group=None, device=None, solver=None, fused=True, cost=None):
+                              max_total_steps=1_000_000, group=None, device=None, solver=None, fused=True, cost=None,
+                              model=capi.MODEL_HH2, weights=None, mlp_layers=0, mlp_width=0, weights_key=None):
     """Sum-of-squares error of every candidate over all protocols (PINTS SumOfSquaresError on a multi-output problem).
 
     candidates  [C, len(free)]  values of the free rate parameters (train-d0.py: p1..p4 -> free = (0, 1, 2, 3))
@@ -26,6 +27,8 @@ def population_sum_of_squares(candidates, protocols_v, data_i, t_eval, *, base_p
     fused (default): the squared residuals are accumulated inside the kernel (ionode_desc.sse_ref / sse_out) and neither states
     nor current traces are written -- the only way BASELINE configs[3] fits (65 536 candidates x 32 sweeps x 1e5 samples would be
     4.5 TB of traces); fused=False stores the traces and reduces them with torch (same values to ~1e-13, for tests).
+    model / weights / mlp_layers / mlp_width: the candidate model -- HH 2-state by default (train-d0.py), or NN-f / NN-d with one
+    shared set of MLP weights and per-candidate rate parameters (free = (4, 5, 6, 7) for NN-f's p5..p8).
     cost (optional, [C]): predicted cost per candidate (e.g. the previous generation's step counts): the candidates are then
     cut into contiguous shards of equal cost rather than equal count (distributed.shard_bounds_by_cost).
     `solver` (tests only): a stand-in with batched.solve's signature, so the sharding / all-gather logic can run under
@@ -41,6 +44,7 @@ def population_sum_of_squares(candidates, protocols_v, data_i, t_eval, *, base_p
     lo, hi = bounds[rank]
     dev = batched._dev(device) if solver is None else torch.device(device or "cpu")
     solve = batched.solve if solver is None else solver
+    mlp = {} if weights is None else dict(weights=weights, mlp_layers=mlp_layers, mlp_width=mlp_width, weights_key=weights_key)
     sse = torch.full((hi - lo,), float("inf"), dtype=torch.float64, device=dev)
     if hi > lo:
         params = np.tile(np.asarray(base_params, dtype=np.float64), (hi - lo, 1))
@@ -49,14 +53,14 @@ def population_sum_of_squares(candidates, protocols_v, data_i, t_eval, *, base_p
         pot = np.tile(np.arange(P, dtype=np.int32), hi - lo)
         ref = torch.as_tensor(np.asarray(data_i), dtype=torch.float64, device=dev)     # [P, Nt]
         if fused and solver is None:
-            sol = solve(capi.MODEL_HH2, params, protocols_v, torch.tensor([list(y0)], dtype=state_dtype), t_eval,
+            sol = solve(model, params, protocols_v, torch.tensor([list(y0)], dtype=state_dtype), t_eval,
                         prot_t0=prot_t0, prot_dt=prot_dt, prot_of_traj=pot, obs_g=obs_g, obs_e=obs_e,
-                        max_total_steps=max_total_steps, device=dev, sse_ref=ref.contiguous(), states=False)
+                        max_total_steps=max_total_steps, device=dev, sse_ref=ref.contiguous(), states=False, **mlp)
             err = sol.sse.reshape(hi - lo, P).sum(dim=1)      # failed solves are inf already
         else:
-            sol = solve(capi.MODEL_HH2, params, protocols_v, torch.tensor([list(y0)], dtype=state_dtype), t_eval,
+            sol = solve(model, params, protocols_v, torch.tensor([list(y0)], dtype=state_dtype), t_eval,
                         prot_t0=prot_t0, prot_dt=prot_dt, prot_of_traj=pot, current=True, obs_g=obs_g, obs_e=obs_e,
-                        max_total_steps=max_total_steps, device=dev)
+                        max_total_steps=max_total_steps, device=dev, **mlp)
             err = ((sol.i.reshape(hi - lo, P, -1) - ref[None]) ** 2).sum(dim=(1, 2))
         ok = (sol.status.reshape(hi - lo, P) == 0).all(dim=1)
         sse = torch.where(ok, err, torch.full_like(err, float("inf")))
