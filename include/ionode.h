@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define IONODE_ABI_VERSION 4
+#define IONODE_ABI_VERSION 5
 
 /* RHS families (func.forward variants of the reference) */
 #define IONODE_MODEL_HH2 0     /* 2-state Hodgkin-Huxley: Lambda, train-s1.py:134-177; candidate ODEFunc train-d0.py:321-374 */
@@ -110,6 +110,11 @@ typedef struct ionode_desc {
                           voltage at the output times, filled by ionode_protocol_at_outputs() for the same protocols and t_eval.
                           The current / objective epilogue then loads V(t_k) instead of re-deriving it per trajectory per sample
                           (same values: the pre-pass runs the integrator's own lookup).  Pays when n_prot << n_traj. */
+  int64_t mlp_image_stride; /* NN models, several weight sets in one launch (an ensemble of trained nets, a population of random
+                          initialisations): floats between consecutive packed images in `mlp_packed` (>= ionode_mlp_packed_floats) ... */
+  int32_t traj_per_image;   /* ... and the number of CONSECUTIVE trajectories that share one image: trajectory b uses image
+                          b / traj_per_image.  A multiple of 16 (of 64 with tile_waves = 64).  0 = one image for every trajectory.
+                          Forward path only (the backward sweep differentiates one weight set). */
 } ionode_desc;
 
 #define IONODE_DEFAULT_MAX_TOTAL_STEPS 1000000

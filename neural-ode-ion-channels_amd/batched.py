@@ -48,7 +48,11 @@ def packed_weights(weights, mlp_layers, mlp_width, dev, key=None):
         return _packed_cache[ck]
     if isinstance(weights, torch.Tensor):
         weights = weights.detach().cpu().numpy()
-    img = torch.from_numpy(capi.mlp_pack(weights, mlp_layers, mlp_width)).to(dev)
+    weights = np.asarray(weights)
+    if weights.ndim == 2:   # several weight sets (solve(traj_per_image=...)): one packed image per row
+        img = torch.from_numpy(np.stack([capi.mlp_pack(w, mlp_layers, mlp_width) for w in weights])).to(dev).contiguous()
+    else:
+        img = torch.from_numpy(capi.mlp_pack(weights, mlp_layers, mlp_width)).to(dev)
     if ck is not None:
         if len(_packed_cache) > 16:
             _packed_cache.clear()
@@ -87,7 +91,7 @@ def solve(model, params, prot_v, y0, t_eval, *, weights=None, mlp_layers=0, mlp_
           prot_t=None, prot_t0=0.0, prot_dt=1.0, prot_of_traj=None, state_dtype=None, rtol=1e-7, atol=1e-9,
           v_oob=-80.0, max_steps=0, max_total_steps=0, max_step=0.0, current=False, obs_g=1.0, obs_e=-86.0, obs_open_state_only=False,
           tile_waves=0, device=None, step_log=None, t_eval_hint="auto", prot_key=None, t_eval_key=None, sse_ref=None,
-          states=True, order=None) -> Solution:
+          states=True, order=None, traj_per_image=0) -> Solution:
     """Integrate B trajectories on the GPU (asynchronous on the current stream).
 
     params [B, 8|12] (or [8|12] -> B = 1), prot_v [P, Np] (or [Np]), y0 [B, D] / [D] (broadcast over B),
@@ -97,6 +101,8 @@ def solve(model, params, prot_v, y0, t_eval, *, weights=None, mlp_layers=0, mlp_
     consecutive entries share an MFMA tile and earlier tiles start first.  Every field of the Solution is then in LAUNCH
     order (un-permuting [B, Nt, D] traces would cost a second pass over them; Solution.to_original() does it on request).
     Each trajectory's values do not depend on its tile-mates, so the ordering changes the time, never the results.
+    traj_per_image: with `weights` [n_sets, n] (an ensemble of trained nets, a population of initialisations): trajectory b is
+    integrated with weight set b // traj_per_image (a multiple of 16); not combined with `order`.
     """
     dev = _dev(device)
     t_eval_exact = None
@@ -141,7 +147,9 @@ def solve(model, params, prot_v, y0, t_eval, *, weights=None, mlp_layers=0, mlp_
         if weights is None:
             raise capi.IonodeError("NN models need `weights` (flat fp32 state dict)")
         packed = packed_weights(weights, mlp_layers, mlp_width, dev, key=weights_key)
-    r = capi.dopri5(model, params_t, prot_v_t, y0_t, t_eval_t, mlp_packed=packed, mlp_layers=mlp_layers,
+    if traj_per_image and order is not None:
+        raise capi.IonodeError("traj_per_image ties trajectories to weight sets by position: it cannot be combined with order")
+    r = capi.dopri5(model, params_t, prot_v_t, y0_t, t_eval_t, mlp_packed=packed, traj_per_image=traj_per_image, mlp_layers=mlp_layers,
                     mlp_width=mlp_width, prot_t=_to(prot_t, torch.float64, dev, key=None if prot_key is None else (prot_key, "t")),
                     prot_t0=prot_t0, prot_dt=prot_dt,
                     prot_of_traj=pot_t, rtol=rtol, atol=atol, v_oob=v_oob,

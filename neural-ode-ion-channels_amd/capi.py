@@ -21,7 +21,7 @@ STATUS_TEXT = {
     2: "non-finite values in state `y`",
     3: "max_num_steps exceeded",
 }
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 EXPORTS = (
     "ionode_abi_version", "ionode_last_error", "ionode_mlp_packed_floats", "ionode_mlp_pack",
@@ -44,6 +44,7 @@ class IonodeDesc(C.Structure):
         ("t_eval_t0_hint", C.c_double), ("t_eval_dt_hint", C.c_double),
         ("max_total_steps", C.c_int64), ("ckpt", C.c_void_p), ("ckpt_cap", C.c_int32), ("t_eval_exact", C.c_int32),
         ("sse_ref", C.c_void_p), ("sse_out", C.c_void_p), ("max_step", C.c_double), ("v_at_outputs", C.c_void_p),
+        ("mlp_image_stride", C.c_int64), ("traj_per_image", C.c_int32),
     ]
 
 
@@ -164,7 +165,7 @@ def dopri5(model, params, prot_v, y0, t_eval, *, mlp_packed=None, mlp_layers=0, 
            prot_t0=0.0, prot_dt=1.0, prot_of_traj=None, rtol=1e-7, atol=1e-9, v_oob=-80.0, max_steps=0,
            max_total_steps=0, max_step=0.0, ckpt=None, current=False, obs_g=1.0, obs_e=-86.0, obs_open_state_only=False, tile_waves=0, stats=True,
            step_log=None, t_eval_hint="auto", t_eval_exact=None, sse_ref=None, states=True, out=None, stream=None,
-           v_at_outputs="auto"):
+           v_at_outputs="auto", traj_per_image=0):
     """Launch one batched solve.  Every tensor lives on the current HIP device.
 
     params [B, n_params] f64, prot_v [P, Np] f64, y0 [B, D] f32|f64 (selects the state dtype),
@@ -183,6 +184,10 @@ def dopri5(model, params, prot_v, y0, t_eval, *, mlp_packed=None, mlp_layers=0, 
                      prot_n=Np, mlp_layers=mlp_layers, mlp_width=mlp_width, n_params=params.shape[1],
                      max_steps=max_steps, max_total_steps=max_total_steps, max_step=max_step, prot_t0=prot_t0, prot_dt=prot_dt, v_oob=v_oob, rtol=rtol, atol=atol,
                      obs_g=obs_g, obs_e=obs_e, obs_open_state_only=int(obs_open_state_only), tile_waves=tile_waves)
+    if traj_per_image:  # several weight images: mlp_packed [n_images, floats], trajectory b uses image b // traj_per_image
+        if mlp_packed is None or mlp_packed.dim() != 2 or mlp_packed.shape[0] * traj_per_image < B or not mlp_packed.is_contiguous():
+            raise IonodeError("traj_per_image needs a contiguous mlp_packed [n_images, floats] with n_images * traj_per_image >= B")
+        desc.mlp_image_stride, desc.traj_per_image = int(mlp_packed.shape[1]), int(traj_per_image)
     # output-grid hint (t0, dt): a guess the kernel verifies against t_eval; "auto" derives it from the end points
     # (one tiny device->host read), None disables it (cooperative scan)
     if isinstance(t_eval_hint, str) and t_eval_hint == "auto":

@@ -255,6 +255,14 @@ int ionode_dopri5(const ionode_desc *d, const float *mlp_packed, const double *p
   a.obs_g = d->obs_g; a.obs_e = d->obs_e; a.obs_open = d->obs_open_state_only;
   a.step_log = d->step_log; a.step_log_cap = d->step_log ? d->step_log_cap : 0;
   a.sse_ref = d->sse_ref; a.sse_out = d->sse_out; a.v_tab = d->v_at_outputs;
+  if (mlp && d->traj_per_image > 0) {
+    const int tile = (pl.block == 64 && pl.v->RT == 64) ? 64 : 16;
+    if (d->traj_per_image % tile != 0 || d->mlp_image_stride < (int64_t)ionode_mlp_packed_floats(d->mlp_layers, d->mlp_width)) {
+      set_err("traj_per_image must be a multiple of the tile size (16; 64 with tile_waves = 64) and mlp_image_stride at least one packed image");
+      return IONODE_ERR_ARG;
+    }
+    a.mlp_stride = d->mlp_image_stride; a.traj_per_img = d->traj_per_image;
+  }
   a.te_t0 = d->t_eval_t0_hint; a.te_dt = (d->t_eval_dt_hint > 0.0 && d->n_out > 1) ? d->t_eval_dt_hint : 0.0;
   a.te_rdt = a.te_dt > 0.0 ? 1.0 / a.te_dt : 0.0;
   a.te_exact = (a.te_dt > 0.0 && d->t_eval_exact) ? 1 : 0;

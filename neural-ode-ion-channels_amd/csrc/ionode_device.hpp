@@ -67,6 +67,8 @@ struct KArgs {
                         // closed-form kernels then form output times arithmetically -- no vector load sits behind their stores
   const double *v_tab;  // optional [P][Nt]: protocol voltage AT the output times (ionode_protocol_at_outputs); the closed-form
                         // kernels' current / objective epilogue then loads V(t_k) instead of re-deriving it per trajectory
+  int64_t mlp_stride;   // several weight images (an ensemble / a population of nets): floats between consecutive images ...
+  int32_t traj_per_img; // ... and how many consecutive trajectories share one (a multiple of the tile size); 0: one image for all
 };
 
 // Dormand-Prince / Shampine coefficients.
@@ -357,8 +359,10 @@ struct MlpTile {
     return ((size_t)2 * HT * 64 + (size_t)2 * R * G * 64 + NP) * 16 + ((size_t)L * NP + NP + 4) * 4;
   }
 
-  __device__ __forceinline__ void init(const KArgs &a, unsigned char *smem, int wave_, int lane_) {
+  __device__ __forceinline__ void init(const KArgs &a, unsigned char *smem, int wave_, int lane_, int first_traj = 0) {
     L = a.L; wave = wave_; lane = lane_;
+    // the tile's weight image: the shared one, or image number first_traj / traj_per_img of an ensemble
+    const float *__restrict__ img = a.mlp + (a.traj_per_img > 0 ? (size_t)(first_traj / a.traj_per_img) * (size_t)a.mlp_stride : (size_t)0);
     Hs = reinterpret_cast<f32x4 *>(smem);
     Ps = Hs + 2 * HT * 64;
     f32x4 *w0 = Ps + 2 * R * G * 64;
@@ -366,14 +370,14 @@ struct MlpTile {
     float *ws = bs + (size_t)L * NP;
     constexpr size_t lstride = layer_floats();
     const int tid = wave * 64 + lane;
-    const f32x4 *src = reinterpret_cast<const f32x4 *>(a.mlp);
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(img);
     for (int i = tid; i < NP; i += 64 * G) w0[i] = src[i];
-    for (int i = tid; i < L * NP; i += 64 * G) bs[i] = a.mlp[4 * (size_t)NP + (size_t)(i / NP) * lstride + (lstride - NP) + (i % NP)];
-    const float *wl = a.mlp + 4 * (size_t)NP + (size_t)L * lstride;
+    for (int i = tid; i < L * NP; i += 64 * G) bs[i] = img[4 * (size_t)NP + (size_t)(i / NP) * lstride + (lstride - NP) + (i % NP)];
+    const float *wl = img + 4 * (size_t)NP + (size_t)L * lstride;
     for (int i = tid; i < NP + 4; i += 64 * G) ws[i] = wl[i];
     W0s = w0; biasS = bs; wlS = ws;
     const size_t img_bytes = (4 * (size_t)NP + (size_t)L * lstride + NP + 4) * 4;
-    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.mlp), 0, (int)img_bytes, 0x00020000);
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(img), 0, (int)img_bytes, 0x00020000);
     voff = (unsigned)(wave * FRAGS * 1024 + lane * 16);
     hid0 = (unsigned)(4 * NP * 4);
     lbytes = (unsigned)(lstride * 4);
@@ -872,7 +876,7 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
 
   using MlpT = MlpTile<G, (T64 ? 1 : (RT > 0 ? RT : 1)), (NT > 0 ? NT : 1), (PD > 0 ? PD : 1), 0>;
   typename std::conditional<MT::MLP, MlpT, NoMlp>::type mlp;
-  if constexpr (MT::MLP) mlp.init(a, smem, wave, lane);
+  if constexpr (MT::MLP) mlp.init(a, smem, wave, lane, (int)blockIdx.x * TPW);
   // lane-wise kernels: interpolant rows + tail buffers; behind the MlpTile region when there is one
   size_t lw_off = 0;
   if constexpr (T64) lw_off = (MlpT::lds_bytes(a.L) + 15) & ~(size_t)15;

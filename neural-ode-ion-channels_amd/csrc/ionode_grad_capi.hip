@@ -109,6 +109,7 @@ int ionode_dopri5_backward(const ionode_desc *d, int32_t it_begin, int32_t it_en
     gerr("ionode_dopri5_backward: required buffer is NULL (ckpt / ckpt_cap come from the descriptor)"); return IONODE_ERR_ARG;
   }
   if (it_begin < 0 || it_end <= it_begin || it_end > n_iter) { gerr("bad iteration range"); return IONODE_ERR_ARG; }
+  if (d->traj_per_image > 0) { gerr("backward sweep: one weight set per launch (traj_per_image must be 0)"); return IONODE_ERR_UNSUPPORTED; }
   if (!hh2 && (d->mlp_layers < 1 || d->mlp_width < 1)) { gerr("bad MLP shape"); return IONODE_ERR_ARG; }
   const int NP = hh2 ? 16 : np_of(d->mlp_width), NT = NP / 16, L = hh2 ? 0 : d->mlp_layers;
   SweepFn fn = m6 ? (d->state_f32 ? &launch_sweep<IONODE_MODEL_MARKOV6, float, 1> : &launch_sweep<IONODE_MODEL_MARKOV6, double, 1>)

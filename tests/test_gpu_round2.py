@@ -381,3 +381,29 @@ def test_tiny_nets_at_64_trajectories_per_wavefront(ion, gpu, oracle, model, L, 
     assert ion.capi.launch_geometry(d)["grid"] == 2500 and ", 1, 64, 1, 1, " in ion.capi.kernel_name(d)     # chosen by itself
     d.n_traj = 30000
     assert ion.capi.launch_geometry(d)["grid"] == 1875 and ", 1, 1, 1, 1, 0>" in ion.capi.kernel_name(d)
+
+
+@pytest.mark.parametrize("L,N,f32", [(5, 200, False), (2, 100, True), (5, 10, False), (1, 500, True)])
+def test_several_weight_sets_in_one_launch(ion, gpu, oracle, L, N, f32):
+    """ionode_desc.traj_per_image / mlp_image_stride: an ensemble of nets in one launch -- trajectory b uses weight set
+    b // 16 (each 16-trajectory tile streams its own packed image).  Four weight sets x 16 sweeps (the last set's tile ragged),
+    bit for bit against the oracle run once per weight set."""
+    rng = np.random.default_rng(100 * L + N)
+    nset, per = 4, 16
+    B = nset * per - 5
+    ws = np.stack([_rand_weights(L, N, 7 * k + N) for k in range(nset)])
+    pv = np.stack([K.atau(30)[1], K.atau(300)[1], K.activation(20)[1][: K.atau(30)[1].size]])
+    te = K.atau(30)[2][:901]
+    params = np.tile(K.P_HH, (B, 1)) * rng.uniform(0.9, 1.1, (B, 8))
+    pot = rng.integers(0, 3, B).astype(np.int32)
+    kw = dict(prot_t0=0.0, prot_dt=1.0, prot_of_traj=pot, max_total_steps=20000)
+    sol = ion.solve(K.MODEL_NNF, params, pv, torch.tensor([K.NN_Y0], dtype=torch.float32 if f32 else torch.float64), te,
+                    weights=ws, mlp_layers=L, mlp_width=N, traj_per_image=per, current=True, **kw)
+    y = sol.y.double().cpu().numpy()
+    for k in range(nset):
+        lo, hi = k * per, min(B, (k + 1) * per)
+        o = oracle.solve(K.MODEL_NNF, params[lo:hi], pv, K.NN_Y0, te, weights=ws[k], mlp_layers=L, mlp_width=N, state_f32=f32,
+                         **dict(kw, prot_of_traj=pot[lo:hi]))
+        assert np.array_equal(y[lo:hi], o["y"]) and np.array_equal(sol.stats[lo:hi].cpu().numpy(), o["stats"]), k
+    with pytest.raises(ion.IonodeError):
+        ion.solve(K.MODEL_NNF, params, pv, torch.tensor([K.NN_Y0]), te, weights=ws, mlp_layers=L, mlp_width=N, traj_per_image=8, **kw)
