@@ -84,7 +84,10 @@ def _case(seed):
     return model, f32, params, pv, y0, te, kw, mlp, obs, rng
 
 
-@pytest.mark.parametrize("seed", range(56))
+import os
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("IONODE_FUZZ_SEEDS", "56"))))
 def test_random_descriptors_match_the_oracle(ion, gpu, oracle, seed):
     model, f32, params, pv, y0, te, kw, mlp, obs, rng = _case(seed)
     B = params.shape[0]
