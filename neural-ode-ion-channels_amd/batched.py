@@ -97,7 +97,8 @@ def solve(model, params, prot_v, y0, t_eval, *, weights=None, mlp_layers=0, mlp_
     params [B, 8|12] (or [8|12] -> B = 1), prot_v [P, Np] (or [Np]), y0 [B, D] / [D] (broadcast over B),
     t_eval [Nt].  state_dtype: torch.float32 (reference-compatible) or torch.float64; default = y0's dtype if it
     is a floating torch tensor, else float64.
-    order: optional permutation of range(B) (schedule.lpt_order): launch slot k integrates trajectory order[k], so 16
+    order: optional permutation of range(B) (schedule.lpt_order), or 'pilot' (a closed-form pilot solve ranks the trajectories
+    first: schedule.pilot_cost): launch slot k integrates trajectory order[k], so 16
     consecutive entries share an MFMA tile and earlier tiles start first.  Every field of the Solution is then in LAUNCH
     order (un-permuting [B, Nt, D] traces would cost a second pass over them; Solution.to_original() does it on request).
     Each trajectory's values do not depend on its tile-mates, so the ordering changes the time, never the results.
@@ -123,6 +124,15 @@ def solve(model, params, prot_v, y0, t_eval, *, weights=None, mlp_layers=0, mlp_
     y0_t = y0_t.contiguous()
     pot_t = _to(prot_of_traj, torch.int32, dev)
     order_t = None
+    if isinstance(order, str):
+        if order != "pilot":
+            raise capi.IonodeError("order: a permutation, None or 'pilot'")
+        # cost-sorted launch order from a closed-form pilot solve of the same protocols (schedule.pilot_cost)
+        from . import schedule
+        te_h = t_eval.detach().cpu().numpy() if isinstance(t_eval, torch.Tensor) else np.asarray(t_eval)
+        order = schedule.lpt_order(schedule.pilot_cost(params_t[:, :8], prot_v_t, float(te_h[0]), float(te_h[-1]), prot_t0=prot_t0,
+                                                       prot_dt=prot_dt, prot_t=prot_t, prot_of_traj=pot_t, rtol=rtol, atol=atol,
+                                                       v_oob=v_oob, device=dev))
     if order is not None:
         order_t = _to(order, torch.int64, dev)
         if order_t.shape != (B,) or int(order_t.min()) < 0 or int(order_t.max()) >= B or \

@@ -298,6 +298,19 @@ def test_launch_order_changes_the_tiling_never_the_results(ion, gpu, model):
         ion.solve(model, params, pv, torch.from_numpy(y0), te, order=np.zeros(B, dtype=np.int64), **kw)     # not a permutation
 
 
+def test_order_pilot_is_a_convenience_for_the_same_thing(ion, gpu):
+    B, Nt = 80, 6001
+    pv = ion.protocols.sinewave(ion.protocols.sinewave_scales(0, B), n_samples=Nt, dt=0.1, xp=torch, device=gpu)
+    params = np.tile(K.P_HH, (B, 1))
+    te = np.arange(0, Nt, 10) * 0.1
+    kw = dict(weights=K.load_weights("s1"), mlp_layers=5, mlp_width=200, prot_t0=0.0, prot_dt=0.1)
+    y0 = torch.tensor([[0.0, 1.0]], dtype=torch.float64)
+    plain = ion.solve(K.MODEL_NNF, params, pv, y0, te, **kw)
+    auto = ion.solve(K.MODEL_NNF, params, pv, y0, te, order="pilot", **kw)
+    assert auto.order is not None and sorted(auto.order.tolist()) == list(range(B))
+    assert torch.equal(auto.to_original(auto.y), plain.y) and torch.equal(auto.to_original(auto.stats), plain.stats)
+
+
 def test_pilot_cost_ranks_the_trajectories(ion, gpu):
     """schedule.pilot_cost: RHS-evaluation counts of a closed-form HH solve over the same protocols -- positive, and ranked
     like the NN-f model's own counts (rank correlation > 0.8 on sine-wave protocols of different speed)."""
