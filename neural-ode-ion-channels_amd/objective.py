@@ -28,7 +28,8 @@ def population_sum_of_squares(candidates, protocols_v, data_i, t_eval, *, base_p
     nor current traces are written -- the only way BASELINE configs[3] fits (65 536 candidates x 32 sweeps x 1e5 samples would be
     4.5 TB of traces); fused=False stores the traces and reduces them with torch (same values to ~1e-13, for tests).
     model / weights / mlp_layers / mlp_width: the candidate model -- HH 2-state by default (train-d0.py), or NN-f / NN-d with one
-    shared set of MLP weights and per-candidate rate parameters (free = (4, 5, 6, 7) for NN-f's p5..p8).
+    shared set of MLP weights and per-candidate rate parameters (free = (4, 5, 6, 7) for NN-f's p5..p8); weights [C, n]: a
+    population of nets, candidate c integrated with its own weight set (free may then be empty: candidates [C, 0]).
     cost (optional, [C]): predicted cost per candidate (e.g. the previous generation's step counts): the candidates are then
     cut into contiguous shards of equal cost rather than equal count (distributed.shard_bounds_by_cost).
     `solver` (tests only): a stand-in with batched.solve's signature, so the sharding / all-gather logic can run under
@@ -45,24 +46,34 @@ def population_sum_of_squares(candidates, protocols_v, data_i, t_eval, *, base_p
     dev = batched._dev(device) if solver is None else torch.device(device or "cpu")
     solve = batched.solve if solver is None else solver
     mlp = {} if weights is None else dict(weights=weights, mlp_layers=mlp_layers, mlp_width=mlp_width, weights_key=weights_key)
+    # a population of NETS: weights [C, n] -- candidate c has its own MLP weights (and its rate parameters).  Every candidate then
+    # owns whole 16-trajectory tiles (ionode_desc.traj_per_image): its P sweeps are padded to a multiple of 16 with repeats of
+    # sweep 0 whose scores are dropped.
+    per_cand = weights is not None and np.asarray(weights).ndim == 2
+    S = P
+    if per_cand:
+        if np.asarray(weights).shape[0] != C:
+            raise capi.IonodeError("weights [C, n]: one weight set per candidate")
+        S = 16 * ((P + 15) // 16)
+        mlp.update(weights=np.asarray(weights)[lo:hi], traj_per_image=S, weights_key=None)
     sse = torch.full((hi - lo,), float("inf"), dtype=torch.float64, device=dev)
     if hi > lo:
         params = np.tile(np.asarray(base_params, dtype=np.float64), (hi - lo, 1))
         params[:, list(free)] = cand[lo:hi]
-        params = np.repeat(params, P, axis=0)                       # candidate-major: trajectory = c*P + p
-        pot = np.tile(np.arange(P, dtype=np.int32), hi - lo)
+        params = np.repeat(params, S, axis=0)                       # candidate-major: trajectory = c*S + p
+        pot = np.tile(np.where(np.arange(S) < P, np.arange(S), 0).astype(np.int32), hi - lo)
         ref = torch.as_tensor(np.asarray(data_i), dtype=torch.float64, device=dev)     # [P, Nt]
         if fused and solver is None:
             sol = solve(model, params, protocols_v, torch.tensor([list(y0)], dtype=state_dtype), t_eval,
                         prot_t0=prot_t0, prot_dt=prot_dt, prot_of_traj=pot, obs_g=obs_g, obs_e=obs_e,
                         max_total_steps=max_total_steps, device=dev, sse_ref=ref.contiguous(), states=False, **mlp)
-            err = sol.sse.reshape(hi - lo, P).sum(dim=1)      # failed solves are inf already
+            err = sol.sse.reshape(hi - lo, S)[:, :P].sum(dim=1)      # failed solves are inf already
         else:
             sol = solve(model, params, protocols_v, torch.tensor([list(y0)], dtype=state_dtype), t_eval,
                         prot_t0=prot_t0, prot_dt=prot_dt, prot_of_traj=pot, current=True, obs_g=obs_g, obs_e=obs_e,
                         max_total_steps=max_total_steps, device=dev, **mlp)
-            err = ((sol.i.reshape(hi - lo, P, -1) - ref[None]) ** 2).sum(dim=(1, 2))
-        ok = (sol.status.reshape(hi - lo, P) == 0).all(dim=1)
+            err = ((sol.i.reshape(hi - lo, S, -1)[:, :P] - ref[None]) ** 2).sum(dim=(1, 2))
+        ok = (sol.status.reshape(hi - lo, S)[:, :P] == 0).all(dim=1)
         sse = torch.where(ok, err, torch.full_like(err, float("inf")))
     if world == 1:
         return sse

@@ -219,3 +219,34 @@ def test_population_objective_for_nnf_candidates(ion, gpu, oracle):
                         for k in range(3)])
         want = ((sim - data) ** 2).sum()
         assert abs(got[c] - want) <= 1e-12 * want
+
+
+def test_population_objective_over_network_weights(ion, gpu, oracle):
+    """BASELINE configs[3] read literally -- "random-init parameter samples" of the NET: every candidate has its own MLP
+    weights (train-s1.py:202-205 initialisation: N(0, 0.1^2), zero bias), all on the same sweeps; each candidate fills its own
+    16-trajectory tiles (traj_per_image).  Scores against the oracle run once per candidate."""
+    obj = importlib.import_module("neural-ode-ion-channels_amd.objective")
+    pv = np.stack([K.activation(v)[1] for v in (-20, 0, 20, 40, 60)])
+    te = K.activation(0)[2][::4]
+    rng = np.random.default_rng(21)
+    C, L, N = 7, 5, 200
+    n = 2 * N + N + L * (N * N + N) + N + 1
+    ws = np.zeros((C, n), dtype=np.float32)
+    for c in range(C):                       # weights ~ N(0, 0.1^2), biases 0
+        off = 0
+        for (o, i) in [(N, 2)] + [(N, N)] * L + [(1, N)]:
+            ws[c, off:off + o * i] = rng.normal(0, 0.1, o * i)
+            off += o * i + o
+    data = rng.normal(0, 0.1, (5, te.size))
+    kw = dict(base_params=K.P_HH, free=(), prot_t0=0.0, prot_dt=1.0, model=K.MODEL_NNF, weights=ws, mlp_layers=L, mlp_width=N,
+              y0=tuple(K.NN_Y0))
+    got = obj.population_sum_of_squares(np.zeros((C, 0)), pv, data, te, **kw).cpu().numpy()
+    unfused = obj.population_sum_of_squares(np.zeros((C, 0)), pv, data, te, fused=False, **kw).cpu().numpy()
+    assert got.shape == (C,) and np.isfinite(got).all() and np.allclose(got, unfused, rtol=1e-12, atol=0)
+    for c in range(C):
+        o = oracle.solve(K.MODEL_NNF, np.tile(K.P_HH, (5, 1)), pv, K.NN_Y0, te, weights=ws[c], mlp_layers=L, mlp_width=N,
+                         prot_t0=0.0, prot_dt=1.0, prot_of_traj=np.arange(5, dtype=np.int32), state_f32=True)
+        sim = np.stack([oracle.current(o["y"][k], oracle.protocol_v(pv[k], te, prot_t0=0.0, prot_dt=1.0)[0], state_f32=True)
+                        for k in range(5)])
+        want = ((sim - data) ** 2).sum()
+        assert abs(got[c] - want) <= 1e-12 * want, c
