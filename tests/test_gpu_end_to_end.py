@@ -1,0 +1,113 @@
+"""-m gpu: the reference's workflow in miniature, every stage on this package's GPU paths (train-s1.py, end to end):
+
+  1. ground truth:   odeint(Lambda(), y0, t) on 7 activation + 5 deactivation steps         (HH closed-form kernel, drop-in shim)
+  2. preprocessing:  current -> smoothed spline fit -> (V, a, da/dt) state-space rows     (preprocess.py = train-s1.py:603-808)
+  3. training:       MlpRegression.fit on those rows                                      (regress + reduce + Adam kernels = :891-909)
+  4. prediction:     odeint(ODEFunc(net), y0, t) on a protocol not used for training      (MFMA tile kernel, drop-in shim)
+  5. fine-tuning:    a gradient step on the trace itself through the differentiable solve    (backward sweep; the --adjoint path)
+
+Checked: the regression loss falls by > 20x; the trained NN-f predicts the held-out current better than the untrained one by
+> 3x; a step along the solver's own gradient lowers the trace loss.  No numbers of the reference are involved (its own training
+takes hours); the point is that the stages compose through the reference's interfaces."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+import kat_cases as K
+import ref_style_modules as M
+
+pytestmark = pytest.mark.gpu
+
+
+def _truth(odeint, v_steps, maker):
+    hh = M.HodgkinHuxley(K.P_HH)
+    out = []
+    for v in v_steps:
+        tp, vp, te = maker(v)
+        hh.set_fixed_form_voltage_protocol(tp, vp)
+        with torch.no_grad():
+            y = odeint(hh, torch.tensor([[0.0, 1.0]]), torch.from_numpy(te).float())[:, 0].double().numpy()
+        out.append((tp, vp, te, y))
+    return out
+
+
+def test_simulate_preprocess_train_predict_finetune(ion, gpu):
+    from torchdiffeq import odeint
+    pp = importlib.import_module("neural-ode-ion-channels_amd.preprocess")
+    reg = importlib.import_module("neural-ode-ion-channels_amd.regression")
+    torch.manual_seed(0)
+    rng = np.random.default_rng(0)
+
+    # 1-2. simulate the ground truth on seven activation steps and turn the currents into state-space rows
+    v_rows, a_rows, d_rows, masks = [], [], [], []
+    sims = _truth(odeint, (-60, -40, -20, 0, 20, 40, 60), K.activation) + _truth(odeint, (-120, -100, -80, -60, -40), K.deactivation)
+    for tp, vp, te, y in sims:
+        v = np.interp(te, tp, vp)
+        i = y[:, 0] * y[:, 1] * (v + 86.0) + rng.normal(0, 1e-4, te.size)                     # "measured" current, small noise
+        i_fit, didt = pp.fit_current(te, i, tp, vp, window_len=11)
+        r = y[:, 1]
+        drdt = np.gradient(r, te)
+        a, dadt = pp.state_space_samples(i_fit, didt, r, drdt, v)
+        steps = np.nonzero(np.diff(v))[0] + 1
+        v_rows.append(v); a_rows.append(a); d_rows.append(dadt)
+        masks.append(pp.step_mask(te.size, steps) & np.isfinite(a) & np.isfinite(dadt) & (np.abs(v + 86.0) > 5.0))
+    v_all, a_all, d_all = pp.training_rows(v_rows, a_rows, d_rows, masks, skip=5, sparse=3)
+    assert v_all.size > 5000
+    x = np.stack([v_all / 100.0, a_all], 1)                                                   # net([V / vrange, a]) * netscale = da/dt
+    # 3. train a 2 x 100 net from the reference's initialisation (N(0, 0.1^2), zero bias)
+    L, N = 2, 100
+    nn0 = M.NNf(K.P_HH, n_layers=L, n_nodes=N)
+    for m in nn0.net:
+        if isinstance(m, torch.nn.Linear):
+            torch.nn.init.normal_(m.weight, mean=0.0, std=0.1); torch.nn.init.constant_(m.bias, 0.0)
+    flat0, _, _ = pp.state_dict_to_flat(nn0.state_dict())
+    trainer = reg.MlpRegression(flat0, L, N, x, d_all, lr=1e-3, step_size=200, gamma=0.9, device=gpu)
+    curve = trainer.fit(4000, log_every=1000)
+    first, last = trainer_loss0(flat0, L, N, x, d_all, reg, gpu), curve[-1][2]
+    assert last < first / 20.0, (first, last)
+
+    # 4. held-out deactivation step: untrained against trained net through the drop-in odeint
+    (tp, vp, te, y_true), = _truth(odeint, (-50,), K.deactivation)
+    v = np.interp(te, tp, vp)
+    i_true = y_true[:, 0] * y_true[:, 1] * (v + 86.0)
+
+    def predict(flat):
+        f = M.NNf(K.P_HH, n_layers=L, n_nodes=N)
+        f.load_state_dict({**f.state_dict(), **pp.flat_to_state_dict(flat, L, N)})
+        f.set_fixed_form_voltage_protocol(tp, vp)
+        with torch.no_grad():
+            yy = odeint(f, torch.tensor([[0.0, 1.0]]), torch.from_numpy(te).float())[:, 0].double().numpy()
+        return f, float(np.mean(np.abs(yy[:, 0] * yy[:, 1] * (v + 86.0) - i_true)))
+    _, err0 = predict(flat0)
+    f_tr, err1 = predict(np.asarray(trainer.state_dict_flat()))
+    assert err1 < err0 / 3.0, (err0, err1)
+
+    # 5. a gradient step on the trace itself, through the differentiable solve (odeint_adjoint is the same function): the gradient
+    # the backward sweep returns is a descent direction of the loss the forward computes
+    from torchdiffeq import odeint_adjoint
+    vt, it = torch.from_numpy(v + 86.0), torch.from_numpy(i_true)
+    t32 = torch.from_numpy(te).float()
+
+    def trace_loss():
+        yy = odeint_adjoint(f_tr, torch.tensor([[0.0, 1.0]]), t32)[:, 0].double()
+        return torch.mean(torch.abs(yy[:, 0] * yy[:, 1] * vt - it))                           # train-s1.py:328-329
+    l0 = trace_loss()
+    l0.backward()
+    ps = list(f_tr.net.parameters())
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in ps)
+    gnorm = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in ps)))
+    assert gnorm > 0
+    theta = [p.detach().clone() for p in ps]
+    best = float(l0)
+    with torch.no_grad():
+        for eta in (1e-2, 1e-3, 1e-4):
+            for p, t0_, in zip(ps, theta):
+                p.copy_(t0_ - (eta / gnorm) * p.grad)
+            best = min(best, float(trace_loss()))
+    assert best < float(l0), (float(l0), best, gnorm)
+
+
+def trainer_loss0(flat0, L, N, x, y, reg, gpu):
+    return float(reg.MlpRegression(flat0, L, N, x, y, device=gpu).loss_and_grad()[0])
