@@ -92,6 +92,7 @@ class _Solve(torch.autograd.Function):
                             mlp_layers=L, mlp_width=N, prot_t=cfg.get("prot_t"), prot_t0=cfg["prot_t0"], prot_dt=cfg["prot_dt"],
                             prot_of_traj=cfg.get("prot_of_traj"), rtol=cfg["rtol"], atol=cfg["atol"], v_oob=cfg["v_oob"],
                             max_steps=cfg["max_steps"], max_total_steps=cfg["max_total_steps"], max_step=cfg.get("max_step", 0.0), ckpt=ckpt,
+                            tile_waves=cfg.get("tile_waves", 0),
                             t_eval_hint=cfg.get("t_eval_hint", "auto"))
             nacc = r["stats"][:, 0]
             most = int(nacc.max().item())
@@ -175,7 +176,7 @@ class _Solve(torch.autograd.Function):
 
 def solve(model, weights_flat, params, prot_v, y0, t_eval, *, mlp_layers=0, mlp_width=0, prot_t=None, prot_t0=0.0,
           prot_dt=1.0, prot_of_traj=None, rtol=1e-7, atol=1e-9, v_oob=-80.0, max_steps=0, max_total_steps=0, max_step=0.0,
-          ckpt_cap=None, record_budget_bytes=None, weights_key=None, t_eval_hint="auto", order=None):
+          ckpt_cap=None, record_budget_bytes=None, weights_key=None, t_eval_hint="auto", order=None, tile_waves=0):
     """Differentiable batched solve.  weights_flat [n] fp32 (reference state-dict order; None for the closed-form HH 2-state
     and 6-state models, whose params are [B, 8] / [B, 12] and y0 [B, 2] / [B, 6]), params [B, 8] fp64, y0 [B, 2]
     fp32 | fp64 (the state dtype) -- device tensors, any of which may require grad; prot_v [P, Np], t_eval [Nt] fp64 device
@@ -212,7 +213,8 @@ def solve(model, weights_flat, params, prot_v, y0, t_eval, *, mlp_layers=0, mlp_
     cfg = dict(model=model, mlp_layers=int(mlp_layers), mlp_width=int(mlp_width), prot_v=prot_v, prot_t=prot_t,
                prot_t0=float(prot_t0), prot_dt=float(prot_dt), prot_of_traj=prot_of_traj, t_eval=t_eval, rtol=float(rtol),
                atol=float(atol), v_oob=float(v_oob), max_steps=int(max_steps), max_total_steps=int(max_total_steps),
-               max_step=float(max_step), ckpt_cap=ckpt_cap, record_budget_bytes=record_budget_bytes, weights_key=weights_key, t_eval_hint=t_eval_hint)
+               max_step=float(max_step), ckpt_cap=ckpt_cap, record_budget_bytes=record_budget_bytes, weights_key=weights_key, t_eval_hint=t_eval_hint,
+               tile_waves=int(tile_waves))
     return _Solve.apply(weights_flat, params, y0.contiguous(), cfg)
 
 

@@ -328,3 +328,33 @@ def test_closed_form_gradients_against_the_checker(ion, gpu, oracle, f32, model)
             worst = max(worst, _rel(gp[b], pb.grad.numpy()), _rel(gy0[b], yb.grad.numpy()))
         print(f"model {model} {'f32' if f32 else 'f64'} {'explicit' if pt is not None else 'uniform'} grid: worst rel-L2 vs checker {worst:.2e}")
         assert worst <= GRAD_REL_TOL
+
+
+@pytest.mark.parametrize("model,L,N", [(K.MODEL_HH2, 0, 0), (K.MODEL_MARKOV6, 0, 0), (K.MODEL_NNF, 5, 10)])
+def test_checkpoints_of_the_64_per_wavefront_kernels(ion, gpu, model, L, N):
+    """The forward variants that integrate one trajectory per lane (closed-form models from ~40-80 k trajectories, N <= 16 nets from
+    73 728; forced here with tile_waves = 64) write the same accepted-step checkpoints as the 16-per-wavefront ones: states and
+    gradients of a ragged batch are bit-identical between the two geometries."""
+    rng = np.random.default_rng(3 + model)
+    B = 150
+    m6 = model == K.MODEL_MARKOV6
+    pv = np.stack([K.atau(30)[1][900:1300], K.atau(100)[1][900:1300]])
+    te = np.arange(0.0, 140.0, 1.0)
+    params = np.tile(K.P_M6 if m6 else K.P_HH, (B, 1)) * rng.uniform(0.9, 1.1, (B, 12 if m6 else 8))
+    y0 = np.tile([0.05, 0.9] + ([0.01] * 4 if m6 else []), (B, 1))
+    w = None if N == 0 else _rand_weights(L, N, 5)
+    coef = torch.from_numpy(rng.normal(size=(B, te.size, y0.shape[1]))).to(gpu)
+    res = []
+    for tw in (64, 16 if N == 0 else 1):
+        p = torch.from_numpy(params).to(gpu).requires_grad_(True)
+        y0t = torch.from_numpy(y0).to(gpu).requires_grad_(True)
+        wt = None if w is None else torch.from_numpy(w.copy()).to(gpu).requires_grad_(True)
+        y, st = ion.grad.solve(model, wt, p, torch.from_numpy(pv).to(gpu), y0t, torch.from_numpy(te).to(gpu), mlp_layers=L, mlp_width=N,
+                               prot_t0=0.0, prot_dt=1.0, tile_waves=tw)
+        assert bool((st == 0).all())
+        (y * coef).sum().backward()
+        res.append((y.detach(), p.grad.clone(), y0t.grad.clone(), None if wt is None else wt.grad.clone()))
+    a, b = res
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    if a[3] is not None:
+        assert float((a[3] - b[3]).double().norm() / b[3].double().norm()) < 1e-6
