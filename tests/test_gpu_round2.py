@@ -387,6 +387,13 @@ def test_tiny_nets_at_64_trajectories_per_wavefront(ion, gpu, oracle, model, L, 
         geo[tw] = g
     ok = o["status"] == 0
     assert np.array_equal(geo[64]["i"][ok], geo[1]["i"][ok])
+    # fused objective in both geometries (the 64-per-wavefront kernel keeps 8-lane partial sums in LDS): same sums to rounding
+    ref = rng.normal(0, 0.2, (3, te.size))
+    sse = {tw: ion.solve(model, params, pv, torch.from_numpy(y0).to(torch.float32 if f32 else torch.float64), te, weights=w,
+                         mlp_layers=L, mlp_width=N, sse_ref=ref, states=False, tile_waves=tw, **kw).sse.cpu().numpy() for tw in (64, 1)}
+    want = ((geo[1]["i"] - ref[pot]) ** 2).sum(1)
+    assert np.isinf(sse[64][77]) and np.isinf(sse[1][77])
+    assert np.allclose(sse[64][ok], want[ok], rtol=1e-12, atol=0) and np.allclose(sse[1][ok], want[ok], rtol=1e-12, atol=0)
     d = ion.capi.make_desc(model=model, state_f32=int(f32), n_state=2, n_out=te.size, n_traj=B, n_prot=3, prot_n=pv.shape[1],
                            mlp_layers=L, mlp_width=N, n_params=8, prot_dt=1.0, rtol=1e-7, atol=1e-9, tile_waves=64)
     assert ion.capi.launch_geometry(d)["grid"] == 3 and ", 1, 64, 1, 1, " in ion.capi.kernel_name(d)
