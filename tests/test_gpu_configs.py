@@ -252,8 +252,8 @@ def test_population_objective_over_network_weights(ion, gpu, oracle):
         assert abs(got[c] - want) <= 1e-12 * want, c
 
 
-@pytest.mark.parametrize("B", [40000, 140000])
-def test_closed_form_three_per_simd_builds_at_large_batches(ion, gpu, oracle, B):
+@pytest.mark.parametrize("B,f32", [(40000, False), (140000, False), (140000, True)])
+def test_closed_form_three_per_simd_builds_at_large_batches(ion, gpu, oracle, B, f32):
     """The 2-state kernels exist at 2 and at 3 wavefronts per SIMD; launches of at most 2048 wavefronts (every small test) take
     the former.  These batches are large enough for the 3-per-SIMD builds -- 16 per wavefront (B = 40 000) and 64 per
     wavefront (B = 140 000) -- in all three emission variants (plain / deferred aligned stores / table epilogue): 24 random
@@ -264,7 +264,7 @@ def test_closed_form_three_per_simd_builds_at_large_batches(ion, gpu, oracle, B)
     half = np.tile(K.P_HH, (B // 2, 1)) * rng.uniform(0.8, 1.25, (B // 2, 8))
     params = np.concatenate([half, half])
     pot = np.tile((np.arange(B // 2) % 3).astype(np.int32), 2)
-    y0 = torch.tensor([[0.0, 1.0]], dtype=torch.float64)
+    y0 = torch.tensor([[0.0, 1.0]], dtype=torch.float32 if f32 else torch.float64)
     pick = rng.choice(B // 2, 24, replace=False)
     ref = rng.normal(0, 0.3, (3, 401))
     for name, te, kw in (("deferred", np.arange(0, 2001, 5) * 1.0, {}),                                   # exact grid, states only
@@ -272,9 +272,33 @@ def test_closed_form_three_per_simd_builds_at_large_batches(ion, gpu, oracle, B)
                          ("table", np.arange(0, 2001, 5) * 1.0, dict(current=True, sse_ref=ref))):       # current + objective
         sol = ion.solve(K.MODEL_HH2, params, pv, y0, te, prot_t0=0.0, prot_dt=1.0, prot_of_traj=pot, **kw)
         assert ", 1, %d, 0, 0, %d>" % (16 if B < 81920 else 0, {"deferred": 1, "plain": 0, "table": 2}[name]) in sol.kernel, sol.kernel
-        o = oracle.solve(K.MODEL_HH2, params[pick], pv, [0.0, 1.0], te, prot_t0=0.0, prot_dt=1.0, prot_of_traj=pot[pick], nthreads=8)
-        assert np.array_equal(sol.y[pick].cpu().numpy(), o["y"]) and np.array_equal(sol.stats[pick].cpu().numpy(), o["stats"])
+        assert ("float" if f32 else "double") in sol.kernel
+        o = oracle.solve(K.MODEL_HH2, params[pick], pv, [0.0, 1.0], te, prot_t0=0.0, prot_dt=1.0, prot_of_traj=pot[pick], nthreads=8,
+                         state_f32=f32)
+        assert np.array_equal(sol.y[pick].double().cpu().numpy(), o["y"]) and np.array_equal(sol.stats[pick].cpu().numpy(), o["stats"])
         assert torch.equal(sol.y[: B // 2], sol.y[B // 2:]) and bool((sol.status == 0).all())
         if name == "table":
             want = ((sol.i - torch.from_numpy(ref).to(gpu)[torch.from_numpy(pot).to(gpu).long()]) ** 2).sum(1)
             assert torch.allclose(sol.sse, want, rtol=1e-12, atol=0)
+
+
+def test_tiny_net_kernel_chosen_for_large_batches(ion, gpu, oracle):
+    """From 73 728 trajectories the N <= 16 nets run one trajectory per lane by themselves (with the deferred aligned emission on an
+    exact grid): 24 random trajectories of an 80 000-trajectory batch against the oracle, repeated inputs repeat their bits."""
+    import torch
+    rng = np.random.default_rng(8)
+    B, L, N = 80000, 5, 10
+    w = rng.normal(0, 0.3, 2 * N + N + L * (N * N + N) + N + 1).astype(np.float32)
+    pv = np.stack([K.activation(v)[1][:2001] for v in (-40, 0, 40)])
+    half = np.tile(K.P_HH, (B // 2, 1)) * rng.uniform(0.85, 1.2, (B // 2, 8))
+    params = np.concatenate([half, half])
+    pot = np.tile((np.arange(B // 2) % 3).astype(np.int32), 2)
+    te = np.arange(0, 2001, 5) * 1.0
+    sol = ion.solve(K.MODEL_NNF, params, pv, torch.tensor([K.NN_Y0], dtype=torch.float64), te, weights=w, mlp_layers=L, mlp_width=N,
+                    prot_t0=0.0, prot_dt=1.0, prot_of_traj=pot)
+    assert ", 1, 64, 1, 1, 1>" in sol.kernel and bool((sol.status == 0).all())
+    pick = rng.choice(B // 2, 24, replace=False)
+    o = oracle.solve(K.MODEL_NNF, params[pick], pv, K.NN_Y0, te, weights=w, mlp_layers=L, mlp_width=N, prot_t0=0.0, prot_dt=1.0,
+                     prot_of_traj=pot[pick], nthreads=8)
+    assert np.array_equal(sol.y[pick].cpu().numpy(), o["y"]) and np.array_equal(sol.stats[pick].cpu().numpy(), o["stats"])
+    assert torch.equal(sol.y[: B // 2], sol.y[B // 2:])
