@@ -252,7 +252,7 @@ def test_population_objective_over_network_weights(ion, gpu, oracle):
         assert abs(got[c] - want) <= 1e-12 * want, c
 
 
-@pytest.mark.parametrize("B,f32", [(40000, False), (140000, False), (140000, True)])
+@pytest.mark.parametrize("B,f32", [(40000, False), (40000, True), (140000, False), (140000, True)])
 def test_closed_form_three_per_simd_builds_at_large_batches(ion, gpu, oracle, B, f32):
     """The 2-state kernels exist at 2 and at 3 wavefronts per SIMD; launches of at most 2048 wavefronts (every small test) take
     the former.  These batches are large enough for the 3-per-SIMD builds -- 16 per wavefront (B = 40 000) and 64 per
