@@ -106,14 +106,21 @@ def main():
     out = {}
     if args.stamps:
         slog = torch.zeros((16, 4), dtype=torch.float64, device=dev)
-        capi.dopri5(capi.MODEL_NNF, params, prot_v, y0, t_eval, mlp_packed=packed, mlp_layers=MLP_L, mlp_width=MLP_N,
-                    prot_t0=0.0, prot_dt=0.1, current=True, tile_waves=args.tile_waves, t_eval_hint=(0.0, 0.1), step_log=slog)
+        rs = capi.dopri5(capi.MODEL_NNF, params, prot_v, y0, t_eval, mlp_packed=packed, mlp_layers=MLP_L, mlp_width=MLP_N,
+                         prot_t0=0.0, prot_dt=0.1, current=True, tile_waves=args.tile_waves, t_eval_hint=(0.0, 0.1), step_log=slog)
         torch.cuda.synchronize()
         t = slog.cpu().numpy().reshape(-1)[:16]
+        nfe0 = int(rs["stats"][:16, 2].max().item())  # RHS evaluations of tile 0 = of its slowest trajectory
+        ts = slog.cpu().numpy().reshape(-1)[16:32]
+        if ts.sum() > 0:
+            print("ASM STAMPS (cycles per layer pass; 0..12 = k-tile steps, 13 = first half of step 0, 14 = barrier, 15 = outside):",
+                  [int(x / (nfe0 * MLP_L)) for x in ts], file=sys.stderr)
+        print("STAMPS tile 0: %d evaluations, %.0f cycles each" % (nfe0, t[:11].sum() / nfe0), file=sys.stderr)
         names = ["outside-mlp", "layer0", "barriers", "hidden-mfma", "lrelu+store", "last-layer", "rk-stage/err", "interp+emit"]
         names += ["layer-prologue", "ktile-0", "ktile-last"]
         tot = t[:11].sum()
-        print("STAMPS (wave 0 of block 0, cycles):", {n: (int(v), round(v / tot, 3)) for n, v in zip(names, t[:11])}, file=sys.stderr)
+        print("STAMPS (wave 0 of block 0, cycles per evaluation, share):",
+              {n: (int(v / nfe0), round(v / tot, 3)) for n, v in zip(names, t[:11])}, file=sys.stderr)
 
     def allreduce(x, op=None):
         if dist is None:

@@ -97,6 +97,7 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false) {
     pl->block = 64u * pl->v->G;
     const int Gv = pl->v->G, Rv = NT - Gv * (NT / Gv);  // remainder row tiles: K-split partial sums in LDS
     pl->lds = ((size_t)2 * (NT + Gv - 1) * 64 + (size_t)2 * Rv * Gv * 64 + NP) * 16 + ((size_t)d->mlp_layers * NP + NP + 4) * 4;
+    if (Gv == 4 && NT == 13) pl->lds = ((pl->lds + 15) & ~(size_t)15) + 1024;  // scratch slot of the asm stream (MlpTile::scratch_off)
     if (t64) pl->lds = ((pl->lds + 15) & ~(size_t)15) + (size_t)64 * (4 + 5 * 2) * 8 + (size_t)64 * 64;  // + interpolant rows + tails
   }
   if (!pl->v) { set_err("no kernel variant compiled for this descriptor"); return IONODE_ERR_UNSUPPORTED; }

@@ -310,8 +310,20 @@ __device__ __forceinline__ float lrelu(float x) { return fmaxf(x, x * 0.01f); }
 // bytes by 17 % changed nothing): the MFMA count and the issue work per k-tile step and per layer boundary are.
 // Small vectors (layer-0 rows, biases, last-layer weights) live in LDS for the kernel's lifetime.
 // ---------------------------------------------------------------------------------------------
+// Hand-scheduled hidden-layer stream (tools/gen_mlp_asm.py -> mlp_asm_nt13.inc): the N = 200 tile <4, 4, 13, 13> runs its
+// hidden stack as ONE inline-asm statement with a fixed register map (weight ring in AGPRs a[0:171], working set in
+// v[184:255]) and a software-pipelined layer boundary; same canonical accumulation order, same bits.  -DIONODE_NO_ASM_CORE
+// builds the compiler-scheduled stream instead (A/B, stamps).
+#if !defined(IONODE_NO_ASM_CORE)
+#define IONODE_ASM_CORE 1
+#include "mlp_asm_nt13.inc"
+#else
+#define IONODE_ASM_CORE 0
+#endif
+
 template <int G, int RT, int NT, int PD, int TAIL = 0>
 struct MlpTile {
+  static constexpr bool ASM = IONODE_ASM_CORE && G == 4 && NT == 13 && PD == 13;
   static constexpr int F = NT / G;       // full row tiles per wavefront
   static constexpr int R = NT - G * F;   // remainder row tiles, K-split over the G wavefronts
   static constexpr int NP = 16 * NT;
@@ -344,6 +356,7 @@ struct MlpTile {
   unsigned voff;      // per lane: byte offset of (this wavefront's stream, lane) inside a hidden layer
   unsigned hid0;      // byte offset of hidden layer 0 in the image
   unsigned lbytes;    // bytes per hidden layer in the image
+  unsigned lds0;      // LDS byte address of the tile's region (asm stream)
   int L, wave, lane;
 #ifdef IONODE_STAMPS
   Stamps *sp;
@@ -358,6 +371,9 @@ struct MlpTile {
   static __host__ __device__ constexpr size_t lds_bytes(int L) {
     return ((size_t)2 * HT * 64 + (size_t)2 * R * G * 64 + NP) * 16 + ((size_t)L * NP + NP + 4) * 4;
   }
+  // the asm stream parks the stores of a not-yet-existing previous layer in a 1 KiB scratch slot behind the tile's LDS
+  // (so that every pass issues the same LDS operations and the wait counts are static)
+  static __host__ __device__ constexpr size_t scratch_off(int L) { return (lds_bytes(L) + 15) & ~(size_t)15; }
 
   __device__ __forceinline__ void init(const KArgs &a, unsigned char *smem, int wave_, int lane_, int first_traj = 0) {
     L = a.L; wave = wave_; lane = lane_;
@@ -384,6 +400,18 @@ struct MlpTile {
     if constexpr (TINY) {
 #pragma unroll
       for (int l = 0; l < LMAX; ++l) wres[l] = (l < L) ? frag(hid0 + (unsigned)l * lbytes, 0) : f32x4{0, 0, 0, 0};
+    }
+    if constexpr (ASM) {
+#if IONODE_ASM_CORE
+      lds0 = (unsigned)(uintptr_t)smem;
+      if (L > 0)
+        asm volatile(IONODE_MLPASM_INIT_13
+                     :
+                     : [voff] "v"(voff), [rsrc] "s"(rsrc), [hid0] "s"(hid0)
+                     : "memory", "scc", IONODE_MLPASM_CLOBBER_A_13, IONODE_MLPASM_CLOBBER_S_13);
+#endif
+      __syncthreads();
+      return;
     }
     // prime the ring with the first PD steps of hidden layer 0
 #pragma unroll
@@ -520,6 +548,29 @@ struct MlpTile {
     }
     MSTAMP(1);  // slot 1: layer 0
 
+#if IONODE_ASM_CORE
+    if constexpr (ASM) {
+      if (L > 0) {
+        // per-lane LDS byte addresses of the two activation buffers (b = 0: input of even layers) and partial-sum buffers
+        const unsigned hw0 = lds0 + (unsigned)(wave * 64 + lane) * 16u, hw1 = hw0 + (unsigned)tstride * 16u;
+        const unsigned fw0 = lds0 + (unsigned)((NT - 1) * 64 + lane) * 16u, fw1 = fw0 + (unsigned)tstride * 16u;
+        const unsigned pl0 = lds0 + (unsigned)(2 * tstride) * 16u + (unsigned)lane * 16u, pl1 = pl0 + (unsigned)pstride * 16u;
+        const unsigned pw0 = pl0 + (unsigned)wave * 1024u, pw1 = pl1 + (unsigned)wave * 1024u;
+        const unsigned bias0 = (unsigned)(uintptr_t)biasS;
+        const unsigned bias_a = bias0 + (unsigned)(16 * wave + 4 * q) * 4u, bias_r = bias0 + (unsigned)(16 * (NT - 1) + 4 * q) * 4u;
+        const unsigned dummy = lds0 + (unsigned)scratch_off(L) + (unsigned)lane * 16u;
+        const int nl = __builtin_amdgcn_readfirstlane(L);
+        asm volatile(IONODE_MLPASM_LAYERS_13
+                     :
+                     : [hw_in] "v"(hw0), [hw_out] "v"(hw1), [fw_in] "v"(fw0), [fw_out] "v"(fw1), [pl_in] "v"(pl0), [pl_out] "v"(pl1),
+                       [pw_in] "v"(pw0), [pw_out] "v"(pw1), [bias_a] "v"(bias_a), [bias_r] "v"(bias_r), [voff] "v"(voff),
+                       [dummy] "v"(dummy), [h0] "v"(hOwn[0]), [h1] "v"(hOwn[1]), [h2] "v"(hOwn[2]), [h3] "v"(hOwn[3]),
+                       [rsrc] "s"(rsrc), [nl] "s"(nl), [lbytes] "s"(lbytes), [hid0] "s"(hid0), [wave] "s"(wave)
+                     : "memory", "scc", "vcc", IONODE_MLPASM_CLOBBER_V_13, IONODE_MLPASM_CLOBBER_A_13, IONODE_MLPASM_CLOBBER_S_13);
+      }
+      MSTAMP(3);  // slot 3: the whole hidden stack (asm stream)
+    } else
+#endif
     for (int l = 0; l < L; ++l) {
       f32x4 *__restrict__ Hin = Hs + (l & 1) * tstride;
       f32x4 *__restrict__ Hout = Hs + ((l + 1) & 1) * tstride;
@@ -1503,6 +1554,13 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
   STAMP(stamps_, 0);
   if (blockIdx.x == 0 && threadIdx.x == 0 && a.step_log != nullptr && a.step_log_cap >= 4)
     for (int i_ = 0; i_ < 16; ++i_) a.step_log[i_] = (double)stamps_.acc[i_];
+#ifdef IONODE_ASM_STAMPS  // per-position cycle sums of the asm stream (tools/gen_mlp_asm.py --stamps): lanes of a[92]
+  if constexpr (MT::MLP && G == 4 && NT == 13) {
+    unsigned sv_;
+    asm volatile("v_accvgpr_read_b32 %0, a92" : "=v"(sv_));
+    if (blockIdx.x == 0 && threadIdx.x < 16 && a.step_log != nullptr && a.step_log_cap >= 8) a.step_log[16 + threadIdx.x] = (double)sv_;
+  }
+#endif
 #endif
   if constexpr (LW) {
     if (a.sse_out != nullptr) {
