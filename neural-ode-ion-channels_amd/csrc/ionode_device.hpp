@@ -99,6 +99,15 @@ __device__ constexpr double kCmid[7] = {
 // across devices/libraries if both are fixed IEEE operation sequences.  < 1 ulp / <= 2 ulp accurate.
 __device__ __forceinline__ double pow2i(int k) { return __longlong_as_double((long long)(k + 1023) << 52); }
 
+// fma(p, r, c) with the constant c as a SCALAR operand.  Left to itself hipcc emits v_fmac_f64 with c copied into the destination
+// register first (two v_mov_b32 per constant and use -- or, with machine-LICM, every constant hoisted into a VGPR pair that is
+// then spilled); both are VALU instructions on the pipe the f32 MFMA shares.  An SGPR pair costs two s_mov_b32.
+__device__ __forceinline__ double fma_sc(double p, double r, double c) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(p), "v"(r), "s"(c));
+  return d;
+}
+
 __device__ __forceinline__ double det_exp(double x) {
   if (x != x) return x;
   if (x > 709.782712893384) return __builtin_inf();
@@ -153,6 +162,34 @@ __device__ __forceinline__ double det_exp_ldexp(double x) {
   return __builtin_ldexp(p, (int)kf);
 }
 
+// det_exp for the MLP kernels' rate terms: same operation sequence, constants as scalar operands (fma_sc), scaling by one
+// v_ldexp_f64 (bit-identical, det_exp_ldexp below) -- 36 instead of 62 vector instructions per call.
+__device__ __forceinline__ double det_exp_s(double x) {
+  // branch-free: the range cases are selects behind the polynomial (in-range arguments take the same operations as det_exp;
+  // out-of-range arguments compute a discarded value), so two calls interleave instead of running under exec masks
+  const double kf = rint(x * 0x1.71547652b82fep+0);
+  double r = fma(-kf, 0x1.62e42fee00000p-1, x);
+  r = fma(-kf, 0x1.a39ef35793c76p-33, r);
+  double p = 1.0 / 6227020800.0;
+  p = fma_sc(p, r, 1.0 / 479001600.0);
+  p = fma_sc(p, r, 1.0 / 39916800.0);
+  p = fma_sc(p, r, 1.0 / 3628800.0);
+  p = fma_sc(p, r, 1.0 / 362880.0);
+  p = fma_sc(p, r, 1.0 / 40320.0);
+  p = fma_sc(p, r, 1.0 / 5040.0);
+  p = fma_sc(p, r, 1.0 / 720.0);
+  p = fma_sc(p, r, 1.0 / 120.0);
+  p = fma_sc(p, r, 1.0 / 24.0);
+  p = fma_sc(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  double e = __builtin_ldexp(p, (int)kf);  // == (p * 2^k1) * 2^(k - k1), see det_exp_ldexp
+  e = (x > 709.782712893384) ? __builtin_inf() : e;
+  e = (x < -745.1332191019412) ? 0.0 : e;
+  return (x != x) ? x : e;
+}
+
 // a / b when rb = RN(1 / b) is at hand: q0 = RN(a * rb) is a faithful quotient, and one correction step with the exact
 // remainder r = a - b*q0 (fma) gives RN(a / b) -- the correctly rounded IEEE quotient, bit for bit what `a / b` returns
 // (Markstein 1990; holds barring over/underflow: operands here are times in ms, voltages in mV and O(1) ratios).  Three
@@ -166,6 +203,24 @@ __device__ __forceinline__ double div_by(double a, double b, double rb) {
   const double q1 = fma(r, rb, q0);
   const double aq = __builtin_fabs(q0);
   return (aq > 0.0 && aq < __builtin_inf()) ? q1 : q0;
+}
+
+// a / b for a compile-time constant b (rb = RN(1 / b)): the same correction step, with the true division kept for the quotients
+// the proof excludes (zero, subnormal range, overflow).  fp32: checked against x / 1000.0f for all 2^32 inputs -- they differ only
+// where |quotient| < 2^-126 (67 108 inputs, all |x| < 9.5e-38); the guards below are far inside the safe range.
+__device__ __forceinline__ double div_const(double a, double b, double rb) {
+  const double q0 = a * rb;
+  const double r = fma(-b, q0, a);
+  const double q1 = fma(r, rb, q0);
+  const double aq = __builtin_fabs(q0);
+  return (aq > 0x1p-900 && aq < 0x1p+900) ? q1 : a / b;
+}
+__device__ __forceinline__ float div_constf(float a, float b, float rb) {
+  const float q0 = a * rb;
+  const float r = fmaf(-b, q0, a);
+  const float q1 = fmaf(r, rb, q0);
+  const float aq = __builtin_fabsf(q0);
+  return (aq > 0x1p-100f && aq < 0x1p+100f) ? q1 : a / b;
 }
 
 __device__ __forceinline__ double det_root5(double x) {
@@ -357,6 +412,7 @@ struct MlpTile {
   unsigned hid0;      // byte offset of hidden layer 0 in the image
   unsigned lbytes;    // bytes per hidden layer in the image
   unsigned lds0;      // LDS byte address of the tile's region (asm stream)
+  int bl_bits;        // bias of Linear(N, 1), wave-uniform (asm stream)
   int L, wave, lane;
 #ifdef IONODE_STAMPS
   Stamps *sp;
@@ -411,6 +467,7 @@ struct MlpTile {
                      : "memory", "scc", IONODE_MLPASM_CLOBBER_A_13, IONODE_MLPASM_CLOBBER_S_13);
 #endif
       __syncthreads();
+      bl_bits = __builtin_amdgcn_readfirstlane(__float_as_int(wlS[NP]));
       return;
     }
     // prime the ring with the first PD steps of hidden layer 0
@@ -525,6 +582,35 @@ struct MlpTile {
     constexpr int tstride = HT * 64;
     constexpr int pstride = R * G * 64;
     MSTAMP(0);  // slot 0: everything outside the MLP (RK scalar work, emission)
+#if IONODE_ASM_CORE
+    if constexpr (ASM) {
+      if (L > 0) {
+        // the whole evaluation -- Linear(2, N), the hidden stack, Linear(N, 1) -- is one asm statement (tools/gen_mlp_asm.py).
+        // Inputs: per-lane LDS byte addresses of the two activation buffers (b = 0: input of even layers), the partial-sum
+        // buffers, this lane's rows of the small vectors, and the wavefront's weight stream.
+        const unsigned hw0 = lds0 + (unsigned)(wave * 64 + lane) * 16u, hw1 = hw0 + (unsigned)tstride * 16u;
+        const unsigned fw0 = lds0 + (unsigned)((NT - 1) * 64 + lane) * 16u, fw1 = fw0 + (unsigned)tstride * 16u;
+        const unsigned pl0 = lds0 + (unsigned)(2 * tstride) * 16u + (unsigned)lane * 16u, pl1 = pl0 + (unsigned)pstride * 16u;
+        const unsigned pw0 = pl0 + (unsigned)wave * 1024u, pw1 = pl1 + (unsigned)wave * 1024u;
+        const unsigned bias0 = (unsigned)(uintptr_t)biasS, w00 = (unsigned)(uintptr_t)W0s;
+        const unsigned bias_a = bias0 + (unsigned)(16 * wave + 4 * q) * 4u, bias_r = bias0 + (unsigned)(16 * (NT - 1) + 4 * q) * 4u;
+        const unsigned w0a = w00 + (unsigned)(16 * wave + 4 * q) * 16u, w0r = w00 + (unsigned)(16 * (NT - 1) + 4 * q) * 16u;
+        const unsigned wla = (unsigned)(uintptr_t)wlS + (unsigned)q * 16u;
+        const unsigned dummy = lds0 + (unsigned)scratch_off(L) + (unsigned)lane * 16u;
+        const int nl = __builtin_amdgcn_readfirstlane(L);
+        float out;
+        asm volatile(IONODE_MLPASM_LAYERS_13
+                     : [out] "=v"(out)
+                     : [hw_in] "v"(hw0), [hw_out] "v"(hw1), [fw_in] "v"(fw0), [fw_out] "v"(fw1), [pl_in] "v"(pl0), [pl_out] "v"(pl1),
+                       [pw_in] "v"(pw0), [pw_out] "v"(pw1), [bias_a] "v"(bias_a), [bias_r] "v"(bias_r), [voff] "v"(voff),
+                       [dummy] "v"(dummy), [w0a] "v"(w0a), [w0r] "v"(w0r), [wla] "v"(wla), [x0] "v"(x0), [x1] "v"(x1),
+                       [rsrc] "s"(rsrc), [nl] "s"(nl), [lbytes] "s"(lbytes), [hid0] "s"(hid0), [wave] "s"(wave), [bl] "s"(bl_bits)
+                     : "memory", "scc", "vcc", IONODE_MLPASM_CLOBBER_V_13, IONODE_MLPASM_CLOBBER_A_13, IONODE_MLPASM_CLOBBER_S_13);
+        MSTAMP(3);  // slot 3: the whole evaluation (asm stream)
+        return out;
+      }
+    }
+#endif
 
     // layer 0: Linear(2, N) + LeakyReLU on the VALU, written in accumulator layout; row tile rt by wavefront rt % G.
     // hOwn = this wavefront's tile `wave`: the k-tile it consumes at step 0 of the next layer ((0 + w) mod NT).
@@ -548,29 +634,7 @@ struct MlpTile {
     }
     MSTAMP(1);  // slot 1: layer 0
 
-#if IONODE_ASM_CORE
-    if constexpr (ASM) {
-      if (L > 0) {
-        // per-lane LDS byte addresses of the two activation buffers (b = 0: input of even layers) and partial-sum buffers
-        const unsigned hw0 = lds0 + (unsigned)(wave * 64 + lane) * 16u, hw1 = hw0 + (unsigned)tstride * 16u;
-        const unsigned fw0 = lds0 + (unsigned)((NT - 1) * 64 + lane) * 16u, fw1 = fw0 + (unsigned)tstride * 16u;
-        const unsigned pl0 = lds0 + (unsigned)(2 * tstride) * 16u + (unsigned)lane * 16u, pl1 = pl0 + (unsigned)pstride * 16u;
-        const unsigned pw0 = pl0 + (unsigned)wave * 1024u, pw1 = pl1 + (unsigned)wave * 1024u;
-        const unsigned bias0 = (unsigned)(uintptr_t)biasS;
-        const unsigned bias_a = bias0 + (unsigned)(16 * wave + 4 * q) * 4u, bias_r = bias0 + (unsigned)(16 * (NT - 1) + 4 * q) * 4u;
-        const unsigned dummy = lds0 + (unsigned)scratch_off(L) + (unsigned)lane * 16u;
-        const int nl = __builtin_amdgcn_readfirstlane(L);
-        asm volatile(IONODE_MLPASM_LAYERS_13
-                     :
-                     : [hw_in] "v"(hw0), [hw_out] "v"(hw1), [fw_in] "v"(fw0), [fw_out] "v"(fw1), [pl_in] "v"(pl0), [pl_out] "v"(pl1),
-                       [pw_in] "v"(pw0), [pw_out] "v"(pw1), [bias_a] "v"(bias_a), [bias_r] "v"(bias_r), [voff] "v"(voff),
-                       [dummy] "v"(dummy), [h0] "v"(hOwn[0]), [h1] "v"(hOwn[1]), [h2] "v"(hOwn[2]), [h3] "v"(hOwn[3]),
-                       [rsrc] "s"(rsrc), [nl] "s"(nl), [lbytes] "s"(lbytes), [hid0] "s"(hid0), [wave] "s"(wave)
-                     : "memory", "scc", "vcc", IONODE_MLPASM_CLOBBER_V_13, IONODE_MLPASM_CLOBBER_A_13, IONODE_MLPASM_CLOBBER_S_13);
-      }
-      MSTAMP(3);  // slot 3: the whole hidden stack (asm stream)
-    } else
-#endif
+    if constexpr (!ASM)  // (the asm tile comes here only with L == 0)
     for (int l = 0; l < L; ++l) {
       f32x4 *__restrict__ Hin = Hs + (l & 1) * tstride;
       f32x4 *__restrict__ Hout = Hs + ((l + 1) & 1) * tstride;
@@ -755,9 +819,10 @@ __device__ __forceinline__ void rhs(const KArgs &a, const double *p, double v, b
     float net = 0.0f;
     if constexpr (MT::MLP) {
       const float vf = (float)a.v_oob;
-      const float nv = oob32 ? vf / 100.0f : (float)(v / 100.0);  // v / self.vrange, then .float()
-      if constexpr (WIDE) net = mlp.eval_tiny64(nv, (float)av) / 1000.0f;  // 64 trajectories per wavefront (N <= 16)
-      else net = mlp.eval(nv, (float)av) / 1000.0f;                // / self.netscale
+      // v / self.vrange, then .float(); net / self.netscale -- exact quotients by the constants 100 and 1000 (div_const)
+      const float nv = oob32 ? vf / 100.0f : (float)div_const(v, 100.0, 0.01);
+      if constexpr (WIDE) net = div_constf(mlp.eval_tiny64(nv, (float)av), 1000.0f, 0.001f);  // 64 trajectories per wavefront (N <= 16)
+      else net = div_constf(mlp.eval(nv, (float)av), 1000.0f, 0.001f);
     }
 
     if (oob32) {
@@ -779,13 +844,14 @@ __device__ __forceinline__ void rhs(const KArgs &a, const double *p, double v, b
     }
     const S one_m_a = (S)1 - av;  // `1. - a` / `self.unity - r` are formed in y.dtype
     const S one_m_r = (S)1 - rv;
-    const double k3 = p[4] * det_exp(p[5] * v);
-    const double k4 = p[6] * det_exp(-p[7] * v);
+    auto dexp = [](double x) { if constexpr (MT::MLP) return det_exp_s(x); else return det_exp(x); };
+    const double k3 = p[4] * dexp(p[5] * v);
+    const double k4 = p[6] * dexp(-p[7] * v);
     const double drdt = -k3 * (double)rv + k4 * (double)one_m_r;
     double dadt = 0.0;
     if constexpr (HAS_HH_A) {
-      const double k1 = p[0] * det_exp(p[1] * v);
-      const double k2 = p[2] * det_exp(-p[3] * v);
+      const double k1 = p[0] * dexp(p[1] * v);
+      const double k2 = p[2] * dexp(-p[3] * v);
       dadt = k1 * (double)one_m_a - k2 * (double)av;
     }
     if constexpr (MT::MLP) dadt = (MODEL == IONODE_MODEL_NND) ? dadt + (double)net : (double)net;

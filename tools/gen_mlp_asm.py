@@ -36,7 +36,7 @@ G = 4  # wavefronts per tile
 
 
 class Gen:
-    def __init__(self, nt, pd=7, vb=184, sb=84, stamps=False):
+    def __init__(self, nt, pd=7, vb=180, sb=84, stamps=False):
         assert nt % G == 1 or True
         self.NT = nt
         self.F = nt // G
@@ -62,9 +62,9 @@ class Gen:
         self.X = v(44)
         self.Y = v(48)
         names = ["HW_IN", "HW_OUT", "FW_IN", "FW_OUT", "PL_IN", "PL_OUT", "PW_IN", "PW_OUT",
-                 "BIAS_A", "BIAS_R", "VOFF", "DUMMY", "DUP", "LO_TILE", "LO_PART", "FOLDW"]
+                 "BIAS_A", "BIAS_R", "VOFF", "DUMMY", "DUP", "LO_TILE", "LO_PART", "FOLDW", "W0A", "W0R", "WLA", "PART"]
         self.A = {n: v(52 + i) for i, n in enumerate(names)}
-        self.n_vgpr = 72
+        self.n_vgpr = 76
         assert 52 + len(names) <= self.n_vgpr and vb + self.n_vgpr <= 256
         # --- fixed SGPR map ---
         s = lambda k: sb + k
@@ -374,11 +374,10 @@ class Gen:
         lbl = "%="
         # ---- entry ----
         e("s_waitcnt lgkmcnt(0)")
-        ins = ["HW_IN", "HW_OUT", "FW_IN", "FW_OUT", "PL_IN", "PL_OUT", "PW_IN", "PW_OUT", "BIAS_A", "BIAS_R", "VOFF", "DUMMY"]
+        ins = ["HW_IN", "HW_OUT", "FW_IN", "FW_OUT", "PL_IN", "PL_OUT", "PW_IN", "PW_OUT", "BIAS_A", "BIAS_R", "VOFF", "DUMMY",
+               "W0A", "W0R", "WLA"]
         for n in ins:
             e("v_mov_b32_e32 v%d, %%[%s]" % (A[n], n.lower()))
-        for r in range(4):
-            e("v_mov_b32_e32 v%d, %%[h%d]" % (self.HO + r, r))
         e("s_mov_b32 s%d, 0" % self.S_L)
         e("s_mov_b32 s%d, %%[nl]" % self.S_NL)
         e("s_mov_b32 s%d, %%[lbytes]" % self.S_LB)
@@ -388,9 +387,41 @@ class Gen:
         e("s_cselect_b64 s[%d:%d], -1, 0" % self.S_W0)
         e("s_cmp_lt_u32 %[wave], 3")
         e("s_cselect_b64 s[%d:%d], -1, 0" % self.S_W3)
-        for n in ("LO_TILE", "LO_PART", "FOLDW", "DUP"):
+        for n in ("LO_TILE", "LO_PART", "FOLDW"):
             e("v_mov_b32_e32 v%d, v%d" % (A[n], A["DUMMY"]))
+        e("v_add_u32_e32 v%d, %d, v%d" % (A["DUP"], self.NT * 1024, A["HW_IN"]))
+        e("v_cndmask_b32_e64 v%d, v%d, v%d, s[%d:%d]" % (A["DUP"], A["DUMMY"], A["DUP"], self.S_W3[0], self.S_W3[1]))
         T4 = self.T + [self.TR]
+        # ---- layer 0: Linear(2, N) + LeakyReLU on the VALU, h = lrelu(fmaf(w1, x1, fmaf(w0, x0, b))); rows {b, w0, w1, 0} in LDS.
+        # Row tiles wave, wave + 4, wave + 8 (own tile -> HO and the B operand of step 0) and the remainder tile (every
+        # wavefront writes it: identical bits).  Two 16-register row buffers: the next tile's rows are in flight meanwhile.
+        self.reset_counters()
+        RB = [T4, [self.B[0], self.B[1], self.X, self.Y]]
+        tiles = [("W0A", 0, self.HO, [("HW_IN", 0), ("DUP", 0)]), ("W0A", 1024, self.ACC[0], [("HW_IN", 4096)]),
+                 ("W0A", 2048, self.ACC[1], [("HW_IN", 8192)]), ("W0R", 0, self.ACC[2], [("FW_IN", 0)])]
+        rd = {}
+
+        def l0_reads(ti):
+            areg, off, _, _ = tiles[ti]
+            rd[ti] = [self.ds_read(RB[ti & 1][r], areg, off + 16 * r) for r in range(4)]
+        l0_reads(0)
+        l0_reads(1)
+        for ti, (areg, off, dst, stores) in enumerate(tiles):
+            rows = RB[ti & 1]
+            self.wait_ds(rd[ti][3])
+            for r in range(4):
+                e("v_fma_f32 v%d, v%d, %%[x0], v%d" % (rows[r], rows[r] + 1, rows[r]))
+            for r in range(4):
+                e("v_fma_f32 v%d, v%d, %%[x1], v%d" % (rows[r], rows[r] + 2, rows[r]))
+            for r in range(4):
+                e("v_mul_f32_e32 v%d, s%d, v%d" % (rows[r] + 3, self.S_C01, rows[r]))
+            for r in range(4):
+                e("v_max_f32_e32 v%d, v%d, v%d" % (dst + r, rows[r], rows[r] + 3))
+            if ti + 2 < len(tiles):
+                l0_reads(ti + 2)
+            for (areg2, off2) in stores:
+                self.ds_write(areg2, dst, off2)
+        # bias of hidden layer 0 -> C operands of its first MFMAs
         e("ds_read_b128 %s, v%d" % (self.vr(T4[0]), A["BIAS_A"]))
         e("ds_read_b128 %s, v%d offset:256" % (self.vr(T4[1]), A["BIAS_A"]))
         e("ds_read_b128 %s, v%d offset:512" % (self.vr(T4[2]), A["BIAS_A"]))
@@ -443,6 +474,71 @@ class Gen:
         e("ds_write_b128 v%d, %s" % (A["LO_TILE"], self.vr(self.X)))
         e("ds_write_b128 v%d, %s" % (A["LO_PART"], self.vr(self.ACCR)))
         e("s_waitcnt lgkmcnt(0)")
+        e("s_barrier")
+        self.stamp(12)  # (diagnostic: charged to the last step)
+        # ---- Linear(N, 1): four partial fmaf chains (one per lane group q) over kt, r; fixed combine tree ((p0+p1)+(p2+p3)) + bl.
+        # After the last swap the *_IN names are the buffers the last hidden layer wrote.
+        self.reset_counters()
+        PART, TMP = A["PART"], A["LO_TILE"]
+        e("v_add_u32_e32 v%d, %d, v%d" % (A["LO_PART"], -(self.NT - 1) * 1024 & 0xffffffff, A["FW_IN"]))  # slot 0 of the buffer, this lane
+        HB = "LO_PART"
+        # register quads free here: the accumulators, the bias quads, both B buffers, HO, X, Y
+        Q = [self.ACC[0], self.ACC[1], self.ACC[2], self.ACCR, T4[0], T4[1], T4[2], T4[3], self.B[0], self.B[1], self.HO, self.X, self.Y]
+        NTF = self.NT - 1   # tiles 0 .. NT-2 are activations; tile NT-1 is folded from the partial sums
+        # remainder tile first (its result waits in HO): h = lrelu((p0 + p1) + (p2 + p3)), weights wl[16 (NT-1) + 4 q + r] in TR
+        pr = [Q[8], Q[9], Q[11], Q[12]]
+        idp = [self.ds_read(pr[k], "PL_IN", k * 1024) for k in range(4)]
+        idw12 = self.ds_read(Q[7], "WLA", (self.NT - 1) * 64)
+        grpA = [(Q[0], Q[4]), (Q[1], Q[5]), (Q[2], Q[6])]
+        grpB = [(Q[3], Q[8]), (Q[9], Q[11])]
+        groups = []
+        kt = 0
+        while kt < NTF:
+            g = grpA if len(groups) % 2 == 0 else grpB
+            n = min(len(g), NTF - kt)
+            groups.append([(kt + i, g[i][0], g[i][1]) for i in range(n)])
+            kt += n
+        ids = {}
+
+        def ll_reads(gi):
+            for (k, hreg, wreg) in groups[gi]:
+                ids[(k, "h")] = self.ds_read(hreg, HB, k * 1024)
+                ids[(k, "w")] = self.ds_read(wreg, "WLA", k * 64)
+        ll_reads(0)
+        self.wait_ds(idp[3])
+        for r in range(4):
+            e("v_add_f32_e32 v%d, v%d, v%d" % (pr[0] + r, pr[0] + r, pr[1] + r))
+        for r in range(4):
+            e("v_add_f32_e32 v%d, v%d, v%d" % (pr[2] + r, pr[2] + r, pr[3] + r))
+        for r in range(4):
+            e("v_add_f32_e32 v%d, v%d, v%d" % (pr[0] + r, pr[0] + r, pr[2] + r))
+        self.lrelu_tile(self.HO, pr[0], pr[1])
+        e("v_mov_b32_e32 v%d, 0" % PART)
+        for gi, grp in enumerate(groups):
+            if gi + 1 < len(groups):
+                ll_reads(gi + 1)
+            for (k, hreg, wreg) in grp:
+                self.wait_ds(ids[(k, "w")])
+                for r in range(4):
+                    e("v_fmac_f32_e32 v%d, v%d, v%d" % (PART, wreg + r, hreg + r))
+        self.wait_ds(idw12)
+        for r in range(4):
+            e("v_fmac_f32_e32 v%d, v%d, v%d" % (PART, Q[7] + r, self.HO + r))
+        # pair = part + part[lane ^ 16]; out = (pair + pair[lane ^ 32]) + bl   (swap both copies, add: commutative, same bits)
+        e("v_mov_b32_e32 v%d, v%d" % (TMP, PART))
+        e("s_nop 1")
+        e("v_permlane16_swap_b32_e32 v%d, v%d" % (TMP, PART))
+        e("v_add_f32_e32 v%d, v%d, v%d" % (PART, TMP, PART))
+        e("v_mov_b32_e32 v%d, v%d" % (TMP, PART))
+        e("s_nop 1")
+        e("v_permlane32_swap_b32_e32 v%d, v%d" % (TMP, PART))
+        e("v_add_f32_e32 v%d, v%d, v%d" % (PART, TMP, PART))
+        e("v_add_f32_e32 %%[out], %%[bl], v%d" % PART)
+        # the next evaluation's layer 0 rewrites buffer 0: with an even number of hidden layers that is the buffer just read
+        e("s_bitcmp1_b32 s%d, 0" % self.S_NL)
+        e("s_cbranch_scc1 .Lodd_" + lbl)
+        e("s_barrier")
+        e(".Lodd_" + lbl + ":")
         return self.lines
 
     def bookkeeping(self):
