@@ -117,7 +117,7 @@ def main():
                   [int(x / (nfe0 * MLP_L)) for x in ts], file=sys.stderr)
         print("STAMPS tile 0: %d evaluations, %.0f cycles each" % (nfe0, t[:11].sum() / nfe0), file=sys.stderr)
         names = ["outside-mlp", "layer0", "barriers", "hidden-mfma", "lrelu+store", "last-layer", "rk-stage/err", "interp+emit"]
-        names += ["layer-prologue", "ktile-0", "ktile-last"]
+        names += ["interp-fit", "cursor", "emit-gather"]
         tot = t[:11].sum()
         print("STAMPS (wave 0 of block 0, cycles per evaluation, share):",
               {n: (int(v / nfe0), round(v / tot, 3)) for n, v in zip(names, t[:11])}, file=sys.stderr)

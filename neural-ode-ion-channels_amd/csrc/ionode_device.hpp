@@ -299,9 +299,33 @@ __device__ __forceinline__ double group8_sum_f64(double x) {
   return x;
 }
 
+// Uniform protocol grid, in two halves so that a caller can issue the two sample loads of several lookups back to back:
+// the sample index (false: t outside the protocol), and the interpolation from the two samples.
+__device__ __forceinline__ bool protocol_index(const KArgs &a, double t, int &i);
+__device__ __forceinline__ double protocol_from(const KArgs &a, double v_lo, double v_hi, int i, double t);
+
 // interp1d(t, v) (linear) with the reference's out-of-range rule (train-s1.py:218-229, :234-237).
 // scipy: i = searchsorted(x, t) [left], clipped to [1, n-1]; y = slope*(t - x[i-1]) + y[i-1].
 // Uniform grids find i arithmetically (i = ceil((t - t0)/dt)); explicit grids by bisection.
+__device__ __forceinline__ bool protocol_index(const KArgs &a, double t, int &i) {
+  // branch-free (selects only): several lookups in a row become one block of arithmetic followed by one block of loads; the
+  // index is valid (1 .. n-1) whatever t is, so the sample loads need no guard
+  const int n = a.Np;
+  const double t_last = a.prot_t0 + (double)(n - 1) * a.prot_dt;
+  const bool inr = !(t < a.prot_t0 || t > t_last || t != t);
+  const double u = div_by(t - a.prot_t0, a.prot_dt, a.prot_rdt);
+  double ci = ceil(u);
+  ci = (ci < 1.0) ? 1.0 : ci;
+  ci = (ci > (double)(n - 1)) ? (double)(n - 1) : ci;
+  i = inr ? (int)ci : 1;
+  return inr;
+}
+__device__ __forceinline__ double protocol_from(const KArgs &a, double v_lo, double v_hi, int i, double t) {
+  const double x_lo = a.prot_t0 + (double)(i - 1) * a.prot_dt;
+  const double slope = div_by(v_hi - v_lo, a.prot_dt, a.prot_rdt);
+  return slope * (t - x_lo) + v_lo;
+}
+
 __device__ __forceinline__ bool protocol_v(const KArgs &a, const double *__restrict__ pv, double t, double &v) {
   const int n = a.Np;
   if (a.prot_t != nullptr) {
@@ -317,16 +341,9 @@ __device__ __forceinline__ bool protocol_v(const KArgs &a, const double *__restr
     v = slope * (t - x[i - 1]) + pv[i - 1];
     return true;
   }
-  const double t_last = a.prot_t0 + (double)(n - 1) * a.prot_dt;
-  if (t < a.prot_t0 || t > t_last || t != t) { v = a.v_oob; return false; }
-  const double u = div_by(t - a.prot_t0, a.prot_dt, a.prot_rdt);
-  double ci = ceil(u);
-  if (ci < 1.0) ci = 1.0;
-  if (ci > (double)(n - 1)) ci = (double)(n - 1);
-  const int i = (int)ci;
-  const double x_lo = a.prot_t0 + (double)(i - 1) * a.prot_dt;
-  const double slope = div_by(pv[i] - pv[i - 1], a.prot_dt, a.prot_rdt);
-  v = slope * (t - x_lo) + pv[i - 1];
+  int i;
+  if (!protocol_index(a, t, i)) { v = a.v_oob; return false; }
+  v = protocol_from(a, pv[i - 1], pv[i], i, t);
   return true;
 }
 
@@ -1136,6 +1153,23 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
   bool inst[5];
   auto lookup_stages = [&](double tt, double dd) {
     const S tts = (S)tt, dds = (S)dd, tt1s = (S)(tt + dd);
+    if (MT::MLP && a.prot_t == nullptr) {
+      // uniform protocol grid: five indices, five 16-byte loads back to back, then the interpolations -- ONE memory round
+      // trip per attempt (protocol_v() per stage time waited for each pair of samples in turn: 5 dependent round trips,
+      // ~7 k cycles of the s00 attempt)
+      double tq[5], lo[5], hi[5];
+      int ix[5];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        tq[i] = (double)((i >= 4) ? R::prev_(tt1s) : tts + (S)kAlpha[i] * dds);
+        inst[i] = protocol_index(a, tq[i], ix[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 5; ++i) { lo[i] = pv[ix[i] - 1]; hi[i] = pv[ix[i]]; }
+#pragma unroll
+      for (int i = 0; i < 5; ++i) vst[i] = inst[i] ? protocol_from(a, lo[i], hi[i], ix[i], tq[i]) : a.v_oob;
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
       const S ti = (i >= 4) ? R::prev_(tt1s) : tts + (S)kAlpha[i] * dds;  // alpha == 1: Perturb.PREV (stages 4 and 5)
@@ -1193,6 +1227,7 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
     for (int d = 0; d < D; ++d) k[0][d] = f[d];
     // stage voltages: pure functions of (t0, dt), so all protocol loads are issued ahead of the stages
     if constexpr (!CARRY_V) lookup_stages(t0, dt);
+    STAMP(stamps_, 1);  // slot 1 (asm tile: layer 0 is inside the stream): attempt prologue = stage-voltage lookups
     ClosedRates<MT::MLP ? IONODE_MODEL_HH2 : MODEL> cr;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -1309,6 +1344,7 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
         }
       }
     }
+    STAMP(stamps_, 8);  // slot 8: interpolant fit
     if (a.te_dt > 0.0) {
       // ---- output cursor, lane-parallel: how many requested times fall in (t0, t1] for MY trajectory? ----
       // Guess the last index from the (nearly) uniform output grid, then VERIFY against t_eval itself and walk to the
@@ -1318,7 +1354,7 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
       if (acc_now) {
         const double gf = floor((t1 - a.te_t0) * a.te_rdt);  // a guess: verified below
         long long g = (gf < (double)(oi - 1)) ? (long long)(oi - 1) : ((gf > (double)(Nt - 1)) ? (long long)(Nt - 1) : (long long)gf);
-        if constexpr (CF2 && defer) {
+        if ((CF2 && defer) || (!LW && a.te_exact)) {  // verified uniform output grid: t_k is formed arithmetically, no load
           while (g >= oi && te_at((int)g) > t1) --g;
           while (g + 1 < Nt && te_at((int)g + 1) <= t1) ++g;
         } else {
@@ -1327,6 +1363,7 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
         }
         n_out = (int)(g - oi + 1);
       }
+      STAMP(stamps_, 9);  // slot 9: output cursor
       if constexpr (CF2 && defer) {
         // ---- deferred aligned emission (closed-form, D == 2): whole lines inside 1 KiB-aligned blocks of the row ----
         unsigned long long emd = __ballot(n_out > 0 && lane < TPW);
@@ -1386,6 +1423,91 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
           if (j == jj) ow = E;
         }
         oi += n_out;
+      } else if constexpr (!LW && G > 1) {
+      // ---- MLP tile kernels: the owner wavefront emits its NS = TPW / G trajectories.  Everything that has to come from
+      // memory for the first 64-sample chunk of ALL of them -- output times (unless the grid is verified uniform: arithmetic),
+      // the two protocol samples per output time of the observation model -- is issued before anything is evaluated: one
+      // round trip per accepted step instead of two dependent ones per emitting trajectory.  Samples beyond the first chunk
+      // (steps spanning more than 64 outputs) take the plain loop.
+      constexpr int NS = TPW / G;
+      const bool exact = a.te_exact != 0;
+      const bool want_i = (a.i_out != nullptr) || (a.sse_out != nullptr);
+      const bool ugrid = a.prot_t == nullptr;
+      int o_[NS], n_[NS], ip_[NS];
+      double tk_[NS], plo_[NS], phi_[NS];
+      bool inr_[NS];
+      const double *pv_[NS];
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        const int jj = wave + G * k;
+        o_[k] = __builtin_amdgcn_readlane(oi, jj);
+        n_[k] = __builtin_amdgcn_readlane(n_out, jj);
+        pv_[k] = a.prot_v + (size_t)__builtin_amdgcn_readlane(pidx, jj) * a.Np;
+        tk_[k] = 0.0;
+        if (lane < n_[k]) tk_[k] = exact ? te_at(o_[k] + lane) : a.t_eval[o_[k] + lane];
+      }
+      if (want_i && ugrid) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+          inr_[k] = protocol_index(a, tk_[k], ip_[k]);  // (idle lanes: t = 0, a valid index; their loads are harmless)
+          plo_[k] = pv_[k][ip_[k] - 1]; phi_[k] = pv_[k][ip_[k]];
+        }
+      }
+      STAMP(stamps_, 10);  // slot 10: emission, gather phase
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        const int jj = wave + G * k;
+        const int n = n_[k], o = o_[k];
+        if (n > 0) {
+          const double t0b = bcast_f64(t0, jj), denb = bcast_f64(den, jj), rdenb = bcast_f64(rden, jj);
+          S cb[5][D];
+#pragma unroll
+          for (int c = 0; c < 5; ++c)
+#pragma unroll
+            for (int d = 0; d < D; ++d) cb[c][d] = bcast<S>(ic[c][d], jj);
+          const int tr = __builtin_amdgcn_readlane(traj, jj);
+          S *__restrict__ yo = a.y_out ? reinterpret_cast<S *>(a.y_out) + (size_t)tr * Nt * D : nullptr;
+          double *__restrict__ io = a.i_out ? a.i_out + (size_t)tr * Nt : nullptr;
+          const double *__restrict__ refb = a.sse_out ? a.sse_ref + (size_t)__builtin_amdgcn_readlane(pidx, jj) * Nt : nullptr;
+          double sacc = 0.0;
+          for (int c0 = 0; c0 < n; c0 += 64) {
+            const int idx = o + c0 + lane;
+            double tk = tk_[k];
+            if (c0 > 0 && c0 + lane < n) tk = exact ? te_at(idx) : a.t_eval[idx];
+            if (c0 + lane < n) {
+              const S x = (S)div_by(tk - t0b, denb, rdenb);  // _interp_evaluate: x = (t - t0) / (t1 - t0) in fp64, cast; running powers
+              S out[D];
+              S xp = x;
+#pragma unroll
+              for (int d = 0; d < D; ++d) out[d] = cb[0][d] + x * cb[1][d];
+#pragma unroll
+              for (int c = 2; c < 5; ++c) {
+                xp = xp * x;
+#pragma unroll
+                for (int d = 0; d < D; ++d) out[d] = out[d] + xp * cb[c][d];
+              }
+              if (yo) store_state<S, D>(yo + (size_t)idx * D, out);
+              if (want_i) {
+                double vk;
+                if (c0 == 0 && ugrid) vk = inr_[k] ? protocol_from(a, plo_[k], phi_[k], ip_[k], tk) : a.v_oob;
+                else protocol_v(a, pv_[k], tk, vk);
+                S gate;
+                if (a.obs_open) gate = out[D - 1]; else gate = out[0] * out[1];
+                if (a.obs_g != 1.0) gate = (S)a.obs_g * gate;
+                const double ik = (double)gate * (vk - a.obs_e);
+                if (io) io[idx] = ik;
+                if (refb) { const double rr = ik - refb[idx]; sacc += rr * rr; }
+              }
+            }
+          }
+          if (a.sse_out) {  // fused objective: the step's squared residuals of trajectory jj
+#pragma unroll
+            for (int msk = 32; msk >= 1; msk >>= 1) sacc += __shfl_xor(sacc, msk);
+            if (j == jj) sse += sacc;
+          }
+        }
+      }
+      oi += n_out;
       } else {
       // ---- owner wavefront evaluates and stores; the t_eval loads of the next trajectory are issued ahead ----
       unsigned long long em = __ballot(n_out > 0 && lane < TPW);
