@@ -84,7 +84,11 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false) {
     }
     // N <= 16 (architectures s03-s05): from IONODE_TINY64_FROM trajectories on, one trajectory per lane (64 per wavefront, four
     // MFMA column tiles per evaluation) instead of 16 per wavefront with the scalar integrator work replicated over 4 lane groups
-    const bool t64 = NT == 1 && (d->tile_waves == 64 || (d->tile_waves == 0 && d->n_traj >= IONODE_TINY64_FROM));
+    // (several weight images: the automatic choice takes the 64-per-wavefront kernel only when an image's trajectories fill whole
+    // 64-lane tiles -- a population of nets padded to 16 / 32 / 48 trajectories per candidate stays on the 16-per-wavefront kernel;
+    // an explicit tile_waves = 64 with such a population is still an argument error, below)
+    const bool img64 = d->traj_per_image <= 0 || d->traj_per_image % 64 == 0;
+    const bool t64 = NT == 1 && (d->tile_waves == 64 || (d->tile_waves == 0 && d->n_traj >= IONODE_TINY64_FROM && img64));
     // (deferred aligned emission as for the 2-state closed-form kernels: verified uniform output grid, no current / objective)
     const int t64defer = (t64 && d->t_eval_exact && d->t_eval_dt_hint > 0.0 && d->n_out > 1 && !want_current) ? 1 : 0;
     pl->v = t64 ? find_variant(d->model, f32, 1, NT, 64, t64defer) : find_variant(d->model, f32, d->tile_waves, NT, NT == 1 ? 1 : -1);

@@ -27,6 +27,31 @@ from . import capi
 _image_cache = {}
 DEFAULT_CKPT_CAP = 4096
 DEFAULT_RECORD_BUDGET = 24 << 30
+DEFAULT_CKPT_BUDGET = 96 << 30   # bytes of accepted-step checkpoints one forward may allocate (a third of the 288 GB of HBM3E)
+
+
+def stable_step_cap(model, params, prot_v, v_oob=-80.0, safety=3.0):
+    """Largest dt (ms) that keeps dopri5 inside its real-axis stability interval (|h lambda| < ~3.3) for every trajectory
+    of the batch: safety / lambda_max, lambda_max = the largest relaxation rate of the gating equations at the protocol's
+    extreme voltages (the rates p exp(+-q v) are monotone in v, so the maximum sits at an end of the voltage range).
+    2-state models: lambda = k_open + k_close of the a and r gates (train-s1.py:161-177); 6-state model: Gershgorin bound
+    2 x (sum of the six rates) (train-d1.py:165-187).  This is what `max_step="auto"` passes to the solve."""
+    p = params.detach().to(torch.float64)
+    v = torch.stack([prot_v.min().to(torch.float64), prot_v.max().to(torch.float64),
+                     torch.as_tensor(float(v_oob), dtype=torch.float64, device=prot_v.device)]).to(p.device)
+    n = 6 if model == capi.MODEL_MARKOV6 else 4
+    sign = torch.tensor([1.0 if i % 2 == 0 else -1.0 for i in range(n)], dtype=torch.float64, device=p.device)
+    amp, exp = p[:, 0:2 * n:2], p[:, 1:2 * n:2] * sign            # [B, n]
+    rates = amp[:, :, None] * torch.exp(exp[:, :, None] * v[None, None, :])   # [B, n, 3]
+    if model == capi.MODEL_MARKOV6:
+        lam = 2.0 * rates.abs().sum(1)
+    else:
+        pairs = rates.abs().reshape(p.shape[0], n // 2, 2, 3).sum(2)          # (k1 + k2), (k3 + k4)
+        if model == capi.MODEL_NNF:
+            pairs = pairs[:, 1:]                                              # the a gate is the MLP: only the r gate is stiff
+        lam = pairs.amax(1)
+    lam_max = float(lam.max().item())
+    return safety / lam_max if lam_max > 0 and np.isfinite(lam_max) else 0.0
 
 
 def grad_image(weights_flat, L, N, dev, key=None):
@@ -94,11 +119,19 @@ class _Solve(torch.autograd.Function):
                             max_steps=cfg["max_steps"], max_total_steps=cfg["max_total_steps"], max_step=cfg.get("max_step", 0.0), ckpt=ckpt,
                             tile_waves=cfg.get("tile_waves", 0),
                             t_eval_hint=cfg.get("t_eval_hint", "auto"))
-            nacc = r["stats"][:, 0]
+            # the checkpoint buffer is sized for the trajectories that SUCCEEDED: a failed one (status != 0: step budget spent,
+            # dt underflow) can have 10^5..10^6 accepted steps, contributes no gradient (its n_acc is zeroed in backward) and
+            # must not grow a [B, cap, 4 + 8 D] buffer to hundreds of GB
+            nacc = torch.where(r["status"] == 0, r["stats"][:, 0], torch.zeros_like(r["stats"][:, 0]))
             most = int(nacc.max().item())
             if most <= cap:
                 break
             cap = 1 << int(np.ceil(np.log2(most + 1)))  # the buffer was too small: run the forward again with room
+            need = B * cap * (4 + 8 * y0.shape[1]) * 8
+            limit = int(cfg.get("ckpt_budget_bytes") or DEFAULT_CKPT_BUDGET)
+            if need > limit:
+                raise capi.IonodeError(f"checkpoints of {most} accepted steps x {B} trajectories need {need / 2**30:.1f} GiB "
+                                       f"(> ckpt_budget_bytes = {limit / 2**30:.1f} GiB): split the batch or raise the budget")
         ctx.cfg, ctx.desc = cfg, r["desc"]
         ctx.w_np = w_np
         ctx.save_for_backward(params.detach(), ckpt, r["stats"], r["status"])
@@ -116,7 +149,10 @@ class _Solve(torch.autograd.Function):
         need_w = ctx.needs_input_grad[0] and ctx.w_np is not None
         lib = capi.lib()
         sdt = torch.float32 if desc.state_f32 else torch.float64
-        gy = gy.to(sdt).contiguous()
+        # failed trajectories (status != 0): their rows of y are NaN-filled and carry no gradient -- zero upstream rows (a caller's
+        # unmasked loss would otherwise feed NaN into the sweep) and, below, zero dL/dy0 / dL/dp rows
+        failed = status != 0
+        gy = torch.where(failed[:, None, None], torch.zeros((), dtype=gy.dtype, device=gy.device), gy).to(sdt).contiguous()
         n_acc = torch.where(status == 0, stats[:, 0], torch.zeros_like(stats[:, 0])).to(torch.int32).contiguous()
         n_iter = int(n_acc.max().item()) + 1
         image = grad_image(ctx.w_np, L, N, dev, key=cfg.get("weights_key")) if ctx.w_np is not None else None
@@ -170,19 +206,26 @@ class _Solve(torch.autograd.Function):
                 free[k % n_buf] = done
         if need_w and side is not main:
             main.wait_stream(side)
+        g_params[failed] = 0.0
+        g_y0[failed] = 0.0
         g_w = unpack_partial(acc, L, N).to(torch.float32) if need_w else None
         return g_w, (g_params if ctx.needs_input_grad[1] else None), (g_y0.to(sdt) if ctx.needs_input_grad[2] else None), None
 
 
 def solve(model, weights_flat, params, prot_v, y0, t_eval, *, mlp_layers=0, mlp_width=0, prot_t=None, prot_t0=0.0,
           prot_dt=1.0, prot_of_traj=None, rtol=1e-7, atol=1e-9, v_oob=-80.0, max_steps=0, max_total_steps=0, max_step=0.0,
-          ckpt_cap=None, record_budget_bytes=None, weights_key=None, t_eval_hint="auto", order=None, tile_waves=0):
+          ckpt_cap=None, record_budget_bytes=None, weights_key=None, t_eval_hint="auto", order=None, tile_waves=0,
+          ckpt_budget_bytes=None):
     """Differentiable batched solve.  weights_flat [n] fp32 (reference state-dict order; None for the closed-form HH 2-state
     and 6-state models, whose params are [B, 8] / [B, 12] and y0 [B, 2] / [B, 6]), params [B, 8] fp64, y0 [B, 2]
     fp32 | fp64 (the state dtype) -- device tensors, any of which may require grad; prot_v [P, Np], t_eval [Nt] fp64 device
-    tensors.  Returns (y [B, Nt, 2], status [B]): gradients of failed trajectories (status != 0) are zero.
+    tensors.  Returns (y [B, Nt, 2], status [B]): gradients of failed trajectories (status != 0) are zero -- their rows of the
+    upstream gradient are ignored (y is NaN-filled there), and dL/dy0, dL/dp rows are zero whether or not the caller masks its loss.
+    A failed trajectory never grows the checkpoint buffer; a batch whose successful trajectories need more than
+    ckpt_budget_bytes (default 96 GiB) of checkpoints raises IonodeError instead of running out of memory.
 
-    max_step (ms, extension; 0 = off = the reference's dopri5): at an equilibrium dopri5 lets dt grow until h*lambda is far
+    max_step (ms | "auto", extension; 0 = off = the reference's dopri5; "auto" = stable_step_cap(); a RuntimeWarning is issued
+    when params requires grad and no cap is set): at an equilibrium dopri5 lets dt grow until h*lambda is far
     outside its stability region (the error estimate of a state AT equilibrium is ~0); the forward solve copes through
     rejections, but the exact derivative of those accepted-but-unstable steps multiplies the adjoint by |R(h*lambda)| >> 1
     per step (measured on the 10 s sine-wave protocol, fp32 state: |dL/dp| ~ 1e36 while dL/dW, whose state `a` is not
@@ -192,6 +235,16 @@ def solve(model, weights_flat, params, prot_v, y0, t_eval, *, mlp_layers=0, mlp_
     tiles, expensive tiles first -- pays from two tiles per compute unit, B > 4096); y and status are then in LAUNCH order
     (row k = trajectory order[k]), and the gradients still arrive at params / y0 in the caller's order (the gather is part of
     the autograd graph)."""
+    if isinstance(max_step, str):
+        if max_step != "auto":
+            raise capi.IonodeError("max_step must be a number (ms) or 'auto'")
+        max_step = stable_step_cap(model, params, prot_v, v_oob)
+    elif float(max_step) == 0.0 and isinstance(params, torch.Tensor) and params.requires_grad:
+        import warnings
+        warnings.warn("gradients w.r.t. the rate parameters through an UNCAPPED dopri5 solve: at equilibria dopri5 accepts steps with "
+                      "h*lambda >> 1 whose exact derivative amplifies rounding noise without bound (|dL/dp| ~ 1e36 on long holds, "
+                      "DESIGN.md 5.4).  Pass max_step='auto' (= 3 / lambda_max of the rate constants, grad.stable_step_cap) or a "
+                      "value in ms; the forward values then follow the capped step sequence.", RuntimeWarning, stacklevel=2)
     if model in (capi.MODEL_HH2, capi.MODEL_MARKOV6):
         # closed-form models (train-s1.py:161-177, train-d1.py:165-187): gradients w.r.t. the rate parameters and y0; no weights
         if weights_flat is not None:
@@ -214,7 +267,7 @@ def solve(model, weights_flat, params, prot_v, y0, t_eval, *, mlp_layers=0, mlp_
                prot_t0=float(prot_t0), prot_dt=float(prot_dt), prot_of_traj=prot_of_traj, t_eval=t_eval, rtol=float(rtol),
                atol=float(atol), v_oob=float(v_oob), max_steps=int(max_steps), max_total_steps=int(max_total_steps),
                max_step=float(max_step), ckpt_cap=ckpt_cap, record_budget_bytes=record_budget_bytes, weights_key=weights_key, t_eval_hint=t_eval_hint,
-               tile_waves=int(tile_waves))
+               tile_waves=int(tile_waves), ckpt_budget_bytes=ckpt_budget_bytes)
     return _Solve.apply(weights_flat, params, y0.contiguous(), cfg)
 
 

@@ -40,6 +40,8 @@ def population_sum_of_squares(candidates, protocols_v, data_i, t_eval, *, base_p
     C, P = cand.shape[0], np.asarray(protocols_v).shape[0]
     on = dist.is_available() and dist.is_initialized()
     rank, world = (dist.get_rank(group), dist.get_world_size(group)) if on else (0, 1)
+    if cost is not None and len(cost) != C:
+        raise capi.IonodeError(f"cost has {len(cost)} entries for {C} candidates: the shards would not cover the population")
     bounds = [distributed.shard_bounds(C, r, world) for r in range(world)] if cost is None \
         else distributed.shard_bounds_by_cost(cost, world)
     lo, hi = bounds[rank]

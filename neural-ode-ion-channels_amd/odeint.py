@@ -63,6 +63,10 @@ def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, even
     if torch.is_grad_enabled() and _wants_grad(func, y0):
         return _odeint_with_grad(func, y0, t, spec, rtol, atol, options)
 
+    max_step = options.get("max_step", 0.0)
+    if isinstance(max_step, str):  # "auto": the same cap the differentiable call would use (grad.stable_step_cap)
+        max_step = grad.stable_step_cap(spec.model, torch.from_numpy(np.asarray(spec.params, dtype=np.float64)[None, :]),
+                                        torch.from_numpy(np.asarray(spec.prot_v, dtype=np.float64)))
     t64 = t.detach().to(torch.float64)
     t_key = ("t", rhs.digest(t64.cpu().numpy()))  # the output grid stays device-resident while its values do not change
     sol = batched.solve(spec.model, spec.params, spec.prot_v, y0.reshape(1, -1), t64,
@@ -70,7 +74,7 @@ def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, even
                         weights_key=spec.weights_key, prot_t=spec.prot_t, prot_t0=spec.prot_t0, prot_dt=spec.prot_dt,
                         state_dtype=y0.dtype, rtol=float(rtol), atol=float(atol),
                         max_steps=int(options.get("max_num_steps", 0)),
-                        max_total_steps=int(options.get("max_total_steps", 0)), max_step=float(options.get("max_step", 0.0)),
+                        max_total_steps=int(options.get("max_total_steps", 0)), max_step=float(max_step),
                         prot_key=spec.prot_key, t_eval_key=t_key,
                         tile_waves=int(options.get("tile_waves", 0)))
     sol.raise_on_failure()
@@ -113,7 +117,7 @@ def _odeint_with_grad(func, y0, t, spec, rtol, atol, options):
                            prot_t=batched._to(spec.prot_t, torch.float64, dev, key=(spec.prot_key, "t")),
                            prot_t0=spec.prot_t0, prot_dt=spec.prot_dt, rtol=float(rtol), atol=float(atol),
                            max_steps=int(options.get("max_num_steps", 0)), max_total_steps=int(options.get("max_total_steps", 0)),
-                           max_step=float(options.get("max_step", 0.0)), weights_key=spec.weights_key)
+                           max_step=options.get("max_step", 0.0), weights_key=spec.weights_key)
     st = int(status[0].item())
     if st != 0:
         raise AssertionError(capi.STATUS_TEXT[st])

@@ -103,11 +103,16 @@ def state_dict_to_flat(state_dict, prefix="net."):
     return np.concatenate(parts), len(keys) - 2, int(first.shape[0])
 
 
-def save_checkpoint(path, epoch, flat, mlp_layers, mlp_width, optimizer_state=None, loss=None):
-    """Write a checkpoint the reference's `load_ckp` reads: torch.save({'epoch', 'state_dict', 'optimizer', 'loss'})."""
+def save_checkpoint(path, epoch, flat, mlp_layers, mlp_width, optimizer_state=None, loss=None, lr=1e-3):
+    """Write a checkpoint the reference's `load_ckp` reads: torch.save({'epoch', 'state_dict', 'optimizer', 'loss'}).
+    `load_ckp` calls optimizer.load_state_dict(checkpoint['optimizer']) unconditionally (train-r1.py:68-72), so without an
+    optimizer_state (e.g. adam_state_from_regression(reg)) the checkpoint carries the state dict of a FRESH Adam over the net's
+    2 (L + 2) tensors (no moments yet, learning rate `lr`) -- loadable by a real torch.optim.Adam, never an empty dict."""
     import torch
-    torch.save({"epoch": int(epoch), "state_dict": flat_to_state_dict(flat, mlp_layers, mlp_width),
-                "optimizer": optimizer_state if optimizer_state is not None else {}, "loss": loss}, path)
+    sd = flat_to_state_dict(flat, mlp_layers, mlp_width)
+    if optimizer_state is None:
+        optimizer_state = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1)) for _ in sd], lr=float(lr)).state_dict()
+    torch.save({"epoch": int(epoch), "state_dict": sd, "optimizer": optimizer_state, "loss": loss}, path)
 
 
 def load_checkpoint(path):

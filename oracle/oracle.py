@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "liboracle.so")
+# IONODE_ORACLE_LIB: the sanitizer build of tests/test_oracle_sanitizers.py (oracle/Makefile target `asan`)
+_LIB = os.environ.get("IONODE_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")
 
 MODEL_HH2, MODEL_MARKOV6, MODEL_NNF, MODEL_NND = 0, 1, 2, 3
 STATUS_OK, STATUS_DT_UNDERFLOW, STATUS_NONFINITE, STATUS_MAX_STEPS = 0, 1, 2, 3

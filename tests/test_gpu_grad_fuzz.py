@@ -22,7 +22,10 @@ def _rel(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
 
 
-@pytest.mark.parametrize("seed", [0, 1, 2, 3, 9, 11, 13, 19])
+# A contiguous seed range, no curation (round-2 review): every seed of range(20) runs; a case may skip itself only for the two
+# reasons written in the body (a single output time, every trajectory failing).  The round-3 log of all twenty, with per-seed
+# agreement and durations, is profiles/r03_grad_fuzz.log.
+@pytest.mark.parametrize("seed", list(range(20)))
 def test_random_gradients_match_the_checker(ion, gpu, oracle, seed):
     model, f32, params, pv, y0, te, kw, mlp, obs, rng = _case(seed)
     B = min(params.shape[0], 6 if (f32 and mlp) else 17)   # (the capped fp32 replays of an MLP are the slow ones on the CPU)

@@ -1,0 +1,187 @@
+"""-m gpu: round-3 additions -- the review's hygiene items and the advisor's edge cases.
+
+* BASELINE configs[3] at one GPU's full share over ALL THREE protocol families (8192 candidates x (7 Pr3 + 16 Pr4 + 9 Pr5) sweeps),
+  through planted / repeated / NaN candidates (size-independent properties) and three candidates against the oracle.
+* gradient path: a failing trajectory inside a batch neither grows the checkpoint buffer nor leaks NaN into the gradients of an
+  UNMASKED loss; the checkpoint budget raises instead of exhausting memory; an uncapped rate-parameter gradient warns and
+  max_step="auto" (grad.stable_step_cap) keeps it finite on a long hold in fp32 state.
+* a large population of N <= 16 nets (16 trajectories per candidate) dispatches to a kernel that accepts it.
+* the asm evaluation stream of the N = 200 tile: every depth L = 1 .. 6 (odd / even: the barrier behind Linear(N, 1)), ragged tiles.
+"""
+import importlib
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import kat_cases as K
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config4_share_over_all_three_protocol_families(ion, gpu, oracle):
+    """8192 candidates x 32 sweeps (Pr3 activation train-s1.py:69-80, synthetic Pr4, Pr5 deactivation :83-95) = 262 144 solves,
+    fused sum of squares.  The data are the GPU's own traces of the true parameters: the planted candidates score exactly 0 in
+    every family, repeated candidates repeat, a NaN candidate is inf, three random candidates equal the oracle sweep by sweep."""
+    P = ion.protocols
+    obj = importlib.import_module("neural-ode-ion-channels_amd.objective")
+    fams = {"pr3": np.stack([P.activation_pr3(v) for v in P.PR3_STEPS]),
+            "pr4": np.stack([P.pr4_synthetic(k) for k in range(16)]),
+            "pr5": np.stack([P.deactivation_pr5(v) for v in P.PR5_STEPS])}
+    rng = np.random.default_rng(11)
+    C = 8192
+    cand = np.array([1.13e-4, 7.45e-2, 3.60e-5, 4.49e-2]) * np.exp(rng.normal(0.0, 0.1, (C, 4)))   # CMA-ES first generation, train-d0.py:325-328
+    planted = [0, 4097, C - 1]
+    cand[planted] = K.P_NN_D[:4]
+    cand[100:200] = cand[300:400]
+    cand[77] = np.nan
+    total = np.zeros(C)
+    for name, pv in fams.items():
+        S, Np = pv.shape
+        te = np.arange(Np) * 0.1
+        data = ion.solve(K.MODEL_HH2, np.tile(K.P_NN_D, (S, 1)), pv, torch.tensor([[0.0, 1.0]]), te, prot_t0=0.0, prot_dt=0.1,
+                         current=True).i.cpu().numpy()
+        got = obj.population_sum_of_squares(cand, pv, data, te, base_params=K.P_NN_D, prot_t0=0.0, prot_dt=0.1,
+                                            max_total_steps=200000).cpu().numpy()
+        assert got.shape == (C,) and np.isinf(got[77]) and (got[planted] == 0.0).all(), name
+        fin = np.isfinite(got)
+        assert fin.sum() >= C - 1 and (got[fin] >= 0).all() and np.array_equal(got[100:200], got[300:400]), name
+        for c in (5, 2500, 8000):
+            p = K.P_NN_D.copy()
+            p[:4] = cand[c]
+            o = oracle.solve(K.MODEL_HH2, np.tile(p, (S, 1)), pv, [0.0, 1.0], te, prot_t0=0.0, prot_dt=0.1, state_f32=True,
+                             prot_of_traj=np.arange(S, dtype=np.int32), max_total_steps=200000, nthreads=4)
+            assert (o["status"] == 0).all()
+            sim = np.stack([oracle.current(o["y"][k], oracle.protocol_v(pv[k], te, prot_t0=0.0, prot_dt=0.1)[0], state_f32=True)
+                            for k in range(S)])
+            want = ((sim - data) ** 2).sum()
+            assert abs(got[c] - want) <= 1e-12 * max(want, 1e-300), (name, c)
+        total += got
+    assert (total[planted] == 0.0).all() and np.isinf(total[77]) and total[np.isfinite(total)].min() == 0.0
+
+
+def _hh_batch(gpu, B, f32=False, n_prot=2001):
+    pv = np.full((1, n_prot), -80.0)
+    pv[0, 200:1200] = 20.0
+    te = np.arange(0, n_prot - 1, 10.0)
+    params = np.tile(K.P_HH, (B, 1)) * np.random.default_rng(3).uniform(0.9, 1.1, (B, 8))
+    sdt = torch.float32 if f32 else torch.float64
+    return (torch.from_numpy(params).to(gpu), torch.from_numpy(pv).to(gpu),
+            torch.tensor([[0.0, 1.0]], dtype=sdt, device=gpu).repeat(B, 1).contiguous(), torch.from_numpy(te).to(gpu))
+
+
+def test_failed_trajectory_inside_a_gradient_batch(ion, gpu):
+    """one trajectory fails (too stiff for the explicit solver: step budget / dt underflow).  Its row must not size the checkpoint buffer, its y is
+    NaN-filled, and with an UNMASKED loss the other rows' gradients stay finite while its own are exactly zero."""
+    B = 20
+    params, pv, y0, te = _hh_batch(gpu, B)
+    stiff = params.clone()
+    stiff[7, 4:8] *= 3e3                       # the r gate of trajectory 7 becomes far too stiff for an explicit solver
+    p = stiff.requires_grad_(True)
+    y0 = y0.requires_grad_(True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        y, status = ion.grad.solve(K.MODEL_HH2, None, p, pv, y0, te, prot_t0=0.0, prot_dt=1.0, max_total_steps=3000, ckpt_cap=256)
+    st = status.cpu().numpy()
+    assert st[7] != 0 and (np.delete(st, 7) == 0).all()   # (step budget or dt underflow, whichever the stiff gate hits first)
+    assert torch.isnan(y[7, -1]).all()
+    torch.nan_to_num(y).sum().backward()       # unmasked: the upstream gradient of row 7 is 1 everywhere
+    gp, gy0 = p.grad.cpu().numpy(), y0.grad.cpu().numpy()
+    assert np.isfinite(gp).all() and np.isfinite(gy0).all()
+    assert (gp[7] == 0).all() and (gy0[7] == 0).all() and np.abs(np.delete(gp, 7, 0)).sum() > 0
+    # a clean batch of the other 19 gives the same gradients: the failing row did not disturb its tile-mates
+    keep = [i for i in range(B) if i != 7]
+    p2 = stiff.detach()[keep].clone().requires_grad_(True)
+    y2 = y0.detach()[keep].clone().requires_grad_(True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        yb, sb = ion.grad.solve(K.MODEL_HH2, None, p2, pv, y2, te, prot_t0=0.0, prot_dt=1.0, max_total_steps=3000, ckpt_cap=256)
+    yb.sum().backward()
+    assert torch.equal(yb, y[keep]) and np.array_equal(p2.grad.cpu().numpy(), gp[keep]) and np.array_equal(y2.grad.cpu().numpy(), gy0[keep])
+
+
+def test_checkpoint_budget_raises_instead_of_allocating(ion, gpu):
+    params, pv, y0, te = _hh_batch(gpu, 4)
+    with pytest.raises(ion.capi.IonodeError, match="ckpt_budget_bytes"):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            ion.grad.solve(K.MODEL_HH2, None, params.requires_grad_(True), pv, y0, te, prot_t0=0.0, prot_dt=1.0, ckpt_cap=2,
+                           ckpt_budget_bytes=1 << 10)
+
+
+def test_uncapped_rate_gradient_warns_and_auto_cap_keeps_it_finite(ion, gpu):
+    """in fp32 state the exact derivative of accepted-but-unstable steps on a long hold explodes (|dL/dp| up to
+    1e36).  The default call warns; max_step='auto' (3 / lambda_max of the rate constants) returns a bounded gradient that
+    agrees with an fp64-state solve of the same capped problem."""
+    B = 4
+    params, _, y0, _ = _hh_batch(gpu, B, f32=True)
+    pv = np.full((1, 100001), -80.0)
+    pv[0, 5000:15000] = 40.0                   # 10 s protocol: 1 s at +40 mV, then a 8.5 s hold at -80 mV
+    pv = torch.from_numpy(pv).to(gpu)
+    te = torch.arange(0, 10000.0, 50.0, dtype=torch.float64, device=gpu)
+    p = params.clone().requires_grad_(True)
+    with pytest.warns(RuntimeWarning, match="UNCAPPED"):
+        ion.grad.solve(K.MODEL_HH2, None, p, pv, y0, te, prot_t0=0.0, prot_dt=0.1)
+    cap = ion.grad.stable_step_cap(K.MODEL_HH2, params, pv)
+    assert 1.0 < cap < 40.0
+    grads = {}
+    for f32 in (True, False):
+        p = params.clone().requires_grad_(True)
+        with warnings.catch_warnings():
+            warnings.simplefilter("error", RuntimeWarning)   # 'auto' must not warn
+            y, status = ion.grad.solve(K.MODEL_HH2, None, p, pv, y0.to(torch.float32 if f32 else torch.float64), te, prot_t0=0.0,
+                                       prot_dt=0.1, max_step="auto")
+        assert bool((status == 0).all())
+        (y.double()[:, :, 0] * y.double()[:, :, 1]).sum().backward()
+        grads[f32] = p.grad.cpu().numpy()
+        assert np.isfinite(grads[f32]).all() and np.abs(grads[f32]).max() < 1e6
+    rel = np.linalg.norm(grads[True] - grads[False]) / np.linalg.norm(grads[False])
+    assert rel < 1e-2, rel
+
+
+def test_large_population_of_tiny_nets_dispatches(ion, gpu, oracle):
+    """C x 16 >= 73 728 trajectories with one N = 10 net per candidate (weights [C, n], traj_per_image = 16) used to
+    pick the 64-per-wavefront kernel and fail with IONODE_ERR_ARG; it now runs on the 16-per-wavefront kernel."""
+    P = ion.protocols
+    obj = importlib.import_module("neural-ode-ion-channels_amd.objective")
+    pv = np.stack([P.deactivation_pr5(v)[:2001] for v in P.PR5_STEPS])
+    S, Np = pv.shape
+    te = np.arange(0, Np, 4) * 0.1
+    C, L, N = 4700, 1, 10
+    rng = np.random.default_rng(2)
+    n = 2 * N + N + L * (N * N + N) + N + 1
+    w = rng.normal(0, 0.1, (C, n)).astype(np.float32)
+    w[1] = w[0]
+    data = np.zeros((S, te.size))
+    got = obj.population_sum_of_squares(np.zeros((C, 0)), pv, data, te, base_params=K.P_HH, free=(), prot_t0=0.0, prot_dt=0.1,
+                                        model=K.MODEL_NNF, weights=w, mlp_layers=L, mlp_width=N, state_dtype=torch.float64).cpu().numpy()
+    assert got.shape == (C,) and np.isfinite(got).all() and got[0] == got[1]
+    for c in (0, C - 1):
+        o = oracle.solve(K.MODEL_NNF, np.tile(K.P_HH, (S, 1)), pv, [0.0, 1.0], te, prot_t0=0.0, prot_dt=0.1, weights=w[c],
+                         mlp_layers=L, mlp_width=N, prot_of_traj=np.arange(S, dtype=np.int32))
+        sim = np.stack([oracle.current(o["y"][k], oracle.protocol_v(pv[k], te, prot_t0=0.0, prot_dt=0.1)[0]) for k in range(S)])
+        want = (sim ** 2).sum()
+        assert abs(got[c] - want) <= 1e-10 * want
+
+
+@pytest.mark.parametrize("L", [1, 2, 3, 4, 6])
+@pytest.mark.parametrize("f32", [False, True])
+def test_asm_stream_every_depth(ion, gpu, oracle, L, f32):
+    """The N = 200 tile's evaluation is one asm statement looping over the hidden layers (tools/gen_mlp_asm.py): odd and even depths
+    (weight-ring wrap to layer 0, the barrier behind Linear(N, 1) for even L), ragged tile (B = 21), NN-f and NN-d."""
+    N, B = 200, 21
+    rng = np.random.default_rng(100 + L)
+    n = 2 * N + N + L * (N * N + N) + N + 1
+    w = (rng.normal(0, 0.08, n)).astype(np.float32)
+    pv = np.stack([K.activation(v)[1][:1501] for v in (-20, 40)])
+    te = np.arange(0, 1500, 3.0)
+    params = np.tile(K.P_HH, (B, 1)) * rng.uniform(0.9, 1.1, (B, 8))
+    pot = (np.arange(B) % 2).astype(np.int32)
+    for model in (K.MODEL_NNF, K.MODEL_NND):
+        g = ion.solve(model, params, pv, torch.tensor([[0.0, 1.0]], dtype=torch.float32 if f32 else torch.float64), te,
+                      weights=w, mlp_layers=L, mlp_width=N, prot_t0=0.0, prot_dt=1.0, prot_of_traj=pot, current=True)
+        o = oracle.solve(model, params, pv, [0.0, 1.0], te, weights=w, mlp_layers=L, mlp_width=N, prot_t0=0.0, prot_dt=1.0,
+                         prot_of_traj=pot, state_f32=f32, nthreads=8)
+        assert np.array_equal(g.status.cpu().numpy(), o["status"]) and np.array_equal(g.stats.cpu().numpy(), o["stats"])
+        assert np.array_equal(g.y.double().cpu().numpy(), o["y"], equal_nan=True)
