@@ -204,18 +204,29 @@ def main():
                          "frac": gbs / PEAK_HBM_GBS, "bytes_per_trajectory": bytes_traj},
     }
 
-    pmc = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+    # which collective library and how many ranks it reports (a SCALE record can be checked from the line itself)
+    res["config"]["dist_backend"] = dist.get_backend() if dist is not None else None
+    res["config"]["dist_world_size"] = dist.get_world_size() if dist is not None else 1
+    lib_sha = capi.library_digest()
+    res["config"]["libionode_sha256"] = lib_sha[:16]
+    pmc = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
     if os.path.exists(pmc) and B == 4096 and Nt == 100001:
         # HBM bytes per launch from the rocprofv3 --pmc passes of this same command (profiles/README.md): FETCH_SIZE is
-        # doubled (gfx950 counts 128-B requests as 64 B), WRITE_SIZE is exact; both are reported in KiB
+        # doubled (gfx950 counts 128-B requests as 64 B), WRITE_SIZE is exact; both are reported in KiB.  The counters belong
+        # to ONE build of the library: the summary records its digest, and a different library in this process means the
+        # byte count is stale -- reported as such, never silently carried over.
         try:
             pj = json.load(open(pmc))
             kname = "void ionode::" + r["kernel"] + "(ionode::KArgs)"
             traffic = (2 * pj["pmc2"][kname]["FETCH_SIZE"] + pj["pmc3"][kname]["WRITE_SIZE"]) * 1024
+            stale = pj.get("libionode_sha256") != lib_sha
             for key in ("roofline", "roofline_hbm"):
-                res[key]["traffic"] = traffic
-                res[key]["traffic_source"] = ("HBM bytes per launch, profiles/r02_pmc_summary.json (separate rocprofv3 --pmc "
-                                              "passes of this command; FETCH_SIZE x2 per the gfx950 note, WRITE_SIZE exact)")
+                res[key]["traffic"] = None if stale else traffic
+                res[key]["traffic_stale"] = stale
+                res[key]["traffic_source"] = ("HBM bytes per launch, profiles/r03_pmc_summary.json (separate rocprofv3 --pmc "
+                                              "passes of this command; FETCH_SIZE x2 per the gfx950 note, WRITE_SIZE exact)"
+                                              + ("; NOT reported: the counters were collected with another build of libionode.so "
+                                                 f"({str(pj.get('libionode_sha256'))[:16]})" if stale else ""))
         except (KeyError, ValueError):
             pass
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -130,6 +130,16 @@ def mlp_pack(state_dict_flat, mlp_layers, mlp_width):
     return out
 
 
+def library_digest():
+    """sha256 of the libionode.so this process uses (bench.py / tools/pmc_summary.py: ties counter evidence to a build)."""
+    import hashlib
+    h = hashlib.sha256()
+    with open(LIB_PATH, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()
+
+
 def make_desc(**kw):
     d = IonodeDesc()
     for k, v in kw.items():

@@ -396,6 +396,7 @@ __device__ __forceinline__ float lrelu(float x) { return fmaxf(x, x * 0.01f); }
 template <int G, int RT, int NT, int PD, int TAIL = 0>
 struct MlpTile {
   static constexpr bool ASM = IONODE_ASM_CORE && G == 4 && NT == 13 && PD == 13;
+  static constexpr int GW = G;           // wavefronts per tile
   static constexpr int F = NT / G;       // full row tiles per wavefront
   static constexpr int R = NT - G * F;   // remainder row tiles, K-split over the G wavefronts
   static constexpr int NP = 16 * NT;
@@ -781,6 +782,7 @@ struct MlpTile {
 
 // Closed-form models carry an empty stand-in so the integrator code is shared.
 struct NoMlp {
+  static constexpr int GW = 1;
   __device__ __forceinline__ float eval(float, float) { return 0.0f; }
 };
 
@@ -861,7 +863,9 @@ __device__ __forceinline__ void rhs(const KArgs &a, const double *p, double v, b
     }
     const S one_m_a = (S)1 - av;  // `1. - a` / `self.unity - r` are formed in y.dtype
     const S one_m_r = (S)1 - rv;
-    auto dexp = [](double x) { if constexpr (MT::MLP) return det_exp_s(x); else return det_exp(x); };
+    // (not for the 64-per-wavefront N <= 16 kernel: two interleaved branch-free exps cost ~30 registers -- it went from 252 to 284
+    // VGPRs, i.e. from two wavefronts per SIMD to one, 58 -> 87 ms)
+    auto dexp = [](double x) { if constexpr (MT::MLP && !WIDE) return det_exp_s(x); else return det_exp(x); };
     const double k3 = p[4] * dexp(p[5] * v);
     const double k4 = p[6] * dexp(-p[7] * v);
     const double drdt = -k3 * (double)rv + k4 * (double)one_m_r;
@@ -1153,7 +1157,12 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
   bool inst[5];
   auto lookup_stages = [&](double tt, double dd) {
     const S tts = (S)tt, dds = (S)dd, tt1s = (S)(tt + dd);
-    if (MT::MLP && a.prot_t == nullptr) {
+#ifndef IONODE_BATCH_LOOKUPS_ALL
+#define IONODE_BATCH_LOOKUPS_ALL 0
+#endif
+    // (tile kernels only: the lane-wise kernels run at 2-3 wavefronts per SIMD and cannot afford the 35 registers -- the N <= 16
+    // kernel at 64 per wavefront went from 251 to 272 VGPRs = one wavefront per SIMD, 58 -> 87 ms; 2-state kernel -4 %)
+    if (((MT::MLP && G > 1) || IONODE_BATCH_LOOKUPS_ALL) && a.prot_t == nullptr) {
       // uniform protocol grid: five indices, five 16-byte loads back to back, then the interpolations -- ONE memory round
       // trip per attempt (protocol_v() per stage time waited for each pair of samples in turn: 5 dependent round trips,
       // ~7 k cycles of the s00 attempt)
