@@ -73,7 +73,8 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false) {
     pl->block = 64;
     // one interpolant row per lane (dense-output broadcast through LDS) + one tail buffer per trajectory (2-state models)
     // (the 4 KiB behind the rows: tail buffers of the deferred emission, or the fused objective's partial sums)
-    pl->lds = (size_t)64 * (4 + 5 * D) * 8 + (size_t)64 * 64;
+    // (+ 512 B: the deferred emission's cursors and its compacted list of emitting lanes)
+    pl->lds = (size_t)64 * (4 + 5 * D) * 8 + (size_t)64 * 64 + 512;
   } else {
     if (d->mlp_width < 1 || d->mlp_layers < 0) { set_err("bad MLP shape"); return IONODE_ERR_ARG; }
     if (d->mlp_width <= 16 && d->mlp_layers > 10) { set_err("N <= 16 kernels keep at most 10 hidden layers resident"); return IONODE_ERR_UNSUPPORTED; }
@@ -102,7 +103,7 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false) {
     const int Gv = pl->v->G, Rv = NT - Gv * (NT / Gv);  // remainder row tiles: K-split partial sums in LDS
     pl->lds = ((size_t)2 * (NT + Gv - 1) * 64 + (size_t)2 * Rv * Gv * 64 + NP) * 16 + ((size_t)d->mlp_layers * NP + NP + 4) * 4;
     if (Gv == 4 && NT == 13) pl->lds = ((pl->lds + 15) & ~(size_t)15) + 1024;  // scratch slot of the asm stream (MlpTile::scratch_off)
-    if (t64) pl->lds = ((pl->lds + 15) & ~(size_t)15) + (size_t)64 * (4 + 5 * 2) * 8 + (size_t)64 * 64;  // + interpolant rows + tails
+    if (t64) pl->lds = ((pl->lds + 15) & ~(size_t)15) + (size_t)64 * (4 + 5 * 2) * 8 + (size_t)64 * 64 + 512;  // + interpolant rows + tails + cursors / list
   }
   if (!pl->v) { set_err("no kernel variant compiled for this descriptor"); return IONODE_ERR_UNSUPPORTED; }
   return IONODE_OK;

@@ -1114,9 +1114,13 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
       for (int m = 0; m < 8; ++m) ssep[lane * 8 + m] = 0.0;
     }
   }
-  int ow = 1;  // defer: next sample index of MY trajectory not yet written to HBM (ow <= oi, oi - ow < LS)
+  // defer: owp[j] = next sample index of trajectory j not yet written to HBM (owp <= oi, oi - owp < LS); elist: the lanes that
+  // emit in the current attempt, compacted (512 bytes behind the 4 KiB of tail buffers; the dispatcher reserves them)
+  int *const owp = reinterpret_cast<int *>(tails + 64 * 64);
+  int *const elist = owp + 64;
   if constexpr (CF2 && defer) {
-    ow = 0;
+    static_assert(TAILB <= 64, "tail buffers fit the reserved 4 KiB");
+    if (lane < TPW) owp[lane] = 0;
     if (valid && lane < TPW) *reinterpret_cast<S *>(tails + lane * TAILB) = y[0], *(reinterpret_cast<S *>(tails + lane * TAILB) + 1) = y[1];
   }
   auto te_at = [&](int idx) -> double { return a.te_t0 + (double)idx * a.te_dt; };
@@ -1252,7 +1256,15 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
       }
       if constexpr (MT::MLP) rhs<MODEL, S, T64>(a, p, vst[i < 4 ? i : 4], inst[i < 4 ? i : 4], yi, k[i + 1], mlp);
       else {
-        if (i < 5) closed_rates<MODEL, S>(a, p, vst[i], inst[i], cr);  // i == 5: same stage time as i == 4, same rates
+        // rate constants depend on the stage VOLTAGE only: i == 5 shares its stage time with i == 4, and on the holding / step
+        // segments of the reference's protocols (Pr3, Pr5, staircase plateaus: train-s1.py:69-95) consecutive stages see the very same
+        // voltage -- when every lane of the wavefront does, the previous stage's rates are reused (same inputs, same bits):
+        // 4 instead of 20 exp per attempt of the 2-state model on a plateau, 12 instead of 60 for the 6-state model
+        if (i < 5) {
+          bool fresh = (i == 0);
+          if (i > 0) fresh = __ballot(vst[i] != vst[i > 0 ? i - 1 : 0] || inst[i] != inst[i > 0 ? i - 1 : 0]) != 0ull;
+          if (fresh) closed_rates<MODEL, S>(a, p, vst[i], inst[i], cr);
+        }
         closed_rhs<MODEL, S>(cr, yi, k[i + 1]);
       }
     }
@@ -1374,62 +1386,82 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
       }
       STAMP(stamps_, 9);  // slot 9: output cursor
       if constexpr (CF2 && defer) {
-        // ---- deferred aligned emission (closed-form, D == 2): whole lines inside 1 KiB-aligned blocks of the row ----
+        // ---- deferred aligned emission (closed-form, D == 2): whole 64-byte sectors, PACKED PK lanes per emitting trajectory ----
+        // A step of these kernels covers 5-10 output samples: emitting one trajectory per pass left 85-90 % of the 64 lanes idle,
+        // and the dense output was 2/3 of the kernel.  Round 3: a pass serves 64 / PK = 8 emitting trajectories, PK = 8 lanes
+        // (consecutive samples) each; everything that was wave-uniform per trajectory (interpolant row, cursor, tail pointer) is
+        // read per lane from the trajectory's LDS row, whose spare slot carries (oi, n_out); the pending-sample cursor `ow` lives
+        // in LDS next to the tail buffers.  Same samples, same arithmetic, same sector-aligned stores (PK samples = 1-2 sectors).
+        constexpr int PK = 8;
+        static_assert(PK % LS == 0 && 64 % PK == 0, "a lane group writes whole sectors");
         unsigned long long emd = __ballot(n_out > 0 && lane < TPW);
 #ifdef IONODE_EXP_NOEMIT  // timing experiment only (wrong results): stepping cost without any dense output
-        emd = 0ull; ow = oi + n_out;
+        if (n_out > 0 && lane < TPW) owp[lane] = oi + n_out;
+        emd = 0ull;
 #endif
-        while (emd) {
-          const int jj = __builtin_ctzll(emd);
-          emd &= emd - 1;
-          const int o = __builtin_amdgcn_readlane(oi, jj), n = __builtin_amdgcn_readlane(n_out, jj);
-          const int w = __builtin_amdgcn_readlane(ow, jj), tr = __builtin_amdgcn_readlane(traj, jj);
-          const double2 *rj = reinterpret_cast<const double2 *>(lsm) + jj * (ROW / 2);
-          const double2 h0 = rj[0], h1 = rj[1];
-          const double t0b = h0.x, denb = h0.y, rdenb = h1.x;
-          S cb[5][D];
-#pragma unroll
-          for (int c = 0; c < 5; ++c) {
-            const double2 cc = rj[2 + c];
-            cb[c][0] = (S)cc.x; cb[c][1] = (S)cc.y;
+        if (emd) {
+          if (n_out > 0 && lane < TPW) {
+            reinterpret_cast<int2 *>(lsm + lane * ROWB + 24)[0] = make_int2(oi, n_out);   // the row's spare slot
+            elist[__builtin_amdgcn_mbcnt_hi((unsigned)(emd >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)emd, 0))] = lane;
           }
-          const long long G0 = (long long)tr * Nt;  // global sample index of the row's first sample
-          const int end = o + n;
-          int E = Nt;                                // samples [w, E) go to HBM now, [E, end) wait in the tail buffer
-          if (end < Nt) {
-            E = (int)(((G0 + end) & ~(long long)(LS - 1)) - G0);
-            if (E < w) E = w;
-          }
-          S *__restrict__ yo = reinterpret_cast<S *>(a.y_out) + (size_t)tr * Nt * D;
-          unsigned char *const tj = tails + jj * TAILB;
-          for (int b0 = (int)(((G0 + w) & ~63ll) - G0); b0 < end; b0 += 64) {
-            const int idx = b0 + lane;
-            if (idx >= w && idx < end) {
-              S out[D];
-              if (idx < o) {  // computed by an earlier step: parked in the tail buffer
-                const S *ts = reinterpret_cast<const S *>(tj) + (size_t)(idx - w) * D;
-                out[0] = ts[0]; out[1] = ts[1];
-              } else {
-                const S x = (S)div_by(te_at(idx) - t0b, denb, rdenb);  // _interp_evaluate: x in fp64, cast; running powers
-                S xp = x;
+          const int ne = __builtin_popcountll(emd);
+          const int slot = lane / PK, kk = lane % PK;
+          for (int g = 0; g < ne; g += 64 / PK) {
+            const bool has = g + slot < ne;
+            const int jj = elist[has ? g + slot : g];   // (idle lane groups shadow the group's first trajectory, stores masked)
+            const double2 *rj = reinterpret_cast<const double2 *>(lsm) + jj * (ROW / 2);
+            const double2 h0 = rj[0], h1 = rj[1];
+            const double t0b = h0.x, denb = h0.y, rdenb = h1.x;
+            const int2 on2 = *reinterpret_cast<const int2 *>(&h1.y);
+            const int o = on2.x, n = on2.y;
+            S cb[5][D];
 #pragma unroll
-                for (int d = 0; d < D; ++d) out[d] = cb[0][d] + x * cb[1][d];
-#pragma unroll
-                for (int c = 2; c < 5; ++c) {
-                  xp = xp * x;
-#pragma unroll
-                  for (int d = 0; d < D; ++d) out[d] = out[d] + xp * cb[c][d];
-                }
-              }
-#ifdef IONODE_EXP_NOSTORE  // timing experiment only (wrong results): everything but the global stores
-              if (idx < E) { if (out[0] == (S)1.2345e-300) store_state<S, D>(yo + (size_t)idx * D, out); }
-#else
-              if (idx < E) store_state<S, D>(yo + (size_t)idx * D, out);
-#endif
-              else store_state<S, D>(reinterpret_cast<S *>(tj) + (size_t)(idx - E) * D, out);
+            for (int c = 0; c < 5; ++c) {
+              const double2 cc = rj[2 + c];
+              cb[c][0] = (S)cc.x; cb[c][1] = (S)cc.y;
             }
+            const int w = owp[jj];
+            const int tr = (int)blockIdx.x * TPW + jj;
+            const long long G0 = (long long)tr * Nt;  // global sample index of the row's first sample
+            const int end = o + n;
+            int E = Nt;                                // samples [w, E) go to HBM now, [E, end) wait in the tail buffer
+            if (end < Nt) {
+              E = (int)(((G0 + end) & ~(long long)(LS - 1)) - G0);
+              if (E < w) E = w;
+            }
+            S *__restrict__ yo = reinterpret_cast<S *>(a.y_out) + (size_t)tr * Nt * D;
+            unsigned char *const tj = tails + jj * TAILB;
+            int b0 = (int)(((G0 + w) & ~(long long)(PK - 1)) - G0);
+            while (__ballot(has && b0 < end) != 0ull) {
+              const int idx = b0 + kk;
+              if (has && idx >= w && idx < end) {
+                S out[D];
+                if (idx < o) {  // computed by an earlier step: parked in the tail buffer
+                  const S *ts = reinterpret_cast<const S *>(tj) + (size_t)(idx - w) * D;
+                  out[0] = ts[0]; out[1] = ts[1];
+                } else {
+                  const S x = (S)div_by(te_at(idx) - t0b, denb, rdenb);  // _interp_evaluate: x in fp64, cast; running powers
+                  S xp = x;
+#pragma unroll
+                  for (int d = 0; d < D; ++d) out[d] = cb[0][d] + x * cb[1][d];
+#pragma unroll
+                  for (int c = 2; c < 5; ++c) {
+                    xp = xp * x;
+#pragma unroll
+                    for (int d = 0; d < D; ++d) out[d] = out[d] + xp * cb[c][d];
+                  }
+                }
+#ifdef IONODE_EXP_NOSTORE  // timing experiment only (wrong results): everything but the global stores
+                if (idx < E) { if (out[0] == (S)1.2345e-300) store_state<S, D>(yo + (size_t)idx * D, out); }
+#else
+                if (idx < E) store_state<S, D>(yo + (size_t)idx * D, out);
+#endif
+                else store_state<S, D>(reinterpret_cast<S *>(tj) + (size_t)(idx - E) * D, out);
+              }
+              b0 += PK;
+            }
+            if (has && kk == 0) owp[jj] = E;
           }
-          if (j == jj) ow = E;
         }
         oi += n_out;
       } else if constexpr (!LW && G > 1) {
@@ -1733,11 +1765,11 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
   }
 
   if constexpr (CF2 && defer) {  // trajectories that did not end on their last sample (failed, or a single output): flush the tail
-    unsigned long long fl = __ballot(valid && lane < TPW && ow < oi);
+    unsigned long long fl = __ballot(valid && lane < TPW && owp[lane < TPW ? lane : 0] < oi);
     while (fl) {
       const int jj = __builtin_ctzll(fl);
       fl &= fl - 1;
-      const int w = __builtin_amdgcn_readlane(ow, jj), o = __builtin_amdgcn_readlane(oi, jj);
+      const int w = owp[jj], o = __builtin_amdgcn_readlane(oi, jj);
       const int tr = __builtin_amdgcn_readlane(traj, jj);
       S *__restrict__ yo = reinterpret_cast<S *>(a.y_out) + (size_t)tr * Nt * D;
       if (w + lane < o) {
