@@ -31,7 +31,7 @@ struct Plan {
 const ionode::Variant *find_variant(int model, int f32, int G, int NT, int rt = -1, int tail = 0) {
   using namespace ionode;
   typedef const Variant *(*TabFn)(int *);
-  static const TabFn tabs[] = {variants_closed, variants_nnf_f64, variants_nnf_f32, variants_nnd_f64, variants_nnd_f32};
+  static const TabFn tabs[] = {variants_closed, variants_closed3, variants_nnf_f64, variants_nnf_f32, variants_nnd_f64, variants_nnd_f32};
   for (TabFn tf : tabs) {
     int n = 0;
     const Variant *t = tf(&n);

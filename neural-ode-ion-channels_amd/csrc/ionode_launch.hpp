@@ -40,6 +40,7 @@ hipError_t launch(const KArgs &a, unsigned grid, size_t lds, hipStream_t s) {
 
 // one table per translation unit (they compile in parallel)
 const Variant *variants_closed(int *n);
+const Variant *variants_closed3(int *n);
 const Variant *variants_nnf_f64(int *n);
 const Variant *variants_nnf_f32(int *n);
 const Variant *variants_nnd_f64(int *n);
