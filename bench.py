@@ -280,17 +280,22 @@ def closed_form_legs(ion, dev, weights):
     N10, L10 = 10, 5
     w10 = np.random.default_rng(1).normal(0, 0.1, 2 * N10 + N10 + L10 * (N10 * N10 + N10) + N10 + 1).astype(np.float32)
     legs = {}
-    for name, model, p0, y0, B, mlp in (("hh2", capi.MODEL_HH2, P_HH, [0.0, 1.0], 262144, None),
+    for name, model, p0, y0, B, mlp, f32 in (("hh2", capi.MODEL_HH2, P_HH, [0.0, 1.0], 262144, None, False),
                                         # 12 resident wavefronts per CU x 256 CUs x 64 trajectories = 196 608 per "round":
                                         # 262 144 is 1.33 rounds (the last third runs on a third-full chip), 393 216 is 2.0
-                                        ("hh2_two_full_rounds", capi.MODEL_HH2, P_HH, [0.0, 1.0], 393216, None),
-                                        ("markov6", capi.MODEL_MARKOV6, p_m6, [0.0, 1.0, 0, 0, 0, 0], 65536, None),
-                                        ("nnf_s03_5x10", capi.MODEL_NNF, P_HH, [0.0, 1.0], 65536, (w10, L10, N10)),
+                                        ("hh2_two_full_rounds", capi.MODEL_HH2, P_HH, [0.0, 1.0], 393216, None, False),
+                                        ("markov6", capi.MODEL_MARKOV6, p_m6, [0.0, 1.0, 0, 0, 0, 0], 65536, None, False),
+                                        ("nnf_s03_5x10", capi.MODEL_NNF, P_HH, [0.0, 1.0], 65536, (w10, L10, N10), False),
                                         # from 73 728 trajectories the N <= 16 nets run one trajectory per lane (64 per wavefront)
-                                        ("nnf_s03_5x10_262144", capi.MODEL_NNF, P_HH, [0.0, 1.0], 262144, (w10, L10, N10))):
+                                        ("nnf_s03_5x10_262144", capi.MODEL_NNF, P_HH, [0.0, 1.0], 262144, (w10, L10, N10), False),
+                                        # the reference's own state dtype (fp32, SURVEY.md finding 4): half the bytes per sample, the
+                                        # same instruction stream -- the byte-based fraction halves, the trajectories per second do not
+                                        ("hh2_two_full_rounds_f32", capi.MODEL_HH2, P_HH, [0.0, 1.0], 393216, None, True),
+                                        ("markov6_f32", capi.MODEL_MARKOV6, p_m6, [0.0, 1.0, 0, 0, 0, 0], 65536, None, True),
+                                        ("nnf_s03_5x10_262144_f32", capi.MODEL_NNF, P_HH, [0.0, 1.0], 262144, (w10, L10, N10), True)):
         D = len(y0)
         params = torch.from_numpy(p0[None, :] * rng.uniform(0.8, 1.25, (B, p0.size))).to(dev)
-        y0t = torch.tensor([y0], dtype=torch.float64, device=dev).repeat(B, 1).contiguous()
+        y0t = torch.tensor([y0], dtype=torch.float32 if f32 else torch.float64, device=dev).repeat(B, 1).contiguous()
         pot = (torch.arange(B, dtype=torch.int32, device=dev) % n_prot).contiguous()
         kw = dict(prot_t0=0.0, prot_dt=0.1, prot_of_traj=pot, t_eval_hint=(0.0, 0.1), t_eval_exact=True)
         if mlp:
@@ -302,9 +307,9 @@ def closed_form_legs(ion, dev, weights):
             hold["r"] = capi.dopri5(model, params, pv, y0t, te, out=o, **kw)
             o.update({k: hold["r"][k] for k in ("y", "status", "stats")})
         ms = _timed(run, 2)
-        nbytes = B * Nt * D * 8 + n_prot * Nt * 8
+        nbytes = B * Nt * D * (4 if f32 else 8) + n_prot * Nt * 8
         st = hold["r"]["stats"].cpu().numpy()
-        legs[name] = {"kernel": hold["r"]["kernel"], "trajectories": B, "n_out": Nt, "kernel_ms": ms,
+        legs[name] = {"kernel": hold["r"]["kernel"], "trajectories": B, "n_out": Nt, "state": "f32" if f32 else "f64", "kernel_ms": ms,
                       "trajectories_per_s": B / ms * 1e3, "bound": "hbm", "achieved": nbytes / ms / 1e6, "peak": PEAK_HBM_GBS,
                       "unit": "GB/s", "frac": nbytes / ms / 1e6 / PEAK_HBM_GBS, "mean_nfe": float(st[:, 2].mean()),
                       "ok": int((hold["r"]["status"] == 0).sum().item())}
