@@ -1,23 +1,32 @@
-"""Dev tool: copy the evidence tools/collect_profiles.sh left under gpurun_out/r02_prof/ into profiles/ and print the key numbers."""
+"""Dev tool: copy the evidence tools/collect_profiles.sh left under gpurun_out/<R>_prof/ into profiles/ and print the key numbers.
+python tools/copy_profiles.py [r03]"""
 import csv
 import json
 import os
 import shutil
+import sys
 
-O = "gpurun_out/r02_prof"
-for f in ["r02_bench.json", "r02_bench_profiled.json", "r02_bench_profiled_legs.json", "r02_kernel_stats.csv", "r02_kernel_stats_legs.csv"]:
+R = sys.argv[1] if len(sys.argv) > 1 else "r03"
+O = f"gpurun_out/{R}_prof"
+for f in [f"{R}_bench.json", f"{R}_bench_profiled.json", f"{R}_bench_profiled_legs.json", f"{R}_kernel_stats.csv", f"{R}_kernel_stats_legs.csv"]:
     shutil.copy(os.path.join(O, f), "profiles/" + f)
-summ = {p: json.load(open(f"{O}/{p}.json")) for p in ["pmc1", "pmc2", "pmc3", "cf1", "cf2", "cf3"]}
-json.dump(summ, open("profiles/r02_pmc_summary.json", "w"), indent=1)
-b = json.load(open("profiles/r02_bench.json"))
-print("headline", b["value"], b["roofline"]["frac"], b["roofline"]["kernel_ms"], "cpu", b["cpu_baseline"]["value"], b["cpu_baseline_python"]["value"])
+names = ["pmc1", "pmc2", "pmc3", "pmc4"] + [f"cf{i}{c}" for i in (1, 2, 3, 4) for c in "abc"]
+summ = {p: json.load(open(f"{O}/{p}.json")) for p in names if os.path.exists(f"{O}/{p}.json")}
+summ["libionode_sha256"] = open(f"{O}/libionode.sha256").read().strip()   # the build the counters belong to (bench.py checks it)
+summ["legend"] = {"pmc1-4": "headline s00 kernel (bench.py --steps 1)", "cf1": "HH 2-state 393216 x 20001 fp64", "cf2": "6-state 65536 x 20001",
+                  "cf3": "NN-f 5x10, 65536 (16 per wavefront)", "cf4": "NN-f 5x10, 262144 (64 per wavefront)",
+                  "units": "FETCH_SIZE / WRITE_SIZE in KiB (FETCH_SIZE x2 on gfx950 for wide streaming reads); SQ_* summed over the chip"}
+json.dump(summ, open(f"profiles/{R}_pmc_summary.json", "w"), indent=1)
+b = json.load(open(f"profiles/{R}_bench.json"))
+print("headline", b["value"], b["roofline"]["frac"], b["roofline"]["kernel_ms"], "traffic", b["roofline"].get("traffic"), "cpu", b["cpu_baseline"]["value"])
 for k, v in b["roofline_closed_form"].items():
     if isinstance(v, dict):
         print(k, round(v["kernel_ms"], 2), v.get("frac"), v["kernel"], v.get("trajectories_per_s"))
 print("grad", b["gradient_config5"]["forward_with_checkpoints_s"], b["gradient_config5"]["backward_s"])
 print("regress", b["regression_step"]["ms_per_iteration"], b["regression_step"]["frac"])
 print("order", {k: (round(v["ms"], 1), round(v["frac_of_fp32_peak"], 4)) for k, v in b["launch_order_16384"].items() if isinstance(v, dict)})
-for name in ("r02_kernel_stats.csv", "r02_kernel_stats_legs.csv"):
+print("config3", {k: v for k, v in b["config3_nnd_staircase_16384"].items() if not isinstance(v, (dict, list))})
+for name in (f"{R}_kernel_stats.csv", f"{R}_kernel_stats_legs.csv"):
     print("--", name)
     for r in csv.DictReader(open("profiles/" + name)):
         if "ionode" in r["Name"]:
