@@ -281,6 +281,11 @@ def closed_form_legs(ion, dev, weights):
     w10 = np.random.default_rng(1).normal(0, 0.1, 2 * N10 + N10 + L10 * (N10 * N10 + N10) + N10 + 1).astype(np.float32)
     legs = {}
     for name, model, p0, y0, B, mlp, f32 in (("hh2", capi.MODEL_HH2, P_HH, [0.0, 1.0], 262144, None, False),
+                                        # the same launch with the trajectories of a protocol adjacent (schedule.protocol_order): the 64 lanes of
+                                        # a wavefront read ONE protocol instead of 64 (the 10 MB of protocols exceed an XCD's 4 MB L2)
+                                        ("hh2_two_full_rounds_protocol_major", capi.MODEL_HH2, P_HH, [0.0, 1.0], 393216, None, False),
+                                        # the 6-state model beyond two residency rounds: its two-wavefronts-per-SIMD build
+                                        ("markov6_262144", capi.MODEL_MARKOV6, p_m6, [0.0, 1.0, 0, 0, 0, 0], 262144, None, False),
                                         # 12 resident wavefronts per CU x 256 CUs x 64 trajectories = 196 608 per "round":
                                         # 262 144 is 1.33 rounds (the last third runs on a third-full chip), 393 216 is 2.0
                                         ("hh2_two_full_rounds", capi.MODEL_HH2, P_HH, [0.0, 1.0], 393216, None, False),
@@ -297,6 +302,8 @@ def closed_form_legs(ion, dev, weights):
         params = torch.from_numpy(p0[None, :] * rng.uniform(0.8, 1.25, (B, p0.size))).to(dev)
         y0t = torch.tensor([y0], dtype=torch.float32 if f32 else torch.float64, device=dev).repeat(B, 1).contiguous()
         pot = (torch.arange(B, dtype=torch.int32, device=dev) % n_prot).contiguous()
+        if name.endswith("protocol_major"):
+            pot = pot[ion.schedule.protocol_order(pot)].contiguous()
         kw = dict(prot_t0=0.0, prot_dt=0.1, prot_of_traj=pot, t_eval_hint=(0.0, 0.1), t_eval_exact=True)
         if mlp:
             kw.update(mlp_packed=torch.from_numpy(capi.mlp_pack(mlp[0], mlp[1], mlp[2])).to(dev), mlp_layers=mlp[1], mlp_width=mlp[2])

@@ -67,7 +67,9 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false) {
     // round at 2 per SIMD (2048 wavefronts), else the 3-per-SIMD build (tools/ab_hh.sh, ab_hh2.sh: 131 072 trajectories at 64
     // per wavefront 19.3 against 24.3 ms; beyond one round the 2-per-SIMD build loses, e.g. 163 839: 32.8 against 24.6 ms)
     const long long waves = ((long long)d->n_traj + tpw - 1) / tpw;
-    const int wslot = (d->model == IONODE_MODEL_HH2 && waves <= 2048) ? 2 : 0;
+    int wslot = (d->model == IONODE_MODEL_HH2 && waves <= 2048) ? 2 : 0;
+    // 6-state model: one wavefront per SIMD (no spill) up to two residency rounds; beyond, the two-per-SIMD build (inst_closed3.hip)
+    if (d->model == IONODE_MODEL_MARKOV6 && tpw == 64 && d->n_traj >= 196608) wslot = 2;
     pl->v = find_variant(d->model, f32, 1, wslot, tpw == 64 ? 0 : 16, defer);
     pl->grid = (unsigned)((d->n_traj + tpw - 1) / tpw);
     pl->block = 64;

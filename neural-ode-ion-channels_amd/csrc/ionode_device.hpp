@@ -957,8 +957,11 @@ template <typename S> __device__ __forceinline__ S abs_(S x) { return x < 0 ? -x
 // wavefronts (+20 % at 131 072 trajectories; -25 % at 196 608); 4 per SIMD spills 43 dwords and loses.  6-state: ONE wavefront per
 // SIMD (the whole 512-register file): at 2 per SIMD it spilled 48 dwords into scratch inside the stage loop and ran 1.6x
 // (65 536 trajectories) to 2x (16 384) slower; from 131 072 trajectories the two are equal.  MLP tiles: 1 per SIMD.
+#ifndef IONODE_M6_WAVES
+#define IONODE_M6_WAVES 1
+#endif
 #ifndef IONODE_CF_WAVES
-#define IONODE_CF_WAVES(MODEL, G) ((G) > 1 ? 1 : ((MODEL) == IONODE_MODEL_HH2 ? 3 : 1))
+#define IONODE_CF_WAVES(MODEL, G) ((G) > 1 ? 1 : ((MODEL) == IONODE_MODEL_HH2 ? 3 : IONODE_M6_WAVES))
 #endif
 // Closed-form kernels do not use the NT slot of the template: a non-zero value there is an explicit wavefronts-per-SIMD
 // budget (the 2-state kernel is also instantiated at 2: 238 VGPRs, no spill -- the faster build below ~160 k trajectories)
@@ -966,7 +969,7 @@ template <typename S> __device__ __forceinline__ S abs_(S x) { return x < 0 ? -x
 #define IONODE_T64_WAVES 1
 #endif
 #define IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT) \
-  (((MODEL) == IONODE_MODEL_HH2 && (NT) > 0) ? (NT) : (((MODEL) >= IONODE_MODEL_NNF && (RT) == 64) ? IONODE_T64_WAVES : IONODE_CF_WAVES(MODEL, G)))
+  ((((MODEL) == IONODE_MODEL_HH2 || (MODEL) == IONODE_MODEL_MARKOV6) && (NT) > 0) ? (NT) : (((MODEL) >= IONODE_MODEL_NNF && (RT) == 64) ? IONODE_T64_WAVES : IONODE_CF_WAVES(MODEL, G)))
 
 template <typename S, int D> __device__ __forceinline__ void store_state(S *dst, const S *v) {
   if constexpr (D == 2 && sizeof(S) == 8) {

@@ -41,3 +41,14 @@ def pilot_cost(params, prot_v, t0, t1, *, prot_t0=0.0, prot_dt=1.0, prot_t=None,
                         prot_dt=prot_dt, prot_of_traj=prot_of_traj, rtol=rtol, atol=atol, v_oob=v_oob, device=device,
                         t_eval_hint=None)
     return sol.stats[:, 2].to(torch.float64)
+
+
+def protocol_order(prot_of_traj):
+    """Launch order that puts the trajectories of one protocol next to each other (stable: ties keep their index order).
+    The lanes of a closed-form wavefront then interpolate ONE protocol instead of up to 64 different ones: the sample loads of a
+    stage lookup coalesce, and the protocols' footprint per XCD L2 shrinks -- HH 2-state, 393 216 x 20 001 on 64 protocols
+    (10 MB against 4 MB of L2 per XCD): 44.7 -> 42.5 ms.  Use as `order=` of batched.solve / grad.solve (results are unchanged;
+    rows come back in launch order, Solution.to_original() undoes it) or apply it to the inputs directly."""
+    import torch
+    p = torch.as_tensor(prot_of_traj)
+    return torch.sort(p.to(torch.int64), stable=True).indices
