@@ -7,6 +7,9 @@
 
 #include "ionode_launch.hpp"
 
+#ifndef IONODE_TILE32_FROM
+#define IONODE_TILE32_FROM 8192  // N = 200: two 16-trajectory tiles per compute unit
+#endif
 #ifndef IONODE_TINY64_FROM
 #define IONODE_TINY64_FROM 73728  // 16 per wavefront: 32 768 trajectories per residency round of 12.8 ms; 64 per wavefront: 131 072 per round of 30 ms
 #endif
@@ -81,8 +84,8 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false) {
     if (d->mlp_width < 1 || d->mlp_layers < 0) { set_err("bad MLP shape"); return IONODE_ERR_ARG; }
     if (d->mlp_width <= 16 && d->mlp_layers > 10) { set_err("N <= 16 kernels keep at most 10 hidden layers resident"); return IONODE_ERR_UNSUPPORTED; }
     const int NP = np_of(d->mlp_width), NT = NP / 16;
-    if (d->tile_waves != 0 && d->tile_waves != 1 && d->tile_waves != 4 && !(d->tile_waves == 64 && NT == 1)) {
-      set_err("tile_waves must be 0, 1 or 4 for MLP models (64: the N <= 16 kernel at 64 trajectories per wavefront)");
+    if (d->tile_waves != 0 && d->tile_waves != 1 && d->tile_waves != 4 && !(d->tile_waves == 64 && NT == 1) && !(d->tile_waves == 8 && NT == 13)) {
+      set_err("tile_waves must be 0, 1 or 4 for MLP models (64: the N <= 16 kernel at 64 trajectories per wavefront; 8: the N = 200 kernel with 32 trajectories per tile)");
       return IONODE_ERR_UNSUPPORTED;
     }
     // N <= 16 (architectures s03-s05): from IONODE_TINY64_FROM trajectories on, one trajectory per lane (64 per wavefront, four
@@ -94,17 +97,24 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false) {
     const bool t64 = NT == 1 && (d->tile_waves == 64 || (d->tile_waves == 0 && d->n_traj >= IONODE_TINY64_FROM && img64));
     // (deferred aligned emission as for the 2-state closed-form kernels: verified uniform output grid, no current / objective)
     const int t64defer = (t64 && d->t_eval_exact && d->t_eval_dt_hint > 0.0 && d->n_out > 1 && !want_current) ? 1 : 0;
-    pl->v = t64 ? find_variant(d->model, f32, 1, NT, 64, t64defer) : find_variant(d->model, f32, d->tile_waves, NT, NT == 1 ? 1 : -1);
+    // N = 200: from two 16-trajectory tiles per compute unit on (8192 trajectories), 32-trajectory tiles -- two column sets per weight
+    // fragment, the scalar integrator work replicated twice instead of four times (tile_waves = 8 forces it, 4 forces the 16-tile).
+    // Needs a hidden layer (asm stream) and weight images that cover whole 32-trajectory tiles.
+    const bool t32 = !t64 && NT == 13 && d->mlp_layers >= 1 && (d->traj_per_image <= 0 || d->traj_per_image % 32 == 0) &&
+                     (d->tile_waves == 8 || (d->tile_waves == 0 && d->n_traj >= IONODE_TILE32_FROM));
+    pl->v = t64 ? find_variant(d->model, f32, 1, NT, 64, t64defer)
+                : find_variant(d->model, f32, (d->tile_waves == 8 ? 4 : d->tile_waves), NT, NT == 1 ? 1 : -1, t32 ? 4 : 0);
     if (!pl->v) {
       set_err("MLP width outside the compiled kernel variants: N must pad to 16, 112, 208 or 512 "
               "(architectures s00-s11: N = 10, 100, 200, 500)");
       return IONODE_ERR_UNSUPPORTED;
     }
-    pl->grid = t64 ? (unsigned)((d->n_traj + 63) / 64) : (unsigned)((d->n_traj + 15) / 16);
+    pl->grid = t64 ? (unsigned)((d->n_traj + 63) / 64) : (t32 ? (unsigned)((d->n_traj + 31) / 32) : (unsigned)((d->n_traj + 15) / 16));
     pl->block = 64u * pl->v->G;
     const int Gv = pl->v->G, Rv = NT - Gv * (NT / Gv);  // remainder row tiles: K-split partial sums in LDS
     pl->lds = ((size_t)2 * (NT + Gv - 1) * 64 + (size_t)2 * Rv * Gv * 64 + NP) * 16 + ((size_t)d->mlp_layers * NP + NP + 4) * 4;
-    if (Gv == 4 && NT == 13) pl->lds = ((pl->lds + 15) & ~(size_t)15) + 1024;  // scratch slot of the asm stream (MlpTile::scratch_off)
+    // the asm tile (N = 200): + scratch slot (+ the input exchange of the two-column-set tile), MlpTile::lds_total
+    if (Gv == 4 && NT == 13) pl->lds = t32 ? ionode::MlpTile<4, 4, 13, 13, 4>::lds_total(d->mlp_layers) : ionode::MlpTile<4, 4, 13, 13, 0>::lds_total(d->mlp_layers);
     if (t64) pl->lds = ((pl->lds + 15) & ~(size_t)15) + (size_t)64 * (4 + 5 * 2) * 8 + (size_t)64 * 64 + 512;  // + interpolant rows + tails + cursors / list
   }
   if (!pl->v) { set_err("no kernel variant compiled for this descriptor"); return IONODE_ERR_UNSUPPORTED; }
@@ -264,7 +274,7 @@ int ionode_dopri5(const ionode_desc *d, const float *mlp_packed, const double *p
   a.step_log = d->step_log; a.step_log_cap = d->step_log ? d->step_log_cap : 0;
   a.sse_ref = d->sse_ref; a.sse_out = d->sse_out; a.v_tab = d->v_at_outputs;
   if (mlp && d->traj_per_image > 0) {
-    const int tile = (pl.block == 64 && pl.v->RT == 64) ? 64 : 16;
+    const int tile = (pl.block == 64 && pl.v->RT == 64) ? 64 : (pl.v->tail == 4 && pl.v->G == 4 ? 32 : 16);
     if (d->traj_per_image % tile != 0 || d->mlp_image_stride < (int64_t)ionode_mlp_packed_floats(d->mlp_layers, d->mlp_width)) {
       set_err("traj_per_image must be a multiple of the tile size (16; 64 with tile_waves = 64) and mlp_image_stride at least one packed image");
       return IONODE_ERR_ARG;

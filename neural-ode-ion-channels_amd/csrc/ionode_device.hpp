@@ -389,6 +389,7 @@ __device__ __forceinline__ float lrelu(float x) { return fmaxf(x, x * 0.01f); }
 #if !defined(IONODE_NO_ASM_CORE)
 #define IONODE_ASM_CORE 1
 #include "mlp_asm_nt13.inc"
+#include "mlp_asm_nt13x2.inc"
 #else
 #define IONODE_ASM_CORE 0
 #endif
@@ -397,13 +398,18 @@ template <int G, int RT, int NT, int PD, int TAIL = 0>
 struct MlpTile {
   static constexpr bool ASM = IONODE_ASM_CORE && G == 4 && NT == 13 && PD == 13;
   static constexpr int GW = G;           // wavefronts per tile
+  // TAIL == 4: TWO 16-trajectory column sets per tile (32 trajectories per workgroup; launches of >= 2 tiles per compute unit).
+  // Every weight fragment then feeds two MFMAs, and wavefronts 0, 1 integrate set 0, wavefronts 2, 3 set 1: the scalar
+  // Runge-Kutta work is replicated twice per trajectory instead of four times.  Asm stream only (tools/gen_mlp_asm.py --ns 2).
+  static constexpr int NSETS = (TAIL == 4) ? 2 : 1;
+  static_assert(NSETS == 1 || ASM, "two column sets exist for the asm tile only");
   static constexpr int F = NT / G;       // full row tiles per wavefront
   static constexpr int R = NT - G * F;   // remainder row tiles, K-split over the G wavefronts
   static constexpr int NP = 16 * NT;
   static constexpr int RP = (R > 0 ? R : 1);
   static constexpr int HT = NT + G - 1;  // activation slots per buffer (see Hs)
   static_assert(NT % PD == 0, "ring depth must divide the k-tile count");
-  static_assert(TAIL == 0, "tail scheme retired: the refills are interleaved with the MFMAs instead");
+  static_assert(TAIL == 0 || TAIL == 4, "tail scheme retired: the refills are interleaved with the MFMAs instead");
   static_assert(RT == F + R, "RT = full + remainder tile slots per wavefront");
   static_assert((4 * RT) % 4 == 0 && (RT == 1 || RT == 2 || RT == 4 || RT == 8), "fragment = RT float4 per k-tile");
   static_assert(R == 0 || G == 4, "the remainder combine tree is written for 4 wavefronts");
@@ -443,19 +449,21 @@ struct MlpTile {
   // index of step s's first fragment in a wavefront's layer stream
   static __host__ __device__ constexpr int step_base(int s) { return s * F + R * ((s + G - 1) / G); }
   static __host__ __device__ constexpr size_t lds_bytes(int L) {
-    return ((size_t)2 * HT * 64 + (size_t)2 * R * G * 64 + NP) * 16 + ((size_t)L * NP + NP + 4) * 4;
+    return ((size_t)2 * NSETS * HT * 64 + (size_t)2 * NSETS * R * G * 64 + NP) * 16 + ((size_t)L * NP + NP + 4) * 4;
   }
   // the asm stream parks the stores of a not-yet-existing previous layer in a 1 KiB scratch slot behind the tile's LDS
-  // (so that every pass issues the same LDS operations and the wait counts are static)
+  // (so that every pass issues the same LDS operations and the wait counts are static); two column sets: + 256 B through
+  // which the wavefronts exchange their stage inputs
   static __host__ __device__ constexpr size_t scratch_off(int L) { return (lds_bytes(L) + 15) & ~(size_t)15; }
+  static __host__ __device__ constexpr size_t lds_total(int L) { return ASM ? scratch_off(L) + 1024 + (NSETS > 1 ? 256 : 0) : lds_bytes(L); }
 
   __device__ __forceinline__ void init(const KArgs &a, unsigned char *smem, int wave_, int lane_, int first_traj = 0) {
     L = a.L; wave = wave_; lane = lane_;
     // the tile's weight image: the shared one, or image number first_traj / traj_per_img of an ensemble
     const float *__restrict__ img = a.mlp + (a.traj_per_img > 0 ? (size_t)(first_traj / a.traj_per_img) * (size_t)a.mlp_stride : (size_t)0);
     Hs = reinterpret_cast<f32x4 *>(smem);
-    Ps = Hs + 2 * HT * 64;
-    f32x4 *w0 = Ps + 2 * R * G * 64;
+    Ps = Hs + 2 * NSETS * HT * 64;
+    f32x4 *w0 = Ps + 2 * NSETS * R * G * 64;
     float *bs = reinterpret_cast<float *>(w0 + NP);
     float *ws = bs + (size_t)L * NP;
     constexpr size_t lstride = layer_floats();
@@ -606,9 +614,10 @@ struct MlpTile {
         // the whole evaluation -- Linear(2, N), the hidden stack, Linear(N, 1) -- is one asm statement (tools/gen_mlp_asm.py).
         // Inputs: per-lane LDS byte addresses of the two activation buffers (b = 0: input of even layers), the partial-sum
         // buffers, this lane's rows of the small vectors, and the wavefront's weight stream.
-        const unsigned hw0 = lds0 + (unsigned)(wave * 64 + lane) * 16u, hw1 = hw0 + (unsigned)tstride * 16u;
-        const unsigned fw0 = lds0 + (unsigned)((NT - 1) * 64 + lane) * 16u, fw1 = fw0 + (unsigned)tstride * 16u;
-        const unsigned pl0 = lds0 + (unsigned)(2 * tstride) * 16u + (unsigned)lane * 16u, pl1 = pl0 + (unsigned)pstride * 16u;
+        constexpr unsigned HB = (unsigned)(NSETS * tstride) * 16u, PB = (unsigned)(NSETS * pstride) * 16u;  // bytes per activation / partial-sum buffer
+        const unsigned hw0 = lds0 + (unsigned)(wave * 64 + lane) * 16u, hw1 = hw0 + HB;
+        const unsigned fw0 = lds0 + (unsigned)((NT - 1) * 64 + lane) * 16u, fw1 = fw0 + HB;
+        const unsigned pl0 = lds0 + 2u * HB + (unsigned)lane * 16u, pl1 = pl0 + PB;
         const unsigned pw0 = pl0 + (unsigned)wave * 1024u, pw1 = pl1 + (unsigned)wave * 1024u;
         const unsigned bias0 = (unsigned)(uintptr_t)biasS, w00 = (unsigned)(uintptr_t)W0s;
         const unsigned bias_a = bias0 + (unsigned)(16 * wave + 4 * q) * 4u, bias_r = bias0 + (unsigned)(16 * (NT - 1) + 4 * q) * 4u;
@@ -617,13 +626,31 @@ struct MlpTile {
         const unsigned dummy = lds0 + (unsigned)scratch_off(L) + (unsigned)lane * 16u;
         const int nl = __builtin_amdgcn_readfirstlane(L);
         float out;
-        asm volatile(IONODE_MLPASM_LAYERS_13
-                     : [out] "=v"(out)
-                     : [hw_in] "v"(hw0), [hw_out] "v"(hw1), [fw_in] "v"(fw0), [fw_out] "v"(fw1), [pl_in] "v"(pl0), [pl_out] "v"(pl1),
-                       [pw_in] "v"(pw0), [pw_out] "v"(pw1), [bias_a] "v"(bias_a), [bias_r] "v"(bias_r), [voff] "v"(voff),
-                       [dummy] "v"(dummy), [w0a] "v"(w0a), [w0r] "v"(w0r), [wla] "v"(wla), [x0] "v"(x0), [x1] "v"(x1),
-                       [rsrc] "s"(rsrc), [nl] "s"(nl), [lbytes] "s"(lbytes), [hid0] "s"(hid0), [wave] "s"(wave), [bl] "s"(bl_bits)
-                     : "memory", "scc", "vcc", IONODE_MLPASM_CLOBBER_V_13, IONODE_MLPASM_CLOBBER_A_13, IONODE_MLPASM_CLOBBER_S_13);
+        if constexpr (NSETS == 1) {
+          asm volatile(IONODE_MLPASM_LAYERS_13
+                       : [out] "=v"(out)
+                       : [hw_in] "v"(hw0), [hw_out] "v"(hw1), [fw_in] "v"(fw0), [fw_out] "v"(fw1), [pl_in] "v"(pl0), [pl_out] "v"(pl1),
+                         [pw_in] "v"(pw0), [pw_out] "v"(pw1), [bias_a] "v"(bias_a), [bias_r] "v"(bias_r), [voff] "v"(voff),
+                         [dummy] "v"(dummy), [w0a] "v"(w0a), [w0r] "v"(w0r), [wla] "v"(wla), [x0] "v"(x0), [x1] "v"(x1),
+                         [rsrc] "s"(rsrc), [nl] "s"(nl), [lbytes] "s"(lbytes), [hid0] "s"(hid0), [wave] "s"(wave), [bl] "s"(bl_bits)
+                       : "memory", "scc", "vcc", IONODE_MLPASM_CLOBBER_V_13, IONODE_MLPASM_CLOBBER_A_13, IONODE_MLPASM_CLOBBER_S_13);
+        } else {
+          // two column sets: this wavefront's stage inputs belong to set `wave / 2`; the stream exchanges them through LDS
+          // ([set][16] x {x0, x1} behind the scratch slot) and returns the result of the own set
+          const int cset = wave / (G / NSETS);
+          const unsigned xch = lds0 + (unsigned)scratch_off(L) + 1024u + (unsigned)(lane & 15) * 8u;
+          const unsigned xchw = xch + (unsigned)cset * 128u;
+          const int own_h = cset * (int)(tstride * 16), own_p = cset * (int)(pstride * 16);
+          asm volatile(IONODE_MLPASM_LAYERS_13x2
+                       : [out] "=v"(out)
+                       : [hw_in] "v"(hw0), [hw_out] "v"(hw1), [fw_in] "v"(fw0), [fw_out] "v"(fw1), [pl_in] "v"(pl0), [pl_out] "v"(pl1),
+                         [pw_in] "v"(pw0), [pw_out] "v"(pw1), [bias_a] "v"(bias_a), [bias_r] "v"(bias_r), [voff] "v"(voff),
+                         [dummy] "v"(dummy), [w0a] "v"(w0a), [w0r] "v"(w0r), [wla] "v"(wla), [x0] "v"(x0), [x1] "v"(x1),
+                         [xchw] "v"(xchw), [xchr] "v"(xch),
+                         [rsrc] "s"(rsrc), [nl] "s"(nl), [lbytes] "s"(lbytes), [hid0] "s"(hid0), [wave] "s"(wave), [bl] "s"(bl_bits),
+                         [own_h] "s"(own_h), [own_p] "s"(own_p)
+                       : "memory", "scc", "vcc", IONODE_MLPASM_CLOBBER_V_13x2, IONODE_MLPASM_CLOBBER_A_13x2, IONODE_MLPASM_CLOBBER_S_13x2);
+        }
         MSTAMP(3);  // slot 3: the whole evaluation (asm stream)
         return out;
       }
@@ -1002,20 +1029,26 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
   constexpr bool T64 = MT::MLP && RT == 64;
   static_assert(!T64 || (G == 1 && NT == 1), "64 trajectories per wavefront is the resident-weights (N <= 16) path");
   constexpr bool LW = !MT::MLP || T64;
-  constexpr int TPW = MT::MLP ? (T64 ? 64 : 16) : (RT > 0 ? RT : 64);
+  // MLP tile kernels with TAIL == 4: two 16-trajectory column sets per workgroup (MlpTile::NSETS); wavefronts [0, WPS) integrate
+  // set 0, [WPS, 2 WPS) set 1.  LPS = lanes of a wavefront that hold distinct trajectories.
+  constexpr int NSETS = (MT::MLP && G > 1 && TAIL == 4) ? 2 : 1;
+  constexpr int WPS = G / NSETS;
+  constexpr int TPW = MT::MLP ? (T64 ? 64 : 16 * NSETS) : (RT > 0 ? RT : 64);
+  constexpr int LPS = (MT::MLP && !T64) ? 16 : TPW;
   static_assert(MT::MLP || G == 1, "closed-form models use one wavefront per tile");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps per-wave tile guards scalar
-  const int j = lane % TPW;
-  const bool primary = (lane < TPW) && (wave == 0);  // the replica that writes per-trajectory scalars
-  const int traj_raw = blockIdx.x * TPW + j;
+  const int j = lane % LPS;
+  const int cset = (NSETS > 1) ? wave / WPS : 0, wis = wave % WPS;  // column set of this wavefront, wavefront index inside the set
+  const bool primary = (lane < LPS) && (wis == 0);  // the replica that writes per-trajectory scalars
+  const int traj_raw = blockIdx.x * TPW + cset * LPS + j;
   const bool valid = traj_raw < a.B;
   const int traj = valid ? traj_raw : a.B - 1;
 
-  using MlpT = MlpTile<G, (T64 ? 1 : (RT > 0 ? RT : 1)), (NT > 0 ? NT : 1), (PD > 0 ? PD : 1), 0>;
+  using MlpT = MlpTile<G, (T64 ? 1 : (RT > 0 ? RT : 1)), (NT > 0 ? NT : 1), (PD > 0 ? PD : 1), (NSETS > 1 ? 4 : 0)>;
   typename std::conditional<MT::MLP, MlpT, NoMlp>::type mlp;
   if constexpr (MT::MLP) mlp.init(a, smem, wave, lane, (int)blockIdx.x * TPW);
   // lane-wise kernels: interpolant rows + tail buffers; behind the MlpTile region when there is one
@@ -1123,8 +1156,8 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
   int *const elist = owp + 64;
   if constexpr (CF2 && defer) {
     static_assert(TAILB <= 64, "tail buffers fit the reserved 4 KiB");
-    if (lane < TPW) owp[lane] = 0;
-    if (valid && lane < TPW) *reinterpret_cast<S *>(tails + lane * TAILB) = y[0], *(reinterpret_cast<S *>(tails + lane * TAILB) + 1) = y[1];
+    if (lane < LPS) owp[lane] = 0;
+    if (valid && lane < LPS) *reinterpret_cast<S *>(tails + lane * TAILB) = y[0], *(reinterpret_cast<S *>(tails + lane * TAILB) + 1) = y[1];
   }
   auto te_at = [&](int idx) -> double { return a.te_t0 + (double)idx * a.te_dt; };
 
@@ -1214,11 +1247,11 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
     }
     // failed trajectories: the rest of their output is NaN (cooperative fill)
     {
-      unsigned long long fm = __ballot(failed_now && lane < TPW);
+      unsigned long long fm = __ballot(failed_now && lane < LPS);
       while (fm) {
         const int jj = __builtin_ctzll(fm);
         fm &= fm - 1;
-        if (G == 1 || (jj % G) == wave) {
+        if (WPS == 1 || (jj % WPS) == wis) {
           const int o0 = __builtin_amdgcn_readlane(oi, jj);
           const int tr = __builtin_amdgcn_readlane(traj, jj);
           S *__restrict__ yo = reinterpret_cast<S *>(a.y_out) + (size_t)tr * Nt * D;
@@ -1232,7 +1265,13 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
         }
       }
     }
-    if (__ballot(active) == 0ull) break;
+    if constexpr (NSETS > 1) {
+      // two column sets: the wavefronts of one set may be done while the other set still integrates -- but every stage evaluation is a
+      // collective of all G wavefronts (each computes its row tiles for BOTH sets), so the tile leaves the loop together
+      if (__syncthreads_or(active ? 1 : 0) == 0) break;
+    } else {
+      if (__ballot(active) == 0ull) break;
+    }
 
     // ---- _runge_kutta_step ----
     const double t0 = t;
@@ -1397,13 +1436,13 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
         // in LDS next to the tail buffers.  Same samples, same arithmetic, same sector-aligned stores (PK samples = 1-2 sectors).
         constexpr int PK = 8;
         static_assert(PK % LS == 0 && 64 % PK == 0, "a lane group writes whole sectors");
-        unsigned long long emd = __ballot(n_out > 0 && lane < TPW);
+        unsigned long long emd = __ballot(n_out > 0 && lane < LPS);
 #ifdef IONODE_EXP_NOEMIT  // timing experiment only (wrong results): stepping cost without any dense output
-        if (n_out > 0 && lane < TPW) owp[lane] = oi + n_out;
+        if (n_out > 0 && lane < LPS) owp[lane] = oi + n_out;
         emd = 0ull;
 #endif
         if (emd) {
-          if (n_out > 0 && lane < TPW) {
+          if (n_out > 0 && lane < LPS) {
             reinterpret_cast<int2 *>(lsm + lane * ROWB + 24)[0] = make_int2(oi, n_out);   // the row's spare slot
             elist[__builtin_amdgcn_mbcnt_hi((unsigned)(emd >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)emd, 0))] = lane;
           }
@@ -1473,7 +1512,7 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
       // the two protocol samples per output time of the observation model -- is issued before anything is evaluated: one
       // round trip per accepted step instead of two dependent ones per emitting trajectory.  Samples beyond the first chunk
       // (steps spanning more than 64 outputs) take the plain loop.
-      constexpr int NS = TPW / G;
+      constexpr int NS = LPS / WPS;
       const bool exact = a.te_exact != 0;
       const bool want_i = (a.i_out != nullptr) || (a.sse_out != nullptr);
       const bool ugrid = a.prot_t == nullptr;
@@ -1483,7 +1522,7 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
       const double *pv_[NS];
 #pragma unroll
       for (int k = 0; k < NS; ++k) {
-        const int jj = wave + G * k;
+        const int jj = wis + WPS * k;
         o_[k] = __builtin_amdgcn_readlane(oi, jj);
         n_[k] = __builtin_amdgcn_readlane(n_out, jj);
         pv_[k] = a.prot_v + (size_t)__builtin_amdgcn_readlane(pidx, jj) * a.Np;
@@ -1500,7 +1539,7 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
       STAMP(stamps_, 10);  // slot 10: emission, gather phase
 #pragma unroll
       for (int k = 0; k < NS; ++k) {
-        const int jj = wave + G * k;
+        const int jj = wis + WPS * k;
         const int n = n_[k], o = o_[k];
         if (n > 0) {
           const double t0b = bcast_f64(t0, jj), denb = bcast_f64(den, jj), rdenb = bcast_f64(rden, jj);
@@ -1554,7 +1593,7 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
       oi += n_out;
       } else {
       // ---- owner wavefront evaluates and stores; the t_eval loads of the next trajectory are issued ahead ----
-      unsigned long long em = __ballot(n_out > 0 && lane < TPW);
+      unsigned long long em = __ballot(n_out > 0 && lane < LPS);
       if (G > 1) {  // trajectory jj belongs to wavefront jj % G
         unsigned long long mine = 0ull;
 #pragma unroll
@@ -1670,11 +1709,11 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
       }
     } else {
       // ---- no grid hint: cooperative scan, every wavefront advances every cursor ----
-      unsigned long long em = __ballot(acc_now && lane < TPW);
+      unsigned long long em = __ballot(acc_now && lane < LPS);
       while (em) {
         const int jj = __builtin_ctzll(em);
         em &= em - 1;
-        const bool owner = (G == 1) || ((jj % G) == wave);
+        const bool owner = (WPS == 1) || ((jj % WPS) == wis);
         int o = __builtin_amdgcn_readlane(oi, jj);
         const double t1b = bcast_f64(t1, jj);
         // every wavefront advances the output cursor; only the owner evaluates and stores
@@ -1768,7 +1807,7 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
   }
 
   if constexpr (CF2 && defer) {  // trajectories that did not end on their last sample (failed, or a single output): flush the tail
-    unsigned long long fl = __ballot(valid && lane < TPW && owp[lane < TPW ? lane : 0] < oi);
+    unsigned long long fl = __ballot(valid && lane < LPS && owp[lane < LPS ? lane : 0] < oi);
     while (fl) {
       const int jj = __builtin_ctzll(fl);
       fl &= fl - 1;
@@ -1800,7 +1839,7 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
       for (int m = 0; m < 8; ++m) sse += ssep[j * 8 + m];
     }
   }
-  if (a.sse_out != nullptr && valid && lane < TPW && (G == 1 || (lane % G) == wave))
+  if (a.sse_out != nullptr && valid && lane < LPS && (WPS == 1 || (lane % WPS) == wis))
     a.sse_out[traj] = (status == IONODE_STATUS_OK) ? sse : __builtin_inf();  // the reference's time-limit rule: inf (train-d0.py:430-431)
   if (valid && primary) {
     a.status[traj] = status;

@@ -167,10 +167,13 @@ def test_large_population_of_tiny_nets_dispatches(ion, gpu, oracle):
 
 @pytest.mark.parametrize("L", [1, 2, 3, 4, 6])
 @pytest.mark.parametrize("f32", [False, True])
-def test_asm_stream_every_depth(ion, gpu, oracle, L, f32):
+@pytest.mark.parametrize("tile", [4, 8])
+def test_asm_stream_every_depth(ion, gpu, oracle, L, f32, tile):
     """The N = 200 tile's evaluation is one asm statement looping over the hidden layers (tools/gen_mlp_asm.py): odd and even depths
-    (weight-ring wrap to layer 0, the barrier behind Linear(N, 1) for even L), ragged tile (B = 21), NN-f and NN-d."""
-    N, B = 200, 21
+    (weight-ring wrap to layer 0, the barrier behind Linear(N, 1) for even L), ragged tiles, NN-f and NN-d -- for the 16-trajectory
+    tile (tile_waves = 4) and the 32-trajectory tile with two column sets per weight fragment (tile_waves = 8: B = 53 is one full
+    tile and one whose second column set holds 5 trajectories)."""
+    N, B = 200, (21 if tile == 4 else 53)
     rng = np.random.default_rng(100 + L)
     n = 2 * N + N + L * (N * N + N) + N + 1
     w = (rng.normal(0, 0.08, n)).astype(np.float32)
@@ -180,11 +183,14 @@ def test_asm_stream_every_depth(ion, gpu, oracle, L, f32):
     pot = (np.arange(B) % 2).astype(np.int32)
     for model in (K.MODEL_NNF, K.MODEL_NND):
         g = ion.solve(model, params, pv, torch.tensor([[0.0, 1.0]], dtype=torch.float32 if f32 else torch.float64), te,
-                      weights=w, mlp_layers=L, mlp_width=N, prot_t0=0.0, prot_dt=1.0, prot_of_traj=pot, current=True)
+                      weights=w, mlp_layers=L, mlp_width=N, prot_t0=0.0, prot_dt=1.0, prot_of_traj=pot, current=True, tile_waves=tile)
+        assert ("13, 13, 4>" if tile == 8 else "13, 13, 0>") in g.kernel, g.kernel
         o = oracle.solve(model, params, pv, [0.0, 1.0], te, weights=w, mlp_layers=L, mlp_width=N, prot_t0=0.0, prot_dt=1.0,
                          prot_of_traj=pot, state_f32=f32, nthreads=8)
         assert np.array_equal(g.status.cpu().numpy(), o["status"]) and np.array_equal(g.stats.cpu().numpy(), o["stats"])
         assert np.array_equal(g.y.double().cpu().numpy(), o["y"], equal_nan=True)
+        cur = np.stack([oracle.current(o["y"][b], oracle.protocol_v(pv[pot[b]], te, prot_t0=0.0, prot_dt=1.0)[0], state_f32=f32) for b in range(B)])
+        assert np.array_equal(g.i.cpu().numpy(), cur)
 
 
 @pytest.mark.parametrize("f32", [False, True])

@@ -1,34 +1,42 @@
 #!/usr/bin/env python3
-"""Generator of the hand-scheduled hidden-layer stream of the 16-trajectory MLP tile (gfx950 inline asm).
+"""Generator of the hand-scheduled MLP evaluation stream of the N = 200 tile (gfx950 inline asm).
 
-    python3 tools/gen_mlp_asm.py --nt 13 --out neural-ode-ion-channels_amd/csrc/mlp_asm_nt13.inc
+    python3 tools/gen_mlp_asm.py --nt 13 --pd 7 --ns 1 --out neural-ode-ion-channels_amd/csrc/mlp_asm_nt13.inc
+    python3 tools/gen_mlp_asm.py --nt 13 --pd 7 --ns 2 --out neural-ode-ion-channels_amd/csrc/mlp_asm_nt13x2.inc
 
-What it emits (consumed by MlpTileAsm in csrc/ionode_mlp_asm.hpp): two C string macros,
+What it emits (consumed by MlpTile in csrc/ionode_device.hpp): two C string macros (suffix <NT> or <NT>x<NS>),
 
-    IONODE_MLPASM_INIT_<NT>    prime the weight ring with hidden layer 0 (kernel start)
-    IONODE_MLPASM_LAYERS_<NT>  the whole hidden stack of one stage evaluation: for l = 0 .. L-1 one pass of
-                               NT k-tile steps of v_mfma_f32_16x16x4_f32 with the layer boundary software-pipelined
+    IONODE_MLPASM_INIT_*    prime the weight ring with hidden layer 0 (kernel start)
+    IONODE_MLPASM_LAYERS_*  one whole evaluation net([x0, x1]) of the tile: Linear(2, N) + LeakyReLU on the VALU, for
+                            l = 0 .. L-1 one pass of NT k-tile steps of v_mfma_f32_16x16x4_f32 with the layer boundary
+                            software-pipelined, Linear(N, 1) on the VALU
 
-plus register-map constants.  The arithmetic is the canonical accumulation order of ionode_device.hpp (MlpTile::eval):
-every accumulator's chain visits the same (k-tile, k-step) sequence, so the bits do not change; what changes is the order
-in which INDEPENDENT accumulators are interleaved, where the epilogue sits, and who allocates the registers:
+plus the clobber lists.  NS = number of 16-trajectory COLUMN SETS per tile: with NS = 2 (32 trajectories per workgroup,
+launches of at least two 16-tiles per compute unit) every weight fragment feeds two MFMAs -- half the fragment stream per
+FLOP -- and wavefronts 0, 1 carry the Runge-Kutta state of column set 0, wavefronts 2, 3 that of set 1, so the scalar
+integrator work is replicated twice instead of four times per trajectory.  The stage inputs are exchanged through LDS; the
+result is returned for the wavefront's own set.
 
-  * fixed register assignment: weight ring in AGPRs a[0 : 12*NT + 4*NOWN) (loaded by buffer_load straight into AGPRs,
-    read by the MFMAs as srcA), accumulators / bias / B operands / temporaries in v[VB : VB+72); hipcc sees one opaque
-    statement with clobbers and keeps its own values elsewhere -- no AGPR<->VGPR copies, no spills in the stream;
-  * the LAST step of a layer finishes the wavefront's own tile (accumulator 0) and accumulator 1 first; their
-    LeakyReLU + ds_write run in the shadow of the remaining MFMAs of that step;
-  * the FIRST step of the next layer starts on accumulators 0 and 1 (B operand = own tile, from registers, C operand =
-    bias prefetched two steps earlier) while accumulator 2 and the remainder tile's partial sums of the previous layer
-    are post-processed and stored; the workgroup barrier sits in the middle of that step and the first LDS-read B
-    operand is issued right behind it, under the step's second half;
-  * remainder-tile fold, bias prefetch, address bookkeeping: all inside MFMA gaps (<= 4 VALU or 1 LDS + 2 VALU per gap);
-  * s_waitcnt counts are derived by simulation of the in-order vmcnt / lgkmcnt queues (checked: the emitted iteration
-    is a fixed point).
+The arithmetic is the canonical accumulation order of ionode_device.hpp (MlpTile::eval): every accumulator's chain visits
+the same (k-tile, k-step) sequence, so the bits do not change; what changes is the order in which INDEPENDENT
+accumulators are interleaved, where the epilogue sits, and who allocates the registers:
 
-Hazards (probed with hipcc on gfx950, tools/README.md): MFMA result -> VALU / LDS-store read: 10 wait states (here: at least
-two younger MFMAs issued in between = 64 cycles, or explicit s_nop); VALU write -> MFMA operand: 2 wait states;
-dependent MFMA on the same accumulator: interlocked.
+  * fixed register assignment: weight ring in AGPRs (loaded by buffer_load straight into AGPRs, read by the MFMAs as
+    srcA), accumulators / bias / B operands / temporaries in the top VGPRs; hipcc sees one opaque statement with clobbers and
+    keeps its own values elsewhere -- no AGPR<->VGPR copies, no spills in the stream;
+  * the LAST step of a layer finishes the wavefront's own tile (accumulator 0) and accumulator 1 first; the FIRST step of
+    the next layer starts on them (B operand = own tile, from registers, C operand = bias prefetched two steps earlier)
+    while accumulator 2 and the remainder tile's partial sums of the previous layer are post-processed; the workgroup
+    barrier sits in the middle of that step and the first LDS-read B operand is issued right behind it;
+  * measured (tools/ubench/mfma_valu.hip): VALU work does NOT hide under v_mfma_f32_16x16x4_f32 -- the f32 MFMA and the VALU
+    share the SIMD's pipe, every VALU instruction costs its 4+ cycles and the first one behind an MFMA ~10 more -- so side
+    work (LeakyReLU, fold, bookkeeping) is issued in few clusters and its instruction count is what matters;
+  * s_waitcnt counts are derived by simulation of the in-order vmcnt / lgkmcnt queues (the emitted layer pass is a fixed
+    point of the simulation).
+
+Hazards (probed with hipcc on gfx950): MFMA result -> VALU / LDS-store read: 10 wait states (here: at least two younger
+MFMAs issued in between = 64 cycles, or explicit s_nop); VALU write -> MFMA operand: 2 wait states; dependent MFMA on the
+same accumulator: interlocked.
 """
 import argparse
 
@@ -36,37 +44,47 @@ G = 4  # wavefronts per tile
 
 
 class Gen:
-    def __init__(self, nt, pd=7, vb=180, sb=84, stamps=False):
-        assert nt % G == 1 or True
+    def __init__(self, nt, pd=7, ns=1, sb=84, stamps=False):
         self.NT = nt
+        self.NS = ns
         self.F = nt // G
         self.R = nt - G * self.F
         assert self.R == 1 and self.F == 3, "written for N = 200 (NT = 13): three full row tiles + one K-split remainder tile per wavefront"
         self.NOWN = (nt + G - 1) // G
-        self.FRAGS = nt * self.F + self.NOWN * self.R
         self.PD = pd            # ring depth in k-tile steps (slot of step u: u mod PD); NT <= 2 PD
         assert pd <= nt <= 2 * pd
         self.RD = self.NOWN if pd == nt else 2   # ring depth of the remainder fragments (owned steps 0, G, 2G, ...)
         assert self.NOWN % self.RD == 0
         self.ring_regs = 12 * pd + 4 * self.RD
-        self.VB = vb
-        self.SB = sb
-        v = lambda k: vb + k
-        # --- fixed VGPR map ---
-        self.ACC = [v(0), v(4), v(8)]
-        self.ACCR = v(12)
-        self.T = [v(16), v(20), v(24)]
-        self.TR = v(28)
-        self.B = [v(32), v(36)]
-        self.HO = v(40)
-        self.X = v(44)
-        self.Y = v(48)
+        self.HSET, self.PSET = 16 * 1024, 4 * 1024          # LDS bytes between the column sets of an activation / partial-sum buffer
+        # --- fixed VGPR map (top of the file) ---
+        regs = []
+
+        def alloc(n):
+            regs.append(n)
+            return sum(regs) - n
+        self.ACC = [[alloc(4) for _ in range(4)] for _ in range(ns)]       # [set][0..2 full tiles, 3 remainder partial]
+        self.T = [alloc(4) for _ in range(4)]                               # bias of the coming layer (C operands); fold temporaries
+        self.B = [[alloc(4) for _ in range(ns)] for _ in range(2)]          # [buffer][set]
+        self.HO = [alloc(4) for _ in range(ns)]                             # own tile of the coming layer (B operand of step 0)
+        self.X, self.Y = alloc(4), alloc(4)
         names = ["HW_IN", "HW_OUT", "FW_IN", "FW_OUT", "PL_IN", "PL_OUT", "PW_IN", "PW_OUT",
-                 "BIAS_A", "BIAS_R", "VOFF", "DUMMY", "DUP", "LO_TILE", "LO_PART", "FOLDW", "W0A", "W0R", "WLA", "PART"]
-        self.A = {n: v(52 + i) for i, n in enumerate(names)}
-        self.n_vgpr = 76
-        assert 52 + len(names) <= self.n_vgpr and vb + self.n_vgpr <= 256
+                 "BIAS_A", "BIAS_R", "VOFF", "DUMMY", "W0A", "W0R", "WLA", "PART", "TMPA", "XCHW", "XCHR"]
+        for cs in range(ns):
+            names += ["DUP%d" % cs, "LO_TILE%d" % cs, "LO_PART%d" % cs, "FOLDW%d" % cs]
+        self.A = {n: alloc(1) for n in names}
+        self.STAMPV = alloc(1)
+        self.n_vgpr = (sum(regs) + 3) // 4 * 4
+        self.VB = 256 - self.n_vgpr
+        fix = lambda x: x + self.VB
+        self.ACC = [[fix(a) for a in row] for row in self.ACC]
+        self.T = [fix(a) for a in self.T]
+        self.B = [[fix(a) for a in row] for row in self.B]
+        self.HO = [fix(a) for a in self.HO]
+        self.X, self.Y, self.STAMPV = fix(self.X), fix(self.Y), fix(self.STAMPV)
+        self.A = {k: fix(v) for k, v in self.A.items()}
         # --- fixed SGPR map ---
+        self.SB = sb
         s = lambda k: sb + k
         self.S_L = s(0)       # layer counter
         self.S_NL = s(1)      # number of layers
@@ -182,23 +200,29 @@ class Gen:
         self.emit("ds_write_b128 v%d, %s%s" % (self.A[addr], self.vr(src), (" offset:%d" % off) if off else ""))
         return self.ds_issue()
 
-    def lrelu(self, dst, src, r, tmp):
-        """dst[r] = max(src[r], 0.01 * src[r])  (nn.LeakyReLU(0.01): fmaxf(x, x * 0.01f))"""
-        self.emit("v_mul_f32_e32 v%d, s%d, v%d" % (tmp, self.S_C01, src + r))
-        self.emit("v_max_f32_e32 v%d, v%d, v%d" % (dst + r, src + r, tmp))
-
     def lrelu_tile(self, dst, src, tmp):
-        """the four registers of a tile: independent multiplies first, then the maxes"""
+        """dst[r] = max(src[r], 0.01 * src[r]) (nn.LeakyReLU(0.01): fmaxf(x, x * 0.01f)) for the four registers of a tile:
+        independent multiplies first, then the maxes"""
         for r in range(4):
             self.emit("v_mul_f32_e32 v%d, s%d, v%d" % (tmp + r, self.S_C01, src + r))
         for r in range(4):
             self.emit("v_max_f32_e32 v%d, v%d, v%d" % (dst + r, src + r, tmp + r))
 
+    def fold_tile(self, dst, p, tmp):
+        """dst = lrelu((p0 + p1) + (p2 + p3)), the remainder tile's fixed combine tree; p = four register quads (p[0] is overwritten)"""
+        for r in range(4):
+            self.emit("v_add_f32_e32 v%d, v%d, v%d" % (p[0] + r, p[0] + r, p[1] + r))
+        for r in range(4):
+            self.emit("v_add_f32_e32 v%d, v%d, v%d" % (p[2] + r, p[2] + r, p[3] + r))
+        for r in range(4):
+            self.emit("v_add_f32_e32 v%d, v%d, v%d" % (p[0] + r, p[0] + r, p[2] + r))
+        self.lrelu_tile(dst, p[0], tmp)
+
     def stamp(self, idx):
         """diagnostic: add the cycles since the previous stamp to lane idx of a[ring_regs] (drains the LDS queue: lgkmcnt)"""
         if not self.stamps:
             return
-        e, tmp, acc = self.emit, self.VB + self.n_vgpr - 1, self.ring_regs
+        e, tmp, acc = self.emit, self.STAMPV, self.ring_regs
         e("s_memtime s[%d:%d]" % self.S_NOW)
         e("s_waitcnt lgkmcnt(0)")
         self.ds_done = self.ds_seq
@@ -216,88 +240,80 @@ class Gen:
 
     # ---------------- one layer pass ----------------
     def step_mfmas(self, u):
-        """ordered MFMA list of step u: (acc register, ring element e, k-step r, wave-0-only)"""
-        NT = self.NT
+        """ordered MFMA list of step u: (column set, accumulator 0..3, ring element e, k-step r, wave-0-only).  An element e is
+        used by NS consecutive MFMAs (one per column set)."""
+        NT, NS = self.NT, self.NS
         own = (u % G == 0)
         w0only = own and not (u + G - 1 < NT)
         ops = []
-        if u == 0:
+        sets = range(NS)
+        if u == 0 or u == NT - 1:
+            # first the own tile and accumulator 1 (they end a layer early / start the next one from registers), then the rest
             for r in range(4):
-                ops += [(0, 3 * r + 0, r, False), (1, 3 * r + 1, r, False)]
+                for i in (0, 1):
+                    ops += [(cs, i, 3 * r + i, r, False) for cs in sets]
             for r in range(4):
-                ops += [(2, 3 * r + 2, r, False), (3, 12 + r, r, False)]
-        elif u == NT - 1:
-            for r in range(4):
-                ops += [(0, 3 * r + 0, r, False), (1, 3 * r + 1, r, False)]
-            for r in range(4):
-                ops.append((2, 3 * r + 2, r, False))
+                ops += [(cs, 2, 3 * r + 2, r, False) for cs in sets]
                 if own:
-                    ops.append((3, 12 + r, r, w0only))
+                    ops += [(cs, 3, 12 + r, r, w0only) for cs in sets]
         else:
             for r in range(4):
                 for i in range(3):
-                    ops.append((i, 3 * r + i, r, False))
+                    ops += [(cs, i, 3 * r + i, r, False) for cs in sets]
                 if own:
-                    ops.append((3, 12 + r, r, w0only))
+                    ops += [(cs, 3, 12 + r, r, w0only) for cs in sets]
         return ops
 
     def layer(self):
-        NT, A = self.NT, self.A
-        accs = self.ACC + [self.ACCR]
-        X, Y, HO = self.X, self.Y, self.HO
-        T4 = self.T + [self.TR]
-        tmp = Y  # scratch VGPRs of the LeakyReLU multiplies: Y[0..3]
+        NT, NS, A = self.NT, self.NS, self.A
+        X, Y = self.X, self.Y
+        T4 = self.T
+        half = 8 * NS   # MFMAs of the first half of steps 0 and NT-1 (accumulators 0 and 1 of every set)
         for u in range(NT):
             ops = self.step_mfmas(u)
-            # last reader of each fragment of this step (only MFMAs that every wavefront executes count; the wave-0-only
-            # remainder MFMAs of the last owned step come last in their fragment anyway)
             last_use = {}
-            for pos, (ai, e, r, w0) in enumerate(ops):
+            for pos, (cs, ai, e, r, w0) in enumerate(ops):
                 last_use[e // 4 if e < 12 else 3] = pos
             side = {}  # position -> list of callables issued behind that MFMA
 
             def at(pos, fn):
                 side.setdefault(pos, []).append(fn)
 
-            bsrc = HO if u == 0 else self.B[u & 1]
-            # ---- LDS read of the next step's B operand ----
-            if u == 0:
-                pass  # issued behind the barrier (below)
-            elif u + 1 < NT:
-                self.ds_read(self.B[(u + 1) & 1], "HW_IN", (u + 1) * 1024, tag="B%d" % (u + 1))
+            # ---- LDS reads of the next step's B operands ----
+            if 1 <= u and u + 1 < NT:
+                for cs in range(NS):
+                    self.ds_read(self.B[(u + 1) & 1][cs], "HW_IN", cs * self.HSET + (u + 1) * 1024, tag="B%d_%d" % (u + 1, cs))
 
-            # ---- shadow work of this step ----
+            # ---- side work of this step ----
             if u == 0:
                 # leftover of the previous layer: accumulator 2 -> activation tile, remainder partial sums -> Ps
-                # (measured, tools/ubench/mfma_valu.hip: VALU work does NOT hide under v_mfma_f32_16x16x4_f32 -- the f32 MFMA
-                # and the VALU share the SIMD's pipe, each VALU instruction costs its 4+ cycles and the first one behind an
-                # MFMA ~10 more -- so side work is issued in few large clusters, not spread over the gaps)
-                at(2, lambda: [self.lrelu_tile(X, accs[2], tmp), self.ds_write("LO_TILE", X), self.ds_write("LO_PART", self.ACCR)])
+                def leftover():
+                    for cs in range(NS):
+                        self.lrelu_tile(X, self.ACC[cs][2], Y)
+                        self.ds_write("LO_TILE%d" % cs, X)
+                        self.ds_write("LO_PART%d" % cs, self.ACC[cs][3])
+                at(2, leftover)
 
                 def barrier():
                     self.stamp(13)   # first half of step 0
                     self.wait_ds_all()
                     self.emit("s_barrier")
                     self.stamp(14)   # the barrier
-                    self.ds_read(self.B[1], "HW_IN", 1024, tag="B1")
-                at(7, barrier)
-            if u == 1:
-                # fold of the remainder tile: h = lrelu((p0 + p1) + (p2 + p3)) -> slot NT-1 of the input buffer (own copy)
-                at(0, lambda: [self.ds_read(T4[k], "PL_IN", k * 1024, tag="P%d" % k) for k in range(4)])
+                    for cs in range(NS):
+                        self.ds_read(self.B[1][cs], "HW_IN", cs * self.HSET + 1024, tag="B1_%d" % cs)
+                at(half - 1, barrier)
+            if 1 <= u <= NS:
+                # fold of the remainder tile of column set u-1: h = lrelu((p0 + p1) + (p2 + p3)) -> slot NT-1 of the input buffer
+                cs = u - 1
+                at(0, lambda cs=cs: [self.ds_read(T4[k], "PL_IN", cs * self.PSET + k * 1024, tag="P%d" % k) for k in range(4)])
 
-                def fold():
+                def fold(cs=cs):
                     self.wait_ds(self.tag_id["P3"])
-                    for r in range(4):
-                        self.emit("v_add_f32_e32 v%d, v%d, v%d" % (X + r, T4[0] + r, T4[1] + r))
-                    for r in range(4):
-                        self.emit("v_add_f32_e32 v%d, v%d, v%d" % (Y + r, T4[2] + r, T4[3] + r))
-                    for r in range(4):
-                        self.emit("v_add_f32_e32 v%d, v%d, v%d" % (X + r, X + r, Y + r))
-                    self.lrelu_tile(X, X, Y)
-                    self.ds_write("FOLDW", X)
-                at(5, fold)
+                    self.fold_tile(X, T4, Y)
+                    self.ds_write("FOLDW%d" % cs, X)
+                at(5 * NS, fold)
             if u == NT - 3:
-                # bias of the next layer -> T (C operands of its first MFMAs)
+                # bias of the next layer -> T (C operands of its first MFMAs, shared by the column sets)
                 at(0, lambda: [self.emit("v_add_u32_e32 v%d, %d, v%d" % (A["BIAS_A"], 16 * NT * 4, A["BIAS_A"])),
                                self.emit("v_add_u32_e32 v%d, %d, v%d" % (A["BIAS_R"], 16 * NT * 4, A["BIAS_R"])),
                                self.ds_read(T4[0], "BIAS_A", 0, tag="T0"), self.ds_read(T4[1], "BIAS_A", 256, tag="T1"),
@@ -306,15 +322,22 @@ class Gen:
                 def mask_tr():
                     self.wait_ds(self.tag_id["T3"])
                     for r in range(4):  # partial sum 0 carries the bias, the others start from +0
-                        self.emit("v_cndmask_b32_e64 v%d, 0, v%d, s[%d:%d]" % (self.TR + r, self.TR + r, self.S_W0[0], self.S_W0[1]))
+                        self.emit("v_cndmask_b32_e64 v%d, 0, v%d, s[%d:%d]" % (T4[3] + r, T4[3] + r, self.S_W0[0], self.S_W0[1]))
+                    # duplicate slot of the own tile (tiles 0..2 are stored twice: rotated reads at immediate offsets)
+                    for cs in range(NS):
+                        self.emit("v_add_u32_e32 v%d, %d, v%d" % (A["DUP%d" % cs], cs * self.HSET + NT * 1024, A["HW_OUT"]))
+                        self.emit("v_cndmask_b32_e64 v%d, v%d, v%d, s[%d:%d]" % (A["DUP%d" % cs], A["DUMMY"], A["DUP%d" % cs], self.S_W3[0], self.S_W3[1]))
                 at(3, mask_tr)
-                # duplicate slot of the own tile (tiles 0..2 are stored twice: rotated reads at immediate offsets)
-                at(3, lambda: [self.emit("v_add_u32_e32 v%d, %d, v%d" % (A["DUP"], NT * 1024, A["HW_OUT"])),
-                               self.emit("v_cndmask_b32_e64 v%d, v%d, v%d, s[%d:%d]" % (A["DUP"], A["DUMMY"], A["DUP"], self.S_W3[0], self.S_W3[1]))])
             if u == NT - 1:
-                # own tile (accumulator 0) and accumulator 1 are complete after position 7
-                at(10, lambda: [self.lrelu_tile(HO, accs[0], tmp), self.ds_write("HW_OUT", HO), self.ds_write("DUP", HO),
-                               self.lrelu_tile(X, accs[1], tmp), self.ds_write("HW_OUT", X, 4096)])
+                # own tile (accumulator 0) and accumulator 1 are complete after the first half
+                def early():
+                    for cs in range(NS):
+                        self.lrelu_tile(self.HO[cs], self.ACC[cs][0], Y)
+                        self.ds_write("HW_OUT", self.HO[cs], cs * self.HSET)
+                        self.ds_write("DUP%d" % cs, self.HO[cs])
+                        self.lrelu_tile(X, self.ACC[cs][1], Y)
+                        self.ds_write("HW_OUT", X, cs * self.HSET + 4096)
+                at(half + 2, early)
 
             # ---- refills: right behind the last MFMA that reads the fragment ----
             for k, pos in last_use.items():
@@ -322,60 +345,61 @@ class Gen:
 
             # ---- emission ----
             if u >= 1:
-                self.wait_ds(self.tag_id["B%d" % u])
+                for cs in range(NS):
+                    self.wait_ds(self.tag_id["B%d_%d" % (u, cs)])
             if u == NT - 1:
-                # positions 8.. of the last step differ between wave 0 (K-slice owner) and the others: two bodies
-                self.emit_ops(u, ops[:8], 0, side, bsrc, accs, T4)
-                tail = ops[8:]
+                # the second half of the last step differs between wave 0 (K-slice owner) and the others: two bodies
+                self.emit_ops(u, ops[:half], 0, side)
+                tail = ops[half:]
                 lbl = "%="
                 self.emit("s_cmp_eq_u64 s[%d:%d], 0" % self.S_W0)
                 self.emit("s_cbranch_scc1 .Lnw0_" + lbl)
                 st = (self.ds_seq, self.ds_done, self.vm_seq, self.vm_done, dict(self.ring_id), dict(self.tag_id))
-                self.emit_ops(u, tail, 8, side, bsrc, accs, T4, dense=True)
+                self.emit_ops(u, tail, half, side)
                 self.emit("s_branch .Ljoin_" + lbl)
                 end0 = (self.ds_seq, self.ds_done, self.vm_seq, self.vm_done)
                 self.emit(".Lnw0_" + lbl + ":")
                 (self.ds_seq, self.ds_done, self.vm_seq, self.vm_done, self.ring_id, self.tag_id) = st
-                self.emit_ops(u, [o for o in tail if not o[3]], 8, side, bsrc, accs, T4, dense=True, renumber=tail)
+                self.emit_ops(u, [o for o in tail if not o[4]], half, side, renumber=tail)
                 assert (end0[0], end0[2]) == (self.ds_seq, self.vm_seq), "both bodies must issue the same memory operations"
                 self.ds_done, self.vm_done = min(self.ds_done, end0[1]), min(self.vm_done, end0[3])  # what both guarantee
                 self.emit(".Ljoin_" + lbl + ":")
             else:
-                self.emit_ops(u, ops, 0, side, bsrc, accs, T4)
+                self.emit_ops(u, ops, 0, side)
             self.stamp(u)
 
-    def emit_ops(self, u, ops, pos0, side, bsrc, accs, T4, dense=False, renumber=None):
+    def emit_ops(self, u, ops, pos0, side, renumber=None):
         """MFMAs of a step from position pos0 on, each followed by its side work.  `renumber`: the full op list whose
         positions the side table refers to (body without the wave-0-only MFMAs: side work of a skipped position is issued
         behind the previous emitted MFMA)."""
         full = renumber if renumber is not None else ops
-        pending = []
-        idx = 0
         for k, op in enumerate(full):
             pos = pos0 + k
             present = op in ops if renumber is not None else True
             if present:
-                ai, e, r, w0 = op
+                cs, ai, e, r, w0 = op
                 key = (u, e // 4 if e < 12 else 3)
                 self.wait_vm(self.ring_id[key])
                 c = None
                 if u == 0 and r == 0:
-                    c = T4[ai]
+                    c = self.T[ai]
                     self.wait_ds(self.tag_id["T%d" % ai])
-                self.mfma(accs[ai], self.areg(u, e), bsrc + r, c)
+                bsrc = self.HO[cs] if u == 0 else self.B[u & 1][cs]
+                self.mfma(self.ACC[cs][ai], self.areg(u, e), bsrc + r, c)
             for fn in side.get(pos, []):
                 fn()
 
     # ---------------- whole statements ----------------
     def gen_layers(self):
-        A = self.A
+        A, NS, NT = self.A, self.NS, self.NT
         self.lines = []
         e = self.emit
         lbl = "%="
+        T4 = self.T
         # ---- entry ----
         e("s_waitcnt lgkmcnt(0)")
         ins = ["HW_IN", "HW_OUT", "FW_IN", "FW_OUT", "PL_IN", "PL_OUT", "PW_IN", "PW_OUT", "BIAS_A", "BIAS_R", "VOFF", "DUMMY",
-               "W0A", "W0R", "WLA"]
+               "W0A", "W0R", "WLA"] + (["XCHW", "XCHR"] if NS > 1 else [])
         for n in ins:
             e("v_mov_b32_e32 v%d, %%[%s]" % (A[n], n.lower()))
         e("s_mov_b32 s%d, 0" % self.S_L)
@@ -387,18 +411,41 @@ class Gen:
         e("s_cselect_b64 s[%d:%d], -1, 0" % self.S_W0)
         e("s_cmp_lt_u32 %[wave], 3")
         e("s_cselect_b64 s[%d:%d], -1, 0" % self.S_W3)
-        for n in ("LO_TILE", "LO_PART", "FOLDW"):
-            e("v_mov_b32_e32 v%d, v%d" % (A[n], A["DUMMY"]))
-        e("v_add_u32_e32 v%d, %d, v%d" % (A["DUP"], self.NT * 1024, A["HW_IN"]))
-        e("v_cndmask_b32_e64 v%d, v%d, v%d, s[%d:%d]" % (A["DUP"], A["DUMMY"], A["DUP"], self.S_W3[0], self.S_W3[1]))
-        T4 = self.T + [self.TR]
+        self.reset_counters()
+        # ---- the stage inputs of every column set.  NS == 1: the statement's own operands.  NS > 1: each wavefront holds the inputs of
+        # ITS set (lane 16 q + j: trajectory j); they are exchanged through LDS [set][16] x {x0, x1} behind one barrier.
+        xin = []
+        if NS == 1:
+            xin = [("%[x0]", "%[x1]")]
+        else:
+            e("v_mov_b32_e32 v%d, %%[x0]" % X_(self, 0))
+            e("v_mov_b32_e32 v%d, %%[x1]" % X_(self, 1))
+            e("ds_write_b64 v%d, v[%d:%d]" % (A["XCHW"], X_(self, 0), X_(self, 1)))
+            self.ds_issue()
+            self.wait_ds_all()
+            e("s_barrier")
+            assert NS == 2
+            ids = []
+            for cs in range(NS):
+                e("ds_read_b64 v[%d:%d], v%d offset:%d" % (self.X + 2 * cs, self.X + 2 * cs + 1, A["XCHR"], 128 * cs))
+                ids.append(self.ds_issue())
+            xin = [("v%d" % (self.X + 2 * cs), "v%d" % (self.X + 2 * cs + 1)) for cs in range(NS)]
+            self.xwait = ids[-1]
+        for cs in range(NS):
+            for n in ("LO_TILE", "LO_PART", "FOLDW"):
+                e("v_mov_b32_e32 v%d, v%d" % (A["%s%d" % (n, cs)], A["DUMMY"]))
+            e("v_add_u32_e32 v%d, %d, v%d" % (A["DUP%d" % cs], cs * self.HSET + NT * 1024, A["HW_IN"]))
+            e("v_cndmask_b32_e64 v%d, v%d, v%d, s[%d:%d]" % (A["DUP%d" % cs], A["DUMMY"], A["DUP%d" % cs], self.S_W3[0], self.S_W3[1]))
         # ---- layer 0: Linear(2, N) + LeakyReLU on the VALU, h = lrelu(fmaf(w1, x1, fmaf(w0, x0, b))); rows {b, w0, w1, 0} in LDS.
         # Row tiles wave, wave + 4, wave + 8 (own tile -> HO and the B operand of step 0) and the remainder tile (every
-        # wavefront writes it: identical bits).  Two 16-register row buffers: the next tile's rows are in flight meanwhile.
-        self.reset_counters()
-        RB = [T4, [self.B[0], self.B[1], self.X, self.Y]]
-        tiles = [("W0A", 0, self.HO, [("HW_IN", 0), ("DUP", 0)]), ("W0A", 1024, self.ACC[0], [("HW_IN", 4096)]),
-                 ("W0A", 2048, self.ACC[1], [("HW_IN", 8192)]), ("W0R", 0, self.ACC[2], [("FW_IN", 0)])]
+        # wavefront writes it: identical bits), for every column set.  Two 16-register row buffers: the next tile's rows are in
+        # flight meanwhile.  t -> Y, 0.01 t -> the rows' zero pad (so the rows survive for the next column set).
+        rb1 = [q for row in self.B for q in row]
+        if NS == 1:
+            rb1 = rb1 + [self.X, self.Y]          # NS == 1: X is free (the inputs are operands); Y is the t temporary -> use ACC quads instead
+            rb1 = [self.B[0][0], self.B[1][0], self.X, self.ACC[0][3]]
+        RB = [T4, rb1[:4]]
+        tiles = [("W0A", 0, None, 0), ("W0A", 1024, 0, 4096), ("W0A", 2048, 1, 8192), ("W0R", 0, 2, None)]
         rd = {}
 
         def l0_reads(ti):
@@ -406,21 +453,33 @@ class Gen:
             rd[ti] = [self.ds_read(RB[ti & 1][r], areg, off + 16 * r) for r in range(4)]
         l0_reads(0)
         l0_reads(1)
-        for ti, (areg, off, dst, stores) in enumerate(tiles):
+        if NS > 1:
+            self.wait_ds(self.xwait)
+        for ti, (areg, off, acci, hoff) in enumerate(tiles):
             rows = RB[ti & 1]
             self.wait_ds(rd[ti][3])
-            for r in range(4):
-                e("v_fma_f32 v%d, v%d, %%[x0], v%d" % (rows[r], rows[r] + 1, rows[r]))
-            for r in range(4):
-                e("v_fma_f32 v%d, v%d, %%[x1], v%d" % (rows[r], rows[r] + 2, rows[r]))
-            for r in range(4):
-                e("v_mul_f32_e32 v%d, s%d, v%d" % (rows[r] + 3, self.S_C01, rows[r]))
-            for r in range(4):
-                e("v_max_f32_e32 v%d, v%d, v%d" % (dst + r, rows[r], rows[r] + 3))
+            for cs in range(NS):
+                x0, x1 = xin[cs]
+                dst = self.HO[cs] if acci is None else self.ACC[cs][acci]
+                for r in range(4):
+                    e("v_fma_f32 v%d, v%d, %s, v%d" % (self.Y + r, rows[r] + 1, x0, rows[r]))
+                for r in range(4):
+                    e("v_fma_f32 v%d, v%d, %s, v%d" % (self.Y + r, rows[r] + 2, x1, self.Y + r))
+                for r in range(4):
+                    e("v_mul_f32_e32 v%d, s%d, v%d" % (rows[r] + 3, self.S_C01, self.Y + r))
+                for r in range(4):
+                    e("v_max_f32_e32 v%d, v%d, v%d" % (dst + r, self.Y + r, rows[r] + 3))
             if ti + 2 < len(tiles):
                 l0_reads(ti + 2)
-            for (areg2, off2) in stores:
-                self.ds_write(areg2, dst, off2)
+            for cs in range(NS):
+                dst = self.HO[cs] if acci is None else self.ACC[cs][acci]
+                if acci is None:
+                    self.ds_write("HW_IN", dst, cs * self.HSET)
+                    self.ds_write("DUP%d" % cs, dst)
+                elif hoff is not None:
+                    self.ds_write("HW_IN", dst, cs * self.HSET + hoff)
+                else:
+                    self.ds_write("FW_IN", dst, cs * self.HSET)
         # bias of hidden layer 0 -> C operands of its first MFMAs
         e("ds_read_b128 %s, v%d" % (self.vr(T4[0]), A["BIAS_A"]))
         e("ds_read_b128 %s, v%d offset:256" % (self.vr(T4[1]), A["BIAS_A"]))
@@ -428,7 +487,7 @@ class Gen:
         e("ds_read_b128 %s, v%d" % (self.vr(T4[3]), A["BIAS_R"]))
         e("s_waitcnt lgkmcnt(0)")
         for r in range(4):
-            e("v_cndmask_b32_e64 v%d, 0, v%d, s[%d:%d]" % (self.TR + r, self.TR + r, self.S_W0[0], self.S_W0[1]))
+            e("v_cndmask_b32_e64 v%d, 0, v%d, s[%d:%d]" % (T4[3] + r, T4[3] + r, self.S_W0[0], self.S_W0[1]))
         e("s_mov_b32 s%d, s%d" % (self.S_LNEXT, self.S_H0))  # refill source of layer l: layer l + 1, or layer 0 after the last
         self.stamp(15)   # everything outside the layer loop
         e(".Lloop_" + lbl + ":")
@@ -438,15 +497,13 @@ class Gen:
         e("s_add_u32 s%d, s%d, 1" % (self.S_T, self.S_L))
         e("s_cmp_lt_u32 s%d, s%d" % (self.S_T, self.S_NL))
         e("s_cselect_b32 s%d, s%d, s%d" % (self.S_LNEXT, self.S_LNEXT, self.S_H0))
-        head = len(self.lines)
         # ---- the layer body: simulate to the fixed point of the wait counts, emit the fixed point ----
         self.reset_counters()
-        # ring as primed by init / left by the previous pass: loads in refill order of a pass
         body = None
         for it in range(3):
             start = len(self.lines)
             if it == 0:
-                for (u, k) in self.refill_order():
+                for (u, k) in self.refill_order():   # ring as primed by init / left by the previous pass
                     where, ut = self.refill_target(u, k)
                     if where == "next":
                         self.vm_seq += 1
@@ -470,25 +527,36 @@ class Gen:
         # ---- exit: the last layer's accumulator 2 and partial sums (not pipelined: nothing follows) ----
         e("s_nop 7")
         e("s_nop 1")
-        self.lrelu_tile(self.X, self.ACC[2], self.Y)
-        e("ds_write_b128 v%d, %s" % (A["LO_TILE"], self.vr(self.X)))
-        e("ds_write_b128 v%d, %s" % (A["LO_PART"], self.vr(self.ACCR)))
+        for cs in range(NS):
+            self.lrelu_tile(self.X, self.ACC[cs][2], self.Y)
+            e("ds_write_b128 v%d, %s" % (A["LO_TILE%d" % cs], self.vr(self.X)))
+            e("ds_write_b128 v%d, %s" % (A["LO_PART%d" % cs], self.vr(self.ACC[cs][3])))
         e("s_waitcnt lgkmcnt(0)")
         e("s_barrier")
         self.stamp(12)  # (diagnostic: charged to the last step)
-        # ---- Linear(N, 1): four partial fmaf chains (one per lane group q) over kt, r; fixed combine tree ((p0+p1)+(p2+p3)) + bl.
-        # After the last swap the *_IN names are the buffers the last hidden layer wrote.
+        # ---- Linear(N, 1) for the wavefront's OWN column set: four partial fmaf chains (one per lane group q) over kt, r; fixed
+        # combine tree ((p0+p1)+(p2+p3)) + bl.  After the last swap the *_IN names are the buffers the last hidden layer wrote;
+        # %[own_h] / %[own_p] are the own set's byte offsets inside an activation / partial-sum buffer (0 for NS == 1).
         self.reset_counters()
-        PART, TMP = A["PART"], A["LO_TILE"]
-        e("v_add_u32_e32 v%d, %d, v%d" % (A["LO_PART"], -(self.NT - 1) * 1024 & 0xffffffff, A["FW_IN"]))  # slot 0 of the buffer, this lane
-        HB = "LO_PART"
-        # register quads free here: the accumulators, the bias quads, both B buffers, HO, X, Y
-        Q = [self.ACC[0], self.ACC[1], self.ACC[2], self.ACCR, T4[0], T4[1], T4[2], T4[3], self.B[0], self.B[1], self.HO, self.X, self.Y]
-        NTF = self.NT - 1   # tiles 0 .. NT-2 are activations; tile NT-1 is folded from the partial sums
-        # remainder tile first (its result waits in HO): h = lrelu((p0 + p1) + (p2 + p3)), weights wl[16 (NT-1) + 4 q + r] in TR
+        PART, TMP, HBv, PLv = A["PART"], A["TMPA"], A["XCHW"], A["XCHR"]
+        e("v_add_u32_e32 v%d, %d, v%d" % (HBv, -(NT - 1) * 1024 & 0xffffffff, A["FW_IN"]))  # slot 0 of the buffer, this lane
+        e("v_mov_b32_e32 v%d, v%d" % (PLv, A["PL_IN"]))
+        if NS > 1:
+            e("v_add_u32_e32 v%d, %%[own_h], v%d" % (HBv, HBv))
+            e("v_add_u32_e32 v%d, %%[own_p], v%d" % (PLv, PLv))
+        # register quads free here: the accumulators, the bias quads, the B buffers, HO, X, Y
+        Q = [a for row in self.ACC for a in row] + T4 + [q for row in self.B for q in row] + self.HO + [self.X, self.Y]
+        if NS == 1:
+            Q = self.ACC[0] + T4 + [self.B[0][0], self.B[1][0], self.HO[0], self.X, self.Y]
+        else:
+            Q = self.ACC[0] + T4 + [self.B[0][0], self.B[1][0], self.HO[0], self.X, self.Y]
+        NTF = NT - 1   # tiles 0 .. NT-2 are activations; tile NT-1 is folded from the partial sums
         pr = [Q[8], Q[9], Q[11], Q[12]]
-        idp = [self.ds_read(pr[k], "PL_IN", k * 1024) for k in range(4)]
-        idw12 = self.ds_read(Q[7], "WLA", (self.NT - 1) * 64)
+        idp = []
+        for k in range(4):
+            e("ds_read_b128 %s, v%d offset:%d" % (self.vr(pr[k]), PLv, k * 1024))
+            idp.append(self.ds_issue())
+        idw12 = self.ds_read(Q[7], "WLA", (NT - 1) * 64)
         grpA = [(Q[0], Q[4]), (Q[1], Q[5]), (Q[2], Q[6])]
         grpB = [(Q[3], Q[8]), (Q[9], Q[11])]
         groups = []
@@ -502,17 +570,12 @@ class Gen:
 
         def ll_reads(gi):
             for (k, hreg, wreg) in groups[gi]:
-                ids[(k, "h")] = self.ds_read(hreg, HB, k * 1024)
+                e("ds_read_b128 %s, v%d offset:%d" % (self.vr(hreg), HBv, k * 1024))
+                ids[(k, "h")] = self.ds_issue()
                 ids[(k, "w")] = self.ds_read(wreg, "WLA", k * 64)
         ll_reads(0)
         self.wait_ds(idp[3])
-        for r in range(4):
-            e("v_add_f32_e32 v%d, v%d, v%d" % (pr[0] + r, pr[0] + r, pr[1] + r))
-        for r in range(4):
-            e("v_add_f32_e32 v%d, v%d, v%d" % (pr[2] + r, pr[2] + r, pr[3] + r))
-        for r in range(4):
-            e("v_add_f32_e32 v%d, v%d, v%d" % (pr[0] + r, pr[0] + r, pr[2] + r))
-        self.lrelu_tile(self.HO, pr[0], pr[1])
+        self.fold_tile(Q[10], pr, Q[12])   # -> Q[10] (HO quad); pr[3] = Q[12] doubles as the LeakyReLU temporary after the sums
         e("v_mov_b32_e32 v%d, 0" % PART)
         for gi, grp in enumerate(groups):
             if gi + 1 < len(groups):
@@ -523,7 +586,7 @@ class Gen:
                     e("v_fmac_f32_e32 v%d, v%d, v%d" % (PART, wreg + r, hreg + r))
         self.wait_ds(idw12)
         for r in range(4):
-            e("v_fmac_f32_e32 v%d, v%d, v%d" % (PART, Q[7] + r, self.HO + r))
+            e("v_fmac_f32_e32 v%d, v%d, v%d" % (PART, Q[7] + r, Q[10] + r))
         # pair = part + part[lane ^ 16]; out = (pair + pair[lane ^ 32]) + bl   (swap both copies, add: commutative, same bits)
         e("v_mov_b32_e32 v%d, v%d" % (TMP, PART))
         e("s_nop 1")
@@ -544,9 +607,14 @@ class Gen:
     def bookkeeping(self):
         """end of a layer pass: where the leftover of this layer goes, and the in/out swap of the double buffers"""
         A, e = self.A, self.emit
-        e("v_add_u32_e32 v%d, %d, v%d" % (A["LO_TILE"], 8192, A["HW_OUT"]))
-        e("v_mov_b32_e32 v%d, v%d" % (A["LO_PART"], A["PW_OUT"]))
-        e("v_mov_b32_e32 v%d, v%d" % (A["FOLDW"], A["FW_OUT"]))
+        for cs in range(self.NS):
+            e("v_add_u32_e32 v%d, %d, v%d" % (A["LO_TILE%d" % cs], cs * self.HSET + 8192, A["HW_OUT"]))
+            if cs == 0:
+                e("v_mov_b32_e32 v%d, v%d" % (A["LO_PART%d" % cs], A["PW_OUT"]))
+                e("v_mov_b32_e32 v%d, v%d" % (A["FOLDW%d" % cs], A["FW_OUT"]))
+            else:
+                e("v_add_u32_e32 v%d, %d, v%d" % (A["LO_PART%d" % cs], cs * self.PSET, A["PW_OUT"]))
+                e("v_add_u32_e32 v%d, %d, v%d" % (A["FOLDW%d" % cs], cs * self.HSET, A["FW_OUT"]))
         for a, b in (("HW_IN", "HW_OUT"), ("FW_IN", "FW_OUT"), ("PL_IN", "PL_OUT"), ("PW_IN", "PW_OUT")):
             e("v_swap_b32 v%d, v%d" % (A[a], A[b]))
 
@@ -556,9 +624,8 @@ class Gen:
         for u in range(self.NT):
             ops = self.step_mfmas(u)
             last_use = {}
-            for pos, (ai, e, r, w0) in enumerate(ops):
+            for pos, (cs, ai, e, r, w0) in enumerate(ops):
                 last_use[e // 4 if e < 12 else 3] = pos
-            # same traversal as layer(): by position, then insertion order of `at`
             bypos = {}
             for k, pos in last_use.items():
                 bypos.setdefault(pos, []).append(k)
@@ -583,6 +650,10 @@ class Gen:
         return self.lines
 
 
+def X_(g, k):
+    return g.Y + k   # scratch pair for the input exchange
+
+
 def cstring(lines):
     return "\n".join('  "%s\\n\\t"' % l for l in lines)
 
@@ -591,26 +662,29 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--nt", type=int, default=13)
     ap.add_argument("--pd", type=int, default=7)
+    ap.add_argument("--ns", type=int, default=1, help="16-trajectory column sets per tile (1 or 2)")
     ap.add_argument("--stamps", action="store_true")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
-    g = Gen(a.nt, a.pd, stamps=a.stamps)
+    g = Gen(a.nt, a.pd, a.ns, stamps=a.stamps)
     layers = list(g.gen_layers())
-    init = list(Gen(a.nt, a.pd, stamps=a.stamps).gen_init())
+    init = list(Gen(a.nt, a.pd, a.ns, stamps=a.stamps).gen_init())
     nmf = sum(1 for l in layers if l.startswith("v_mfma"))
+    sfx = "%d" % a.nt + ("x%d" % a.ns if a.ns > 1 else "")
     with open(a.out, "w") as f:
-        f.write("// GENERATED by tools/gen_mlp_asm.py --nt %d -- do not edit.\n" % a.nt)
-        f.write("// %d instructions, %d MFMAs in the layer body (both bodies of the last step counted).\n" % (len(layers), nmf))
-        f.write("#define IONODE_MLPASM_VB_%d %d\n" % (a.nt, g.VB))
-        f.write("#define IONODE_MLPASM_RING_REGS_%d %d\n" % (a.nt, g.ring_regs))
-        f.write("#define IONODE_MLPASM_INIT_%d \\\n%s\n" % (a.nt, cstring(init).replace("\n", " \\\n")))
-        f.write("#define IONODE_MLPASM_LAYERS_%d \\\n%s\n" % (a.nt, cstring(layers).replace("\n", " \\\n")))
-        vclob = ", ".join('"v%d"' % r for r in range(g.VB, g.VB + g.n_vgpr))
+        f.write("// GENERATED by tools/gen_mlp_asm.py --nt %d --pd %d --ns %d -- do not edit.\n" % (a.nt, a.pd, a.ns))
+        f.write("// %d instructions, %d MFMAs in the layer body (both bodies of the last step counted); working set v[%d:255], ring a[0:%d].\n"
+                % (len(layers), nmf, g.VB, g.ring_regs - 1))
+        f.write("#define IONODE_MLPASM_VB_%s %d\n" % (sfx, g.VB))
+        f.write("#define IONODE_MLPASM_RING_REGS_%s %d\n" % (sfx, g.ring_regs))
+        f.write("#define IONODE_MLPASM_INIT_%s \\\n%s\n" % (sfx, cstring(init).replace("\n", " \\\n")))
+        f.write("#define IONODE_MLPASM_LAYERS_%s \\\n%s\n" % (sfx, cstring(layers).replace("\n", " \\\n")))
+        vclob = ", ".join('"v%d"' % r for r in range(g.VB, 256))
         aclob = ", ".join('"a%d"' % r for r in range(g.ring_regs + (1 if a.stamps else 0)))
         sclob = ", ".join('"s%d"' % r for r in range(g.SB, g.SB + g.n_sgpr))
-        f.write("#define IONODE_MLPASM_CLOBBER_V_%d %s\n" % (a.nt, vclob))
-        f.write("#define IONODE_MLPASM_CLOBBER_A_%d %s\n" % (a.nt, aclob))
-        f.write("#define IONODE_MLPASM_CLOBBER_S_%d %s\n" % (a.nt, sclob))
+        f.write("#define IONODE_MLPASM_CLOBBER_V_%s %s\n" % (sfx, vclob))
+        f.write("#define IONODE_MLPASM_CLOBBER_A_%s %s\n" % (sfx, aclob))
+        f.write("#define IONODE_MLPASM_CLOBBER_S_%s %s\n" % (sfx, sclob))
 
 
 if __name__ == "__main__":
