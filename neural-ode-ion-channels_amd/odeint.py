@@ -10,8 +10,12 @@ RHS modules (rhs.py) are integrated by the fused HIP kernel.  `func` is read at 
 
 Gradients.  Called with autograd enabled and a `func.net` parameter, a tensor-valued rate parameter or `y0` requiring
 grad, the result carries a graph: the backward sweep of grad.py (exact derivative of the executed discretisation, accepted
-steps as constants).  `odeint_adjoint` is the same function -- the reference's --adjoint flag only switches the import
-(train-s1.py:29-32) and never differentiates, so there is no separate adjoint behaviour to mirror.  All RHS families of the reference are covered (NN-f / NN-d for the widths of architectures
+steps as constants).  `odeint_adjoint` returns the same values and, when a gradient is requested, differentiates a step
+sequence capped at grad.stable_step_cap() (3 / lambda_max of the rate constants) unless the caller sets max_step: like
+torchdiffeq's continuous adjoint, that derivative stays bounded on long holds and converges to the continuous adjoint as
+rtol -> 0, whereas the exact derivative of the UNcapped sequence (odeint) amplifies rounding noise at equilibria (grad.py).
+The reference's --adjoint flag only switches the import (train-s1.py:29-32) and never differentiates, so there is no
+reference behaviour to mirror beyond the forward values.  All RHS families of the reference are covered (NN-f / NN-d for the widths of architectures
 s00-s11 with at most 15 hidden layers; HH 2-state and 6-state in closed form); other shapes raise instead of silently returning a
 graph-less tensor.
 
@@ -126,8 +130,18 @@ def _odeint_with_grad(func, y0, t, spec, rtol, atol, options):
 
 def odeint_adjoint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, event_fn=None,
                    adjoint_rtol=None, adjoint_atol=None, adjoint_method=None, adjoint_options=None, adjoint_params=None):
-    """The reference's --adjoint flag only switches this import (train-s1.py:29-32); every call site runs under
-    torch.no_grad() and never differentiates through the solve (SURVEY.md finding 3).  Same values and the same gradient
-    path as `odeint` (module docstring); torchdiffeq's adjoint_* knobs tune its continuous adjoint ODE and have no
-    counterpart in the discrete sweep -- they are accepted and ignored."""
+    """`from torchdiffeq import odeint_adjoint as odeint` (train-s1.py:29-32).  Under torch.no_grad() -- every call site of the
+    reference (SURVEY.md finding 3) -- this IS odeint: same kernel, same bits.
+
+    With a gradient requested it is the STABILISED sweep: the forward solve runs with dt capped at grad.stable_step_cap()
+    (3 / lambda_max of the gating rates at the protocol's extreme voltages; `options={"max_step": ...}` or
+    `adjoint_options={"max_step": ...}` override, 0 switches the cap off) and the backward sweep differentiates that step
+    sequence.  What torchdiffeq's continuous adjoint buys -- a gradient that stays bounded where dopri5 coasts through an
+    equilibrium with h * lambda >> 1 -- is obtained this way without re-integrating the state backwards (unstable for
+    these dissipative gating equations); the capped discrete gradient converges to the continuous adjoint as rtol -> 0
+    (tests/test_gpu_round3.py::test_odeint_adjoint_is_the_stabilised_sweep).  torchdiffeq's other adjoint_* knobs tune its
+    adjoint ODE solve and have no counterpart here: accepted and ignored."""
+    options = dict(options or {})
+    if torch.is_grad_enabled() and _wants_grad(func, y0) and "max_step" not in options:
+        options["max_step"] = (adjoint_options or {}).get("max_step", "auto")
     return odeint(func, y0, t, rtol=rtol, atol=atol, method=method, options=options, event_fn=event_fn)

@@ -215,3 +215,48 @@ def test_six_state_two_per_simd_build_at_large_batches(ion, gpu, oracle, f32):
                          prot_of_traj=pot[pick], nthreads=8, state_f32=f32)
         assert np.array_equal(sol.y[pick].double().cpu().numpy(), o["y"]) and np.array_equal(sol.stats[pick].cpu().numpy(), o["stats"])
         assert torch.equal(sol.y[: B // 2], sol.y[B // 2:]) and bool((sol.status == 0).all())
+
+
+def test_odeint_adjoint_is_the_stabilised_sweep(ion, gpu):
+    """`from torchdiffeq import odeint_adjoint` (train-s1.py:29-32).  Without a gradient request: odeint's bits.  With one: the step
+    sequence is capped at 3 / lambda_max, so the rate-parameter gradient of a long hold stays bounded in fp32 state and no warning is
+    raised; as the tolerance tightens the capped discrete gradient converges (to the continuous adjoint's value): rtol 1e-7 against
+    rtol 1e-10 agree to 1e-4 relative, and both agree with central finite differences of the forward solve."""
+    import ref_style_modules as M
+    from torchdiffeq import odeint, odeint_adjoint
+    tp = np.arange(0.0, 6000.1, 0.5)
+    vp = np.full(tp.size, -80.0)
+    vp[(tp >= 200) & (tp < 1200)] = 30.0                          # 1 s step, then a 4.8 s hold at -80 mV
+    te = torch.arange(0.0, 6000.0, 25.0)
+
+    def make(dtype, p7=None):
+        f = M.HodgkinHuxley(K.P_HH)
+        f.set_fixed_form_voltage_protocol(tp, vp)
+        f.p7 = torch.tensor(float(K.P_HH[6]) if p7 is None else p7, dtype=torch.float64, requires_grad=True)
+        return f, torch.tensor([[0.0, 1.0]], dtype=dtype)
+
+    f, y0 = make(torch.float32)
+    with torch.no_grad():
+        assert torch.equal(odeint_adjoint(f, y0, te), odeint(f, y0, te))
+    grads = {}
+    for dtype, rtol in ((torch.float32, 1e-7), (torch.float64, 1e-7), (torch.float64, 1e-10)):
+        f, y0 = make(dtype)
+        with warnings.catch_warnings():
+            warnings.simplefilter("error", RuntimeWarning)
+            y = odeint_adjoint(f, y0, te.to(dtype), rtol=rtol, atol=rtol * 1e-2)
+        (y[:, 0, 0] * y[:, 0, 1]).double().sum().backward()
+        grads[(dtype, rtol)] = float(f.p7.grad)
+        assert np.isfinite(grads[(dtype, rtol)])
+    ref = grads[(torch.float64, 1e-10)]
+    assert abs(grads[(torch.float64, 1e-7)] - ref) <= 1e-4 * abs(ref), grads
+    assert abs(grads[(torch.float32, 1e-7)] - ref) <= 2e-2 * abs(ref), grads
+    # central finite differences of the (capped, tight) forward solve
+    h = 1e-4 * float(K.P_HH[6])
+    vals = []
+    for dp in (+h, -h):
+        f, y0 = make(torch.float64, float(K.P_HH[6]) + dp)
+        with torch.no_grad():
+            y = odeint(f, y0, te.double(), rtol=1e-11, atol=1e-13, options={"max_step": "auto"})
+        vals.append(float((y[:, 0, 0] * y[:, 0, 1]).sum()))
+    fd = (vals[0] - vals[1]) / (2 * h)
+    assert abs(fd - ref) <= 1e-4 * abs(ref), (fd, ref)
