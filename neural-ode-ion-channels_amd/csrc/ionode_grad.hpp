@@ -127,26 +127,37 @@ struct GradMlp {
   struct Signs {  // 64-bit words, 64 / BITS layers each; scalar members (no indexed array: that would live in scratch)
     static constexpr int PER = 64 / BITS;
     unsigned long long w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0, w5 = 0, w6 = 0, w7 = 0;
+    // N = 500 (eight words): pure mask arithmetic.  A chain of eight selects over the members is folded by hipcc into ONE load
+    // with a selected address, which pins the struct in scratch (72 B per lane in round 2's builds); and/or on values cannot be.
+    static __device__ __forceinline__ unsigned long long on(int k, int i) { return (k == i) ? ~0ull : 0ull; }
     __device__ __forceinline__ void put(int l, unsigned bits) {
       const int sh = (l % PER) * BITS;
       const unsigned long long full = (BITS == 32) ? 0xffffffffull : 0xffffull;
       const unsigned long long m = ~(full << sh), v = (unsigned long long)bits << sh;
       const int k = l / PER;
-      w0 = (k == 0) ? ((w0 & m) | v) : w0;
-      w1 = (k == 1) ? ((w1 & m) | v) : w1;
-      w2 = (k == 2) ? ((w2 & m) | v) : w2;
-      w3 = (k == 3) ? ((w3 & m) | v) : w3;
       if constexpr (PER < 4) {
-        w4 = (k == 4) ? ((w4 & m) | v) : w4;
-        w5 = (k == 5) ? ((w5 & m) | v) : w5;
-        w6 = (k == 6) ? ((w6 & m) | v) : w6;
-        w7 = (k == 7) ? ((w7 & m) | v) : w7;
+        w0 = (w0 & (m | ~on(k, 0))) | (v & on(k, 0));
+        w1 = (w1 & (m | ~on(k, 1))) | (v & on(k, 1));
+        w2 = (w2 & (m | ~on(k, 2))) | (v & on(k, 2));
+        w3 = (w3 & (m | ~on(k, 3))) | (v & on(k, 3));
+        w4 = (w4 & (m | ~on(k, 4))) | (v & on(k, 4));
+        w5 = (w5 & (m | ~on(k, 5))) | (v & on(k, 5));
+        w6 = (w6 & (m | ~on(k, 6))) | (v & on(k, 6));
+        w7 = (w7 & (m | ~on(k, 7))) | (v & on(k, 7));
+      } else {
+        w0 = (k == 0) ? ((w0 & m) | v) : w0;
+        w1 = (k == 1) ? ((w1 & m) | v) : w1;
+        w2 = (k == 2) ? ((w2 & m) | v) : w2;
+        w3 = (k == 3) ? ((w3 & m) | v) : w3;
       }
     }
     __device__ __forceinline__ unsigned get(int l) const {
       const int k = l / PER;
-      unsigned long long w = (k == 0) ? w0 : ((k == 1) ? w1 : ((k == 2) ? w2 : w3));
-      if constexpr (PER < 4) w = (k == 4) ? w4 : ((k == 5) ? w5 : ((k == 6) ? w6 : ((k == 7) ? w7 : w)));
+      unsigned long long w;
+      if constexpr (PER < 4)
+        w = (w0 & on(k, 0)) | (w1 & on(k, 1)) | (w2 & on(k, 2)) | (w3 & on(k, 3)) | (w4 & on(k, 4)) | (w5 & on(k, 5)) | (w6 & on(k, 6)) | (w7 & on(k, 7));
+      else
+        w = (k == 0) ? w0 : ((k == 1) ? w1 : ((k == 2) ? w2 : w3));
       const unsigned long long full = (BITS == 32) ? 0xffffffffull : 0xffffull;
       return (unsigned)((w >> ((l % PER) * BITS)) & full);
     }
