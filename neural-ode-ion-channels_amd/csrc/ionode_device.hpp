@@ -1225,6 +1225,9 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
       inst[i] = protocol_v(a, pv, (double)ti, vst[i]);
     }
   };
+#ifndef IONODE_PACK_LANES
+#define IONODE_PACK_LANES 8  // lanes (consecutive samples) per emitting trajectory in the packed emission of the 6-state kernels
+#endif
 #ifndef IONODE_CARRY_V_MLP
 #define IONODE_CARRY_V_MLP 0  // tried for the MLP kernels too: +1 % time (372.6 -> 376.2 ms same box), kept off
 #endif
@@ -1592,6 +1595,67 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
       }
       oi += n_out;
       } else {
+      // ---- round 3, lane-wise kernels with more than two states (6-state model), states only, verified uniform output grid:
+      // PACKED emission.  A step of the 6-state model covers ~20 output samples, so one emitting trajectory per pass left 2/3 of
+      // the lanes idle and the dense output was 70 % of the kernel's cycles (stamps, 65 536 x 20 001: 55.8 k of 79.8 k per attempt).
+      // A pass serves 64 / PK emitting trajectories, PK consecutive samples each; what was wave-uniform per trajectory (interpolant
+      // row, cursor) is read per lane from the trajectory's LDS row, whose spare slot carries (oi, n_out).  Same samples, same
+      // arithmetic; no load is issued behind the stores (times are arithmetic, rows are in LDS).
+      bool packed_done = false;
+      if constexpr (LW && D > 2) {
+        if (a.te_exact && a.i_out == nullptr && a.sse_out == nullptr && a.y_out != nullptr) {
+          packed_done = true;
+          constexpr int PK = IONODE_PACK_LANES;
+          static_assert(64 % PK == 0, "lane groups");
+          const unsigned long long emd = __ballot(n_out > 0 && lane < LPS);
+          if (emd) {
+            if (n_out > 0 && lane < LPS) {
+              reinterpret_cast<int2 *>(lsm + lane * ROWB + 24)[0] = make_int2(oi, n_out);   // the row's spare slot
+              elist[__builtin_amdgcn_mbcnt_hi((unsigned)(emd >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)emd, 0))] = lane;
+            }
+            const int ne = __builtin_popcountll(emd);
+            const int slot = lane / PK, kk = lane % PK;
+            for (int g = 0; g < ne; g += 64 / PK) {
+              const bool has = g + slot < ne;
+              const int jj = elist[has ? g + slot : g];   // (idle lane groups shadow the group's first trajectory, stores masked)
+              const double2 *rj = reinterpret_cast<const double2 *>(lsm) + jj * (ROW / 2);
+              const double2 h0 = rj[0], h1 = rj[1];
+              const double t0b = h0.x, denb = h0.y, rdenb = h1.x;
+              const int2 on2 = *reinterpret_cast<const int2 *>(&h1.y);
+              const int end = on2.x + on2.y;
+              S cb[5][D];
+#pragma unroll
+              for (int c = 0; c < 5; ++c)
+#pragma unroll
+                for (int d = 0; d < D; d += 2) {
+                  const double2 cc = rj[2 + (c * D + d) / 2];
+                  cb[c][d] = (S)cc.x; cb[c][d + 1] = (S)cc.y;
+                }
+              S *__restrict__ yo = reinterpret_cast<S *>(a.y_out) + (size_t)((int)blockIdx.x * TPW + jj) * Nt * D;
+              int idx = on2.x + kk;
+              while (__ballot(has && idx < end) != 0ull) {
+                if (has && idx < end) {
+                  const S x = (S)div_by(te_at(idx) - t0b, denb, rdenb);  // _interp_evaluate: x in fp64, cast; running powers
+                  S out[D];
+                  S xp = x;
+#pragma unroll
+                  for (int d = 0; d < D; ++d) out[d] = cb[0][d] + x * cb[1][d];
+#pragma unroll
+                  for (int c = 2; c < 5; ++c) {
+                    xp = xp * x;
+#pragma unroll
+                    for (int d = 0; d < D; ++d) out[d] = out[d] + xp * cb[c][d];
+                  }
+                  store_state<S, D>(yo + (size_t)idx * D, out);
+                }
+                idx += PK;
+              }
+            }
+          }
+          oi += n_out;
+        }
+      }
+      if (!packed_done) {
       // ---- owner wavefront evaluates and stores; the t_eval loads of the next trajectory are issued ahead ----
       unsigned long long em = __ballot(n_out > 0 && lane < LPS);
       if (G > 1) {  // trajectory jj belongs to wavefront jj % G
@@ -1706,6 +1770,7 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
         o = on;
       }
       oi += n_out;
+      }  // !packed_done
       }
     } else {
       // ---- no grid hint: cooperative scan, every wavefront advances every cursor ----

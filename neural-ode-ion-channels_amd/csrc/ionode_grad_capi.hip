@@ -3,9 +3,8 @@
 #include <cstdio>
 #include <cstring>
 
-#include "ionode_grad.hpp"
+#include "ionode_grad_launch.hpp"
 #include "ionode_grad_reduce.hpp"
-#include "ionode_regress.hpp"
 
 namespace {
 
@@ -14,20 +13,9 @@ void gerr(const char *m) { snprintf(g_gerr, sizeof g_gerr, "%s", m); }
 
 inline int np_of(int N) { return 16 * ((N + 15) / 16); }
 
-using SweepFn = void (*)(const ionode::GArgs &, unsigned grid, size_t lds, hipStream_t);
-
-template <int MODEL, typename S, int NT>
-void launch_sweep(const ionode::GArgs &a, unsigned grid, size_t lds, hipStream_t s) {
-  auto kern = ionode::ionode_dopri5_backward_kernel<MODEL, S, NT>;
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
-}
-
-template <int NT> SweepFn pick_sweep(int model, int f32) {
-  if (model == IONODE_MODEL_NNF) return f32 ? &launch_sweep<IONODE_MODEL_NNF, float, NT> : &launch_sweep<IONODE_MODEL_NNF, double, NT>;
-  return f32 ? &launch_sweep<IONODE_MODEL_NND, float, NT> : &launch_sweep<IONODE_MODEL_NND, double, NT>;
-}
+using ionode::SweepFn;
+using ionode::pick_sweep;
+using ionode::launch_sweep;
 
 // the widths of architectures/s00-s11.py: N = 10, 100, 200, 500
 SweepFn find_sweep(int model, int f32, int NT) {
@@ -35,7 +23,7 @@ SweepFn find_sweep(int model, int f32, int NT) {
     case 1: return pick_sweep<1>(model, f32);
     case 7: return pick_sweep<7>(model, f32);
     case 13: return pick_sweep<13>(model, f32);
-    case 32: return pick_sweep<32>(model, f32);
+    case 32: return ionode::pick_sweep32(model, f32);   // inst_grad32.hip
     default: return nullptr;
   }
 }
@@ -163,7 +151,7 @@ int ionode_regress_step(int32_t L, int32_t N, const float *grad_image, const flo
     case 1: ionode::launch_regress<1>(a, (unsigned)n_workgroups, s); break;
     case 7: ionode::launch_regress<7>(a, (unsigned)n_workgroups, s); break;
     case 13: ionode::launch_regress<13>(a, (unsigned)n_workgroups, s); break;
-    case 32: ionode::launch_regress<32>(a, (unsigned)n_workgroups, s); break;
+    case 32: ionode::launch_regress32(a, (unsigned)n_workgroups, s); break;
     default: gerr("ionode_regress_step: width outside the compiled variants (N pads to 16, 112, 208 or 512)"); return IONODE_ERR_UNSUPPORTED;
   }
   const hipError_t e = hipGetLastError();

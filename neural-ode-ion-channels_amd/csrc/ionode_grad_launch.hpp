@@ -1,0 +1,28 @@
+// ionode_grad_launch.hpp -- launchers of the backward sweep, shared by the translation units that instantiate it
+// (ionode_grad_capi.hip: N = 10 / 100 / 200; inst_grad32.hip: N = 500, compiled with instruction sinking).
+#pragma once
+#include "ionode_grad.hpp"
+#include "ionode_regress.hpp"
+
+namespace ionode {
+
+using SweepFn = void (*)(const GArgs &, unsigned grid, size_t lds, hipStream_t);
+
+template <int MODEL, typename S, int NT>
+void launch_sweep(const GArgs &a, unsigned grid, size_t lds, hipStream_t s) {
+  auto kern = ionode_dopri5_backward_kernel<MODEL, S, NT>;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
+}
+
+template <int NT> SweepFn pick_sweep(int model, int f32) {
+  if (model == IONODE_MODEL_NNF) return f32 ? &launch_sweep<IONODE_MODEL_NNF, float, NT> : &launch_sweep<IONODE_MODEL_NNF, double, NT>;
+  return f32 ? &launch_sweep<IONODE_MODEL_NND, float, NT> : &launch_sweep<IONODE_MODEL_NND, double, NT>;
+}
+
+// inst_grad32.hip
+SweepFn pick_sweep32(int model, int f32);
+void launch_regress32(const RArgs &a, unsigned grid, hipStream_t s);
+
+}  // namespace ionode

@@ -68,6 +68,7 @@ __global__ void __launch_bounds__(256) ionode_regress_kernel(const RArgs a) {
   }
 }
 
+#ifndef IONODE_GRAD_TEMPLATES_ONLY  // (inst_grad32.hip instantiates the N = 500 templates only)
 // torch.optim.Adam (no amsgrad, no weight decay) on the flat state dict, fp32, element-wise as torch computes it:
 //   m = m + (g - m) * (1 - beta1);  v = v * beta2 + g * g * (1 - beta2)
 //   denom = sqrt(v) / sqrt(1 - beta2^t) + eps;  w = w - (lr / (1 - beta1^t)) * m / denom
@@ -99,6 +100,8 @@ __global__ void ionode_image_refresh_kernel(size_t n_img, const int32_t *__restr
   const int32_t s = imgmap[k];
   img[k] = s > 0 ? w[s - 1] : 0.0f;
 }
+
+#endif  // IONODE_GRAD_TEMPLATES_ONLY
 
 template <int NT> inline void launch_regress(const RArgs &a, unsigned grid, hipStream_t s) {
   const size_t lds = grad_lds_bytes(a.L, NT);

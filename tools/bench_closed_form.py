@@ -29,6 +29,7 @@ ap.add_argument("--layers", type=int, default=5, help="nnf: hidden layers L")
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--tpw", type=int, default=0, help="closed-form: trajectories per wavefront, 64 or 16 (0 = dispatcher default)")
 ap.add_argument("--protocol-major", action="store_true", help="trajectories of one protocol adjacent (lanes of a wavefront share it)")
+ap.add_argument("--stamps", action="store_true", help="library built with -DIONODE_STAMPS: print the phase cycles of wavefront 0")
 a = ap.parse_args()
 
 ion = importlib.import_module("neural-ode-ion-channels_amd")
@@ -59,6 +60,7 @@ if a.protocol_major:
     pot = (torch.arange(B, dtype=torch.int64, device=dev) * a.prot // B).to(torch.int32)
 out = {}
 ms = []
+slog = torch.zeros((16, 4), dtype=torch.float64, device=dev) if a.stamps else None
 sse_ref = torch.zeros((a.prot, Nt), dtype=torch.float64, device=dev) if a.sse else None
 for rep in range(a.reps + 1):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -66,7 +68,7 @@ for rep in range(a.reps + 1):
     r = ion.capi.dopri5(model, params, pv, y0t, te, prot_t0=0.0, prot_dt=0.1, prot_of_traj=pot, current=a.current, tile_waves=a.tpw,
                         mlp_packed=packed, mlp_layers=a.layers if packed is not None else 0,
                         mlp_width=a.width if packed is not None else 0, t_eval_hint=(0.0, 0.1), out=None if a.sse else out,
-                        sse_ref=sse_ref, states=not a.sse)
+                        sse_ref=sse_ref, states=not a.sse, step_log=slog)
     e1.record()
     torch.cuda.synchronize()
     if not a.sse:
@@ -74,6 +76,13 @@ for rep in range(a.reps + 1):
     if rep:
         ms.append(e0.elapsed_time(e1))
 st = r["stats"].cpu().numpy()
+if a.stamps:  # wavefront 0 of workgroup 0: cycles per phase, per step attempt of its slowest trajectory
+    tpw = 64 if "1, 0," in r["kernel"] or "1, 64," in r["kernel"] else 16
+    att = float((st[:tpw, 0] + st[:tpw, 1]).max())
+    c = slog.cpu().numpy().reshape(-1)[:16]
+    names = {0: "outside", 1: "prologue/lookups", 6: "stages+error", 8: "interp-fit", 9: "cursor", 7: "emission", 10: "emit-gather"}
+    print("STAMPS attempts %d, cycles per attempt:" % att, {names.get(i, i): int(c[i] / att) for i in range(16) if c[i] > 0},
+          "total", int(c.sum() / att), file=sys.stderr)
 s = 4 if a.f32 else 8
 bytes_traj = (0 if a.sse else Nt * D * s) + (Nt * 8 if a.current else 0)
 total = B * bytes_traj + a.prot * Nt * 8
