@@ -1154,6 +1154,9 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
   // emit in the current attempt, compacted (512 bytes behind the 4 KiB of tail buffers; the dispatcher reserves them)
   int *const owp = reinterpret_cast<int *>(tails + 64 * 64);
   int *const elist = owp + 64;
+  if constexpr (LW && !(CF2 && defer)) {
+    if (lane < LPS) owp[lane] = pidx;   // packed emission: the trajectory's protocol index, read per lane group
+  }
   if constexpr (CF2 && defer) {
     static_assert(TAILB <= 64, "tail buffers fit the reserved 4 KiB");
     if (lane < LPS) owp[lane] = 0;
@@ -1225,9 +1228,6 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
       inst[i] = protocol_v(a, pv, (double)ti, vst[i]);
     }
   };
-#ifndef IONODE_PACK_LANES
-#define IONODE_PACK_LANES 8  // lanes (consecutive samples) per emitting trajectory in the packed emission of the 6-state kernels
-#endif
 #ifndef IONODE_CARRY_V_MLP
 #define IONODE_CARRY_V_MLP 0  // tried for the MLP kernels too: +1 % time (372.6 -> 376.2 ms same box), kept off
 #endif
@@ -1595,21 +1595,29 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
       }
       oi += n_out;
       } else {
-      // ---- round 3, lane-wise kernels with more than two states (6-state model), states only, verified uniform output grid:
-      // PACKED emission.  A step of the 6-state model covers ~20 output samples, so one emitting trajectory per pass left 2/3 of
-      // the lanes idle and the dense output was 70 % of the kernel's cycles (stamps, 65 536 x 20 001: 55.8 k of 79.8 k per attempt).
-      // A pass serves 64 / PK emitting trajectories, PK consecutive samples each; what was wave-uniform per trajectory (interpolant
-      // row, cursor) is read per lane from the trajectory's LDS row, whose spare slot carries (oi, n_out).  Same samples, same
-      // arithmetic; no load is issued behind the stores (times are arithmetic, rows are in LDS).
-      bool packed_done = false;
-      if constexpr (LW && D > 2) {
-        if (a.te_exact && a.i_out == nullptr && a.sse_out == nullptr && a.y_out != nullptr) {
-          packed_done = true;
-          constexpr int PK = IONODE_PACK_LANES;
-          static_assert(64 % PK == 0, "lane groups");
-          const unsigned long long emd = __ballot(n_out > 0 && lane < LPS);
-          if (emd) {
-            if (n_out > 0 && lane < LPS) {
+      // ---- round 3, lane-wise kernels on a verified uniform output grid: PACKED emission.  A step of the 6-state model covers
+      // ~20 output samples (2-state: ~34), so one emitting trajectory per pass left 1/2 - 2/3 of the lanes idle, and the dense
+      // output was 70 % of the 6-state kernel's cycles (stamps, 65 536 x 20 001: 55.8 k of 79.8 k per attempt).  A pass serves
+      // 64 / PK emitting trajectories, PK = 8 consecutive samples each per iteration; what was wave-uniform per trajectory
+      // (interpolant row, cursor, protocol) is read per lane from LDS: the trajectory's row, whose spare slot carries
+      // (oi, n_out), and the protocol index parked in the cursor array of the deferred variant.  Same samples, same arithmetic;
+      // the fused objective keeps its summation order (8-lane groups = the same 8 consecutive samples, partial sum number
+      // (k / 8) mod 8 -- which is why, with the objective, steps of more than 64 samples take the one-trajectory-per-pass loop below); V(t_k) and the
+      // reference current of the next iteration are loaded before this iteration's stores.
+      bool packed_lane = false;   // my trajectory's samples are emitted by the packed pass (the others: the loop below)
+      if constexpr (LW && (VTAB || D > 2)) {
+        constexpr int PK = 8;
+        const bool want_i = (a.i_out != nullptr) || (a.sse_out != nullptr);
+        // one instance per compiled variant: the table variant (TAIL == 2) serves the current / objective epilogue, the plain one
+        // states only (its epilogue without the table -- a protocol lookup per sample -- stays on the loop below)
+        // (2-state kernels that also store the states keep the loop below: at ~34 samples per step its 64 consecutive samples per
+        // store instruction touch half the cache lines of 8 x 8, and that path is store-bound: 41.5 against 44.7 ms packed)
+        if (a.te_exact && (VTAB ? (want_i && (D > 2 || a.y_out == nullptr)) : (!want_i && a.y_out != nullptr))) {
+          packed_lane = n_out > 0 && lane < LPS && (n_out <= 64 || a.sse_out == nullptr);
+          const unsigned long long emd = __ballot(packed_lane);
+          auto emit_packed = [&](auto wi_tag) {
+            constexpr bool WI = decltype(wi_tag)::value;
+            if (packed_lane) {
               reinterpret_cast<int2 *>(lsm + lane * ROWB + 24)[0] = make_int2(oi, n_out);   // the row's spare slot
               elist[__builtin_amdgcn_mbcnt_hi((unsigned)(emd >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)emd, 0))] = lane;
             }
@@ -1623,6 +1631,21 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
               const double t0b = h0.x, denb = h0.y, rdenb = h1.x;
               const int2 on2 = *reinterpret_cast<const int2 *>(&h1.y);
               const int end = on2.x + on2.y;
+              int idx = on2.x + kk;
+              const int tr = (int)blockIdx.x * TPW + jj;
+              double *__restrict__ io = nullptr;
+              const double *__restrict__ pvb = nullptr, *__restrict__ refb = nullptr, *__restrict__ vtb = nullptr;
+              double vk_nxt = 0.0, rf_nxt = 0.0;
+              if constexpr (WI) {
+                const int pj = owp[jj];
+                if (a.i_out) io = a.i_out + (size_t)tr * Nt;
+                pvb = a.prot_v + (size_t)pj * a.Np;
+                if (a.sse_out) refb = a.sse_ref + (size_t)pj * Nt;
+                if constexpr (VTAB) {
+                  vtb = a.v_tab + (size_t)pj * Nt;
+                  if (has && idx < end) { vk_nxt = vtb[idx]; if (refb) rf_nxt = refb[idx]; }
+                }
+              }
               S cb[5][D];
 #pragma unroll
               for (int c = 0; c < 5; ++c)
@@ -1631,11 +1654,18 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
                   const double2 cc = rj[2 + (c * D + d) / 2];
                   cb[c][d] = (S)cc.x; cb[c][d + 1] = (S)cc.y;
                 }
-              S *__restrict__ yo = reinterpret_cast<S *>(a.y_out) + (size_t)((int)blockIdx.x * TPW + jj) * Nt * D;
-              int idx = on2.x + kk;
+              S *__restrict__ yo = a.y_out ? reinterpret_cast<S *>(a.y_out) + (size_t)tr * Nt * D : nullptr;
+              int part = 0;   // partial sum of the objective this iteration's 8 samples belong to
               while (__ballot(has && idx < end) != 0ull) {
-                if (has && idx < end) {
-                  const S x = (S)div_by(te_at(idx) - t0b, denb, rdenb);  // _interp_evaluate: x in fp64, cast; running powers
+                const bool on = has && idx < end;
+                const double vk_cur = vk_nxt, rf_cur = rf_nxt;
+                if constexpr (VTAB && WI) {
+                  if (has && idx + PK < end) { vk_nxt = vtb[idx + PK]; if (refb) rf_nxt = refb[idx + PK]; }
+                }
+                double rr2 = 0.0;
+                if (on) {
+                  const double tk = te_at(idx);
+                  const S x = (S)div_by(tk - t0b, denb, rdenb);  // _interp_evaluate: x in fp64, cast; running powers
                   S out[D];
                   S xp = x;
 #pragma unroll
@@ -1646,18 +1676,34 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
 #pragma unroll
                     for (int d = 0; d < D; ++d) out[d] = out[d] + xp * cb[c][d];
                   }
-                  store_state<S, D>(yo + (size_t)idx * D, out);
+                  if (!WI || yo) store_state<S, D>(yo + (size_t)idx * D, out);
+                  if constexpr (WI) {
+                    double vk;
+                    if constexpr (VTAB) vk = vk_cur;  // == protocol_v(a, pvb, t_eval[idx]), evaluated once per protocol by the pre-pass
+                    else protocol_v(a, pvb, tk, vk);
+                    S gate;
+                    if (a.obs_open) gate = out[D - 1]; else gate = out[0] * out[1];
+                    if (a.obs_g != 1.0) gate = (S)a.obs_g * gate;
+                    const double ik = (double)gate * (vk - a.obs_e);
+                    if (io) io[idx] = ik;
+                    if (refb) { const double rr = ik - (VTAB ? rf_cur : refb[idx]); rr2 = rr * rr; }
+                  }
+                }
+                if (WI && a.sse_out) {
+                  const double g8 = group8_sum_f64(rr2);
+                  if (kk == 0 && has) ssep[jj * 8 + part] += g8;
+                  part = (part + 1) & 7;
                 }
                 idx += PK;
               }
             }
-          }
-          oi += n_out;
+          };
+          if (emd) emit_packed(std::integral_constant<bool, VTAB>{});
         }
       }
-      if (!packed_done) {
+      {
       // ---- owner wavefront evaluates and stores; the t_eval loads of the next trajectory are issued ahead ----
-      unsigned long long em = __ballot(n_out > 0 && lane < LPS);
+      unsigned long long em = __ballot(n_out > 0 && lane < LPS && !packed_lane);
       if (G > 1) {  // trajectory jj belongs to wavefront jj % G
         unsigned long long mine = 0ull;
 #pragma unroll
@@ -1770,7 +1816,7 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
         o = on;
       }
       oi += n_out;
-      }  // !packed_done
+      }
       }
     } else {
       // ---- no grid hint: cooperative scan, every wavefront advances every cursor ----
