@@ -1203,9 +1203,12 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
 #ifndef IONODE_BATCH_LOOKUPS_ALL
 #define IONODE_BATCH_LOOKUPS_ALL 0
 #endif
+#ifndef IONODE_BATCH_LOOKUPS_M6
+#define IONODE_BATCH_LOOKUPS_M6 1   // 6-state kernel at one wavefront per SIMD (NT slot 0): registers to spare, and nothing else hides the round trips
+#endif
     // (tile kernels only: the lane-wise kernels run at 2-3 wavefronts per SIMD and cannot afford the 35 registers -- the N <= 16
     // kernel at 64 per wavefront went from 251 to 272 VGPRs = one wavefront per SIMD, 58 -> 87 ms; 2-state kernel -4 %)
-    if (((MT::MLP && G > 1) || IONODE_BATCH_LOOKUPS_ALL) && a.prot_t == nullptr) {
+    if (((MT::MLP && G > 1) || (IONODE_BATCH_LOOKUPS_M6 && !MT::MLP && D > 2 && NT == 0) || IONODE_BATCH_LOOKUPS_ALL) && a.prot_t == nullptr) {
       // uniform protocol grid: five indices, five 16-byte loads back to back, then the interpolations -- ONE memory round
       // trip per attempt (protocol_v() per stage time waited for each pair of samples in turn: 5 dependent round trips,
       // ~7 k cycles of the s00 attempt)
