@@ -417,7 +417,19 @@ struct MlpTile {
   static constexpr int FRAGS = NT * F + NOWN * R;    // 1 KiB fragments per wavefront per layer
   // ring slot of step u (blocked scheme: step kt0 + u): F full fragments (+ R remainder fragments when owned)
   f32x4 ring[PD][F > 0 ? F : 1];
-  f32x4 rrem[R > 0 ? (PD + G - 1) / G : 1][RP];
+  // N = 100 (NT = 7: one full tile per wavefront + THREE remainder tiles): K-splitting three tiles over the wavefronts costs three
+  // partial-sum exchanges and a 60-instruction fold per layer on every wavefront, and the layer barrier waits for it.  OWNREM:
+  // wavefront w < R computes remainder tile w WHOLE -- its four canonical partial chains p_0..p_3 (k-tiles kt % 4 == c, ascending)
+  // in four accumulators, folded in registers with the canonical tree -- so the layer's activations are complete at the barrier.
+  // 56 / 56 / 56 / 28 MFMAs per layer instead of 52 / 52 / 52 / 40, no partial sums in LDS; same chains, same bits.  The chains
+  // need the k-tiles in natural order (the full tile walks them rotated), so they read their own B operands, one step behind.
+#ifndef IONODE_OWNREM
+#define IONODE_OWNREM 1
+#endif
+  static constexpr bool OWNREM = IONODE_OWNREM && (G == 4 && F == 1 && R == 3 && PD == NT);
+  f32x4 rrem[(R > 0 && !OWNREM) ? (PD + G - 1) / G : 1][(R > 0 && !OWNREM) ? RP : 1];
+  f32x4 rown[OWNREM ? NT : 1];   // fragments of my remainder tile, one per k-tile (a layer ahead, like the ring)
+  unsigned voff0;                // per lane: lane * 16 (fragments of another wavefront's stream: frag_of)
   // NT == 1 (N <= 16, architectures s03-s05): the whole hidden stack is LMAX fragments -- it stays in registers
   static constexpr bool TINY = (NT == 1 && G == 1);
   static constexpr int LMAX = 10;
@@ -477,6 +489,7 @@ struct MlpTile {
     const size_t img_bytes = (4 * (size_t)NP + (size_t)L * lstride + NP + 4) * 4;
     rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(img), 0, (int)img_bytes, 0x00020000);
     voff = (unsigned)(wave * FRAGS * 1024 + lane * 16);
+    voff0 = (unsigned)(lane * 16);
     hid0 = (unsigned)(4 * NP * 4);
     lbytes = (unsigned)(lstride * 4);
     if constexpr (TINY) {
@@ -501,12 +514,27 @@ struct MlpTile {
     for (int u = 0; u < (TINY ? 0 : PD); ++u) {
 #pragma unroll
       for (int j = 0; j < F; ++j) ring[u][j] = frag(hid0, step_base(u) + j);
-      if (R > 0 && u % G == 0) {
+      if constexpr (R > 0 && !OWNREM) {
+        if (u % G == 0) {
 #pragma unroll
-        for (int j = 0; j < R; ++j) rrem[u / G][j] = frag(hid0, step_base(u) + F + j);
+          for (int j = 0; j < R; ++j) rrem[u / G][j] = frag(hid0, step_base(u) + F + j);
+        }
       }
     }
+    if constexpr (OWNREM) {
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt) rown[kt] = frag_of(hid0, kt);
+    }
     __syncthreads();
+  }
+
+  // OWNREM: the fragment of remainder tile `wave` for k-tile kt.  It sits in the stream of wavefront kt % G (the K-slice owner of
+  // the packed layout, ionode_mlp_pack), at that wavefront's owned step kt - kt % G, behind the step's F full-tile fragments.
+  __device__ __forceinline__ f32x4 frag_of(unsigned lbase, int kt) const {
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+    const unsigned n = (unsigned)((kt % G) * FRAGS + step_base(kt - kt % G) + F) + (unsigned)(wave < R ? wave : 0);
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff0, lbase + n * 1024u, 0);
+    return __builtin_bit_cast(f32x4, v);
   }
 
   // one 1 KiB fragment (64 lanes x float4): fragment n of this wavefront's stream of the layer at byte offset `lbase`
@@ -694,15 +722,22 @@ struct MlpTile {
       // which every wavefront folds into the remainder slots of the input buffer itself (identical bits from all
       // wavefronts; each reads after its own write, so no barrier).  The fold is needed first at step G*F - wave;
       // when that is late enough it runs behind the MFMAs of step 0 instead of in the layer prologue.
-      constexpr bool LAZY_FOLD = (R > 0) && (G * F - (G - 1) >= 3);
+      constexpr bool LAZY_FOLD = (R > 0) && !OWNREM && (G * F - (G - 1) >= 3);
       f32x4 acc[F > 0 ? F : 1], accr[RP];
 #pragma unroll
       for (int i = 0; i < F; ++i)
         acc[i] = *reinterpret_cast<const f32x4 *>(biasS + l * NP + 16 * (wave + i * G) + 4 * q);
+      f32x4 pc[OWNREM ? 4 : 1];   // OWNREM: the four partial chains of my remainder tile
+      f32x4 bn_nxt = f32x4{0, 0, 0, 0};
+      if constexpr (OWNREM) {
+        pc[0] = *reinterpret_cast<const f32x4 *>(biasS + l * NP + 16 * (G * F + (wave < R ? wave : 0)) + 4 * q);  // chain 0 carries the bias
+        pc[1] = pc[2] = pc[3] = f32x4{0, 0, 0, 0};
+      } else {
 #pragma unroll
       for (int j = 0; j < R; ++j) {
         const f32x4 bz = *reinterpret_cast<const f32x4 *>(biasS + l * NP + 16 * (G * F + j) + 4 * q);
         accr[j] = (wave == 0) ? bz : f32x4{0, 0, 0, 0};  // partial sum 0 carries the bias
+      }
       }
       for (int kt0 = 0; kt0 < NT; kt0 += PD) {
         static_assert(R == 0 || PD == NT, "remainder tiles need the full-layer ring (static step index)");
@@ -724,7 +759,13 @@ struct MlpTile {
           if (u + 1 < PD && !(u == 0 && kt0 == 0)) b_nxt = Bw[(u + 1) * 64];
 #endif
           // K-slice ownership: static, except that the last owned step wraps past NT for the higher wavefronts
-          const bool own_static = (R > 0) && (u % G == 0);
+          const bool own_static = (R > 0) && !OWNREM && (u % G == 0);
+          // OWNREM: my remainder tile's chain (u - 1) % 4 takes k-tile u - 1 (natural order, one step behind: k-tile 0 is another
+          // wavefront's tile and exists only behind the layer barrier, which sits at the end of step 0)
+          f32x4 bn = bn_nxt;
+          if constexpr (OWNREM) {
+            if (u >= 1) bn_nxt = Hin[u * 64 + lane];
+          }
           const bool own_always = own_static && (u + G - 1 < NT);
           const bool own = own_static && (own_always || (u + wave < NT));
 #pragma unroll
@@ -734,6 +775,7 @@ struct MlpTile {
               const int e = r * F + i;
               acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[u][e / 4][e % 4], b[r], acc[i], 0, 0, 0);
             }
+            if constexpr (!OWNREM) {
             if (own_static) {
               if (own) {
 #pragma unroll
@@ -741,14 +783,23 @@ struct MlpTile {
                   accr[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(rrem[u / G][j][r], b[r], accr[j], 0, 0, 0);
               }
             }
+            } else {
+              if (u >= 1) {   // (every wavefront, also the one without a remainder tile: a wave-dependent branch around the
+                              // refills makes hipcc drain every load at every use -- 29.8 -> 48.8 ms; it computes tile 0 again, unused)
+                pc[(u - 1) % G] = __builtin_amdgcn_mfma_f32_16x16x4f32(rown[u - 1][r], bn[r], pc[(u - 1) % G], 0, 0, 0);
+                if (r == 3) rown[u - 1] = frag_of(lref, u - 1);
+              }
+            }
             // refill every fragment whose last reader was this k-step; pinned here (see header comment)
 #ifndef IONODE_EXPERIMENT_NO_REFILL  // timing experiment only: results are wrong for L > 1
 #pragma unroll
             for (int j = 0; j < F; ++j)
               if ((4 * j + 3) / F == r) ring[u][j] = frag(lref, step_base(u) + j);
+            if constexpr (!OWNREM) {
             if (own_static && r == 3) {
 #pragma unroll
               for (int j = 0; j < R; ++j) rrem[u / G][j] = frag(lref, step_base(u) + F + j);
+            }
             }
 #endif
             if (LAZY_FOLD && u == 1 && r == 0 && l > 0) {
@@ -760,14 +811,27 @@ struct MlpTile {
           if (u == 0 && kt0 == 0) {
             // ---- the layer barrier: everybody's activations / partial sums of the previous layer are in LDS ----
             if (G > 1) __syncthreads();
-            if (R > 0 && !LAZY_FOLD && l > 0) {
+            if (R > 0 && !OWNREM && !LAZY_FOLD && l > 0) {
 #pragma unroll
               for (int j = 0; j < R; ++j) Hin[(G * F + j) * 64 + lane] = remainder_h(Pin, j);
             }
             if (PD > 1) b_nxt = Bw[64];
+            if constexpr (OWNREM) {
+              bn_nxt = Hin[lane];   // k-tile 0 for my remainder chains (step 1)
+            }
             __builtin_amdgcn_sched_barrier(0);
           }
         }
+      }
+      if constexpr (OWNREM) {
+        const f32x4 bn = bn_nxt;   // k-tile NT - 1
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pc[(NT - 1) % G] = __builtin_amdgcn_mfma_f32_16x16x4f32(rown[NT - 1][r], bn[r], pc[(NT - 1) % G], 0, 0, 0);
+        rown[NT - 1] = frag_of(lnext, NT - 1);
+        f32x4 h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = lrelu((pc[0][r] + pc[1][r]) + (pc[2][r] + pc[3][r]));  // the canonical combine tree
+        if (wave < R) Hout[(G * F + wave) * 64 + lane] = h;
       }
       MSTAMP(10);  // slot 10: last k-tile
 #pragma unroll
@@ -779,8 +843,10 @@ struct MlpTile {
         Hout[(wave + i * G) * 64 + lane] = h;
         if (wave + i * G < G - 1) Hout[(wave + i * G + NT) * 64 + lane] = h;
       }
+      if constexpr (!OWNREM) {
 #pragma unroll
       for (int j = 0; j < R; ++j) Pout[(j * G + wave) * 64 + lane] = accr[j];
+      }
       MSTAMP(4);  // slot 4: LeakyReLU + activation store
     }
     if (G > 1) __syncthreads();  // the last hidden layer's (or layer 0's) activations for the output layer
@@ -794,7 +860,7 @@ struct MlpTile {
     for (int kt = 0; kt < NT; ++kt) {
       const f32x4 w = *reinterpret_cast<const f32x4 *>(wlS + 16 * kt + 4 * q);
       f32x4 h;
-      if (R > 0 && kt >= G * F && L > 0) h = remainder_h(Pin, kt - G * F);
+      if (R > 0 && !OWNREM && kt >= G * F && L > 0) h = remainder_h(Pin, kt - G * F);
       else h = Hin[kt * 64 + lane];
 #pragma unroll
       for (int r = 0; r < 4; ++r) part = fmaf(w[r], h[r], part);
