@@ -243,7 +243,8 @@ def main():
         torch.cuda.empty_cache()
         for key, fn in (("roofline_closed_form", closed_form_legs), ("gradient_config5", gradient_leg),
                         ("regression_step", regression_leg), ("launch_order_16384", launch_order_leg),
-                        ("objective_config4_share", objective_leg), ("config3_nnd_staircase_16384", config3_leg)):
+                        ("objective_config4_share", objective_leg), ("config3_nnd_staircase_16384", config3_leg),
+                        ("other_architectures_4096", architectures_leg)):
             try:
                 res[key] = fn(ion, dev, weights)
             except Exception as e:  # informational legs only
@@ -341,8 +342,40 @@ def closed_form_legs(ion, dev, weights):
                                        "note": "ms includes the protocol-at-outputs pre-pass (64 x 20001 lookups)"}
     del params, y0t, hold
     torch.cuda.empty_cache()
-    legs["note"] = ("fp64-VALU-issue bound, not HBM bound: ~5000 vector instructions per step attempt and 64-trajectory wavefront "
-                    "(profiles/r02_closed_form.md: SQ_ACTIVE_INST_VALU vs SQ_WAIT_ANY, and the no-store / no-emission timing experiments)")
+    legs["note"] = ("fp64-VALU-issue bound, not HBM bound (DESIGN.md 5.1; counters: profiles/r03_pmc_summary.json cf1-cf6: "
+                    "SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles = 74 % for the 2-state kernel)")
+    return legs
+
+
+def architectures_leg(ion, dev, weights):
+    """The other MLP widths of architectures/s00-s11.py through their own tile kernels (table-s1.py:132-153 trains them all):
+    random-init nets, 4096 trajectories (one tile per compute unit), 2 s sine-wave protocols, fp64 state.  FLOPs = sum over
+    trajectories of RHS evaluations x 2 (L N^2 + 3 N): algorithmic, the launch lasts as long as its slowest tile."""
+    capi, P = ion.capi, ion.protocols
+    Nt, n_prot, B = 20001, 64, 4096
+    pv = P.sinewave(P.sinewave_scales(0, n_prot), n_samples=Nt, xp=torch, device=dev)
+    te = torch.arange(Nt, dtype=torch.float64, device=dev) * 0.1
+    params = torch.from_numpy(P_HH[None, :] * np.random.default_rng(0).uniform(0.8, 1.25, (B, 8))).to(dev)
+    y0t = torch.tensor([[0.0, 1.0]], dtype=torch.float64, device=dev).repeat(B, 1).contiguous()
+    pot = (torch.arange(B, dtype=torch.int32, device=dev) % n_prot).contiguous()
+    legs = {}
+    for name, L, N in (("s09_5x100", 5, 100), ("s11_10x100", 10, 100), ("s06_5x500", 5, 500), ("s00_5x200_random_init", 5, 200)):
+        w = np.random.default_rng(1).normal(0, 0.1, 2 * N + N + L * (N * N + N) + N + 1).astype(np.float32)
+        packed = torch.from_numpy(capi.mlp_pack(w, L, N)).to(dev)
+        o, hold = {}, {}
+
+        def run():
+            hold["r"] = capi.dopri5(capi.MODEL_NNF, params, pv, y0t, te, out=o, prot_t0=0.0, prot_dt=0.1, prot_of_traj=pot,
+                                    t_eval_hint=(0.0, 0.1), t_eval_exact=True, mlp_packed=packed, mlp_layers=L, mlp_width=N)
+            o.update({k: hold["r"][k] for k in ("y", "status", "stats")})
+        ms = _timed(run, 2)
+        st = hold["r"]["stats"].cpu().numpy()
+        flop = float(st[:, 2].sum()) * 2.0 * (L * N * N + 3 * N)
+        legs[name] = {"kernel": hold["r"]["kernel"], "kernel_ms": ms, "us_per_rhs_evaluation_of_the_slowest_tile": ms * 1e3 / float(st[:, 2].max()),
+                      "mean_over_max_nfe": float(st[:, 2].mean() / st[:, 2].max()), "achieved": flop / ms / 1e9, "unit": "TFLOP/s",
+                      "peak": PEAK_FP32_TFLOPS, "frac": flop / ms / 1e9 / PEAK_FP32_TFLOPS, "ok": int((hold["r"]["status"] == 0).sum().item())}
+        del packed, o, hold
+        torch.cuda.empty_cache()
     return legs
 
 

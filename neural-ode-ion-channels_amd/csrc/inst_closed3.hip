@@ -12,10 +12,6 @@ static const Variant kTab[] = {
     IONODE_VARIANT(0, double, 0, 1, 16, 0, 0, 1), IONODE_VARIANT(0, float, 1, 1, 16, 0, 0, 1),
     IONODE_VARIANT(0, double, 0, 1, 0, 0, 0, 2), IONODE_VARIANT(0, float, 1, 1, 0, 0, 0, 2),
     IONODE_VARIANT(0, double, 0, 1, 16, 0, 0, 2), IONODE_VARIANT(0, float, 1, 1, 16, 0, 0, 2),
-    // 6-state model at TWO wavefronts per SIMD (NT slot 2; 10 spilled registers without machine-LICM, 44-48 with it): launches of
-    // more than two one-per-SIMD residency rounds, >= 196 608 trajectories -- 262 144: 118 against 142 ms; below that it loses
-    IONODE_VARIANT(1, double, 0, 1, 0, 2, 0, 0), IONODE_VARIANT(1, float, 1, 1, 0, 2, 0, 0),
-    IONODE_VARIANT(1, double, 0, 1, 0, 2, 0, 2), IONODE_VARIANT(1, float, 1, 1, 0, 2, 0, 2),
 };
 const Variant *variants_closed3(int *n) { *n = sizeof(kTab) / sizeof(kTab[0]); return kTab; }
 }  // namespace ionode

@@ -71,8 +71,9 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false) {
     // per wavefront 19.3 against 24.3 ms; beyond one round the 2-per-SIMD build loses, e.g. 163 839: 32.8 against 24.6 ms)
     const long long waves = ((long long)d->n_traj + tpw - 1) / tpw;
     int wslot = (d->model == IONODE_MODEL_HH2 && waves <= 2048) ? 2 : 0;
-    // 6-state model: one wavefront per SIMD (no spill) up to two residency rounds; beyond, the two-per-SIMD build (inst_closed3.hip)
-    if (d->model == IONODE_MODEL_MARKOV6 && tpw == 64 && d->n_traj >= 196608) wslot = 2;
+    // 6-state model: one wavefront per SIMD (the whole register file) at every batch.  (Round 3 had a two-per-SIMD build for
+    // launches beyond two residency rounds; since the packed dense output the two are within 3 % of each other -- 196 608: 69.5
+    // against 72.8 ms, 262 144: 96.1 against 93.7 ms -- and that build was the library's only user of scratch: removed.)
     pl->v = find_variant(d->model, f32, 1, wslot, tpw == 64 ? 0 : 16, defer);
     pl->grid = (unsigned)((d->n_traj + tpw - 1) / tpw);
     pl->block = 64;

@@ -194,10 +194,9 @@ def test_asm_stream_every_depth(ion, gpu, oracle, L, f32, tile):
 
 
 @pytest.mark.parametrize("f32", [False, True])
-def test_six_state_two_per_simd_build_at_large_batches(ion, gpu, oracle, f32):
-    """From 196 608 trajectories the 6-state model takes its two-wavefronts-per-SIMD build (NT slot 2, inst_closed3.hip): 24 random
-    trajectories of a 200 000-trajectory batch against the oracle bit for bit, plain emission and table epilogue; repeated inputs
-    repeat their bits."""
+def test_six_state_model_at_large_batches(ion, gpu, oracle, f32):
+    """The 6-state kernel (one wavefront per SIMD, packed dense output) over three residency rounds: 24 random trajectories of a
+    200 000-trajectory batch against the oracle bit for bit, plain emission and table epilogue; repeated inputs repeat their bits."""
     B = 200000
     rng = np.random.default_rng(B + f32)
     pv = np.stack([K.activation(v)[1][:1201] for v in (-40, 0, 40)])
@@ -210,7 +209,7 @@ def test_six_state_two_per_simd_build_at_large_batches(ion, gpu, oracle, f32):
     ref = rng.normal(0, 0.3, (3, te.size))
     for name, kw in (("plain", {}), ("table", dict(current=True, sse_ref=ref, obs_open_state_only=True))):
         sol = ion.solve(K.MODEL_MARKOV6, params, pv, y0, te, prot_t0=0.0, prot_dt=1.0, prot_of_traj=pot, **kw)
-        assert ", 1, 0, 2, 0, %d>" % {"plain": 0, "table": 2}[name] in sol.kernel and ("float" if f32 else "double") in sol.kernel, sol.kernel
+        assert ", 1, 0, 0, 0, %d>" % {"plain": 0, "table": 2}[name] in sol.kernel and ("float" if f32 else "double") in sol.kernel, sol.kernel
         o = oracle.solve(K.MODEL_MARKOV6, params[pick], pv, [0.0, 1.0, 0.0, 0.0, 0.0, 0.0], te, prot_t0=0.0, prot_dt=1.0,
                          prot_of_traj=pot[pick], nthreads=8, state_f32=f32)
         assert np.array_equal(sol.y[pick].double().cpu().numpy(), o["y"]) and np.array_equal(sol.stats[pick].cpu().numpy(), o["stats"])
