@@ -26,6 +26,7 @@ for k, v in b["roofline_closed_form"].items():
 print("grad", b["gradient_config5"]["forward_with_checkpoints_s"], b["gradient_config5"]["backward_s"])
 print("regress", b["regression_step"]["ms_per_iteration"], b["regression_step"]["frac"])
 print("order", {k: (round(v["ms"], 1), round(v["frac_of_fp32_peak"], 4)) for k, v in b["launch_order_16384"].items() if isinstance(v, dict)})
+print("architectures", {k: (round(v["kernel_ms"], 2), round(v["frac"], 3)) for k, v in b.get("other_architectures_4096", {}).items() if isinstance(v, dict)})
 print("config3", {k: v for k, v in b["config3_nnd_staircase_16384"].items() if not isinstance(v, (dict, list))})
 for name in (f"{R}_kernel_stats.csv", f"{R}_kernel_stats_legs.csv"):
     print("--", name)
