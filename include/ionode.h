@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define IONODE_ABI_VERSION 5
+#define IONODE_ABI_VERSION 6
 
 /* RHS families (func.forward variants of the reference) */
 #define IONODE_MODEL_HH2 0     /* 2-state Hodgkin-Huxley: Lambda, train-s1.py:134-177; candidate ODEFunc train-d0.py:321-374 */
@@ -115,6 +115,12 @@ typedef struct ionode_desc {
   int32_t traj_per_image;   /* ... and the number of CONSECUTIVE trajectories that share one image: trajectory b uses image
                           b / traj_per_image.  A multiple of 16 (of 64 with tile_waves = 64).  0 = one image for every trajectory.
                           Forward path only (the backward sweep differentiates one weight set). */
+  const int32_t *launch_order; /* optional (NULL = index order), DEVICE [n_traj]: a permutation of 0..n_traj-1.  Launch slot s
+                          integrates trajectory launch_order[s]; every input and output stays at the trajectory's OWN index, so the
+                          results are those of index order, bit for bit -- only which trajectories share a tile / a wavefront, and
+                          in which sequence the tiles start, changes.  What the reference's callers would sort by: predicted cost
+                          (tiles become homogeneous, the launch a longest-first list schedule) or protocol (the lanes of a
+                          wavefront interpolate one protocol).  Not with traj_per_image.  ABI 6. */
 } ionode_desc;
 
 #define IONODE_DEFAULT_MAX_TOTAL_STEPS 1000000

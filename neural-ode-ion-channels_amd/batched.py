@@ -91,7 +91,7 @@ def solve(model, params, prot_v, y0, t_eval, *, weights=None, mlp_layers=0, mlp_
           prot_t=None, prot_t0=0.0, prot_dt=1.0, prot_of_traj=None, state_dtype=None, rtol=1e-7, atol=1e-9,
           v_oob=-80.0, max_steps=0, max_total_steps=0, max_step=0.0, current=False, obs_g=1.0, obs_e=-86.0, obs_open_state_only=False,
           tile_waves=0, device=None, step_log=None, t_eval_hint="auto", prot_key=None, t_eval_key=None, sse_ref=None,
-          states=True, order=None, traj_per_image=0) -> Solution:
+          states=True, order=None, traj_per_image=0, launch_order="auto") -> Solution:
     """Integrate B trajectories on the GPU (asynchronous on the current stream).
 
     params [B, 8|12] (or [8|12] -> B = 1), prot_v [P, Np] (or [Np]), y0 [B, D] / [D] (broadcast over B),
@@ -102,6 +102,10 @@ def solve(model, params, prot_v, y0, t_eval, *, weights=None, mlp_layers=0, mlp_
     consecutive entries share an MFMA tile and earlier tiles start first.  Every field of the Solution is then in LAUNCH
     order (un-permuting [B, Nt, D] traces would cost a second pass over them; Solution.to_original() does it on request).
     Each trajectory's values do not depend on its tile-mates, so the ordering changes the time, never the results.
+    launch_order: the same schedule WITHOUT moving any data (ionode_desc.launch_order, ABI 6): a permutation of range(B), the
+    kernel maps launch slots to trajectories itself and every field of the Solution stays in the caller's order -- what a training
+    loop wants (`launch_order=schedule.lpt_order(previous.stats[:, 2])`).  "auto" (default): protocol-major order for the
+    one-trajectory-per-lane kernels, index order otherwise; None: index order.  Not combined with `order` or traj_per_image.
     traj_per_image: with `weights` [n_sets, n] (an ensemble of trained nets, a population of initialisations): trajectory b is
     integrated with weight set b // traj_per_image (a multiple of 16); not combined with `order`.
     """
@@ -157,6 +161,15 @@ def solve(model, params, prot_v, y0, t_eval, *, weights=None, mlp_layers=0, mlp_
         if weights is None:
             raise capi.IonodeError("NN models need `weights` (flat fp32 state dict)")
         packed = packed_weights(weights, mlp_layers, mlp_width, dev, key=weights_key)
+    if launch_order is not None and not isinstance(launch_order, str):
+        if order is not None or traj_per_image:
+            raise capi.IonodeError("launch_order cannot be combined with order / traj_per_image")
+        lo = _to(launch_order, torch.int64, dev)
+        if lo.shape != (B,) or int(lo.min()) < 0 or int(lo.max()) >= B or not bool(torch.bincount(lo, minlength=B).eq(1).all()):
+            raise capi.IonodeError(f"launch_order must be a permutation of range({B})")
+        launch_order = lo.to(torch.int32).contiguous()
+    elif order is not None or traj_per_image:
+        launch_order = None
     if traj_per_image and order is not None:
         raise capi.IonodeError("traj_per_image ties trajectories to weight sets by position: it cannot be combined with order")
     r = capi.dopri5(model, params_t, prot_v_t, y0_t, t_eval_t, mlp_packed=packed, traj_per_image=traj_per_image, mlp_layers=mlp_layers,
@@ -165,6 +178,7 @@ def solve(model, params, prot_v, y0, t_eval, *, weights=None, mlp_layers=0, mlp_
                     prot_of_traj=pot_t, rtol=rtol, atol=atol, v_oob=v_oob,
                     max_steps=max_steps, max_total_steps=max_total_steps, max_step=max_step, current=current, obs_g=obs_g, obs_e=obs_e,
                     obs_open_state_only=obs_open_state_only, tile_waves=tile_waves, step_log=step_log,
-                    t_eval_hint=t_eval_hint, t_eval_exact=t_eval_exact, sse_ref=_to(sse_ref, torch.float64, dev), states=states)
+                    t_eval_hint=t_eval_hint, t_eval_exact=t_eval_exact, sse_ref=_to(sse_ref, torch.float64, dev), states=states,
+                    launch_order=launch_order)
     return Solution(y=r["y"], i=r["i"], status=r["status"], stats=r["stats"], kernel=r["kernel"], sse=r["sse"],
                     order=order_t)

@@ -21,7 +21,7 @@ STATUS_TEXT = {
     2: "non-finite values in state `y`",
     3: "max_num_steps exceeded",
 }
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 EXPORTS = (
     "ionode_abi_version", "ionode_last_error", "ionode_mlp_packed_floats", "ionode_mlp_pack",
@@ -44,7 +44,7 @@ class IonodeDesc(C.Structure):
         ("t_eval_t0_hint", C.c_double), ("t_eval_dt_hint", C.c_double),
         ("max_total_steps", C.c_int64), ("ckpt", C.c_void_p), ("ckpt_cap", C.c_int32), ("t_eval_exact", C.c_int32),
         ("sse_ref", C.c_void_p), ("sse_out", C.c_void_p), ("max_step", C.c_double), ("v_at_outputs", C.c_void_p),
-        ("mlp_image_stride", C.c_int64), ("traj_per_image", C.c_int32),
+        ("mlp_image_stride", C.c_int64), ("traj_per_image", C.c_int32), ("launch_order", C.c_void_p),
     ]
 
 
@@ -171,12 +171,37 @@ def _dev_ptr(t, dtype, name, shape=None):
     return C.c_void_p(t.data_ptr())
 
 
+_order_cache = {}
+
+
+def _protocol_major(prot_of_traj):
+    """Stable argsort of the protocol indices (int32, device), cached per tensor version: the launch order in which the
+    trajectories of one protocol are adjacent.  Already-sorted inputs return None (index order)."""
+    key = (prot_of_traj.data_ptr(), prot_of_traj._version, int(prot_of_traj.shape[0]), str(prot_of_traj.device))
+    hit = _order_cache.get(key)
+    if hit is None:
+        p = prot_of_traj.to(torch.int64)
+        if bool((p[1:] >= p[:-1]).all()):
+            hit = (None,)
+        else:
+            hit = (torch.argsort(p, stable=True).to(torch.int32).contiguous(),)
+        if len(_order_cache) > 8:
+            _order_cache.clear()
+        _order_cache[key] = hit
+    return hit[0]
+
+
 def dopri5(model, params, prot_v, y0, t_eval, *, mlp_packed=None, mlp_layers=0, mlp_width=0, prot_t=None,
            prot_t0=0.0, prot_dt=1.0, prot_of_traj=None, rtol=1e-7, atol=1e-9, v_oob=-80.0, max_steps=0,
            max_total_steps=0, max_step=0.0, ckpt=None, current=False, obs_g=1.0, obs_e=-86.0, obs_open_state_only=False, tile_waves=0, stats=True,
            step_log=None, t_eval_hint="auto", t_eval_exact=None, sse_ref=None, states=True, out=None, stream=None,
-           v_at_outputs="auto", traj_per_image=0):
+           v_at_outputs="auto", traj_per_image=0, launch_order="auto"):
     """Launch one batched solve.  Every tensor lives on the current HIP device.
+
+    launch_order: None (index order), an int32 device permutation [B] (ionode_desc.launch_order: slot s integrates trajectory
+    order[s]; results stay at the trajectories' own indices, bit-identical to index order), or "auto": protocol-major order for
+    the one-trajectory-per-lane kernels when several protocols are interleaved (the 64 lanes of a wavefront then interpolate
+    one protocol instead of 64: -5 % on 393 216 HH trajectories over 64 protocols).
 
     params [B, n_params] f64, prot_v [P, Np] f64, y0 [B, D] f32|f64 (selects the state dtype),
     t_eval [Nt] f64.  Returns dict(y [B, Nt, D], i [B, Nt] | None, status [B] i32, stats [B, 4] i64 | None);
@@ -218,6 +243,16 @@ def dopri5(model, params, prot_v, y0, t_eval, *, mlp_packed=None, mlp_layers=0, 
             k = torch.arange(Nt, dtype=torch.float64, device=t_eval.device)
             t_eval_exact = bool(torch.equal(t_eval, float(t_eval_hint[0]) + k * float(t_eval_hint[1])))
         desc.t_eval_exact = int(bool(t_eval_exact))
+    if isinstance(launch_order, str):
+        if launch_order != "auto":
+            raise IonodeError("launch_order: None, 'auto' or an int32 device tensor [B]")
+        launch_order = None
+        lane_wise = model in (MODEL_HH2, MODEL_MARKOV6) or (mlp_width and mlp_width <= 16)
+        if lane_wise and prot_of_traj is not None and P > 1 and B >= 81920 and not traj_per_image:
+            launch_order = _protocol_major(prot_of_traj)
+    if launch_order is not None:
+        _dev_ptr(launch_order, torch.int32, "launch_order", (B,))
+        desc.launch_order = launch_order.data_ptr()
     if ckpt is not None:  # [B, cap, 4 + 8*D] f64 device tensor: accepted-step records for the backward sweep
         _dev_ptr(ckpt, torch.float64, "ckpt", (B, ckpt.shape[1], 4 + 8 * D))
         desc.ckpt = ckpt.data_ptr()

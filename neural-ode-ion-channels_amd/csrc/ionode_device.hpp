@@ -69,6 +69,8 @@ struct KArgs {
                         // kernels' current / objective epilogue then loads V(t_k) instead of re-deriving it per trajectory
   int64_t mlp_stride;   // several weight images (an ensemble / a population of nets): floats between consecutive images ...
   int32_t traj_per_img; // ... and how many consecutive trajectories share one (a multiple of the tile size); 0: one image for all
+  const int32_t *order; // optional launch order (a permutation of 0..B-1): launch slot s integrates trajectory order[s]; every
+                        // input and output stays at the trajectory's own index -- only the tiling / lane assignment changes
 };
 
 // Dormand-Prince / Shampine coefficients.
@@ -1110,9 +1112,11 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
   const int j = lane % LPS;
   const int cset = (NSETS > 1) ? wave / WPS : 0, wis = wave % WPS;  // column set of this wavefront, wavefront index inside the set
   const bool primary = (lane < LPS) && (wis == 0);  // the replica that writes per-trajectory scalars
-  const int traj_raw = blockIdx.x * TPW + cset * LPS + j;
-  const bool valid = traj_raw < a.B;
-  const int traj = valid ? traj_raw : a.B - 1;
+  const int slot_raw = blockIdx.x * TPW + cset * LPS + j;   // launch slot; the trajectory it integrates: a.order[slot] (or slot)
+  const bool valid = slot_raw < a.B;
+  const int slot_c = valid ? slot_raw : a.B - 1;
+  const int traj = a.order ? a.order[slot_c] : slot_c;
+  const int traj_raw = valid ? traj : a.B;   // (== 0 only for the lane that owns trajectory 0: the step log)
 
   using MlpT = MlpTile<G, (T64 ? 1 : (RT > 0 ? RT : 1)), (NT > 0 ? NT : 1), (PD > 0 ? PD : 1), (NSETS > 1 ? 4 : 0)>;
   typename std::conditional<MT::MLP, MlpT, NoMlp>::type mlp;
@@ -1220,6 +1224,8 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
   // emit in the current attempt, compacted (512 bytes behind the 4 KiB of tail buffers; the dispatcher reserves them)
   int *const owp = reinterpret_cast<int *>(tails + 64 * 64);
   int *const elist = owp + 64;
+  int *const trl = elist + 64;   // trajectory index of every lane (the packed passes address rows per lane group)
+  if constexpr (LW) { if (lane < LPS) trl[lane] = traj; }
   if constexpr (LW && !(CF2 && defer)) {
     if (lane < LPS) owp[lane] = pidx;   // packed emission: the trajectory's protocol index, read per lane group
   }
@@ -1535,7 +1541,7 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
               cb[c][0] = (S)cc.x; cb[c][1] = (S)cc.y;
             }
             const int w = owp[jj];
-            const int tr = (int)blockIdx.x * TPW + jj;
+            const int tr = trl[jj];
             const long long G0 = (long long)tr * Nt;  // global sample index of the row's first sample
             const int end = o + n;
             int E = Nt;                                // samples [w, E) go to HBM now, [E, end) wait in the tail buffer
@@ -1701,7 +1707,7 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
               const int2 on2 = *reinterpret_cast<const int2 *>(&h1.y);
               const int end = on2.x + on2.y;
               int idx = on2.x + kk;
-              const int tr = (int)blockIdx.x * TPW + jj;
+              const int tr = trl[jj];
               double *__restrict__ io = nullptr;
               const double *__restrict__ pvb = nullptr, *__restrict__ refb = nullptr, *__restrict__ vtb = nullptr;
               double vk_nxt = 0.0, rf_nxt = 0.0;

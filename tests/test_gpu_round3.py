@@ -259,3 +259,67 @@ def test_odeint_adjoint_is_the_stabilised_sweep(ion, gpu):
         vals.append(float((y[:, 0, 0] * y[:, 0, 1]).sum()))
     fd = (vals[0] - vals[1]) / (2 * h)
     assert abs(fd - ref) <= 1e-4 * abs(ref), (fd, ref)
+
+
+@pytest.mark.parametrize("case", ["hh_states", "hh_objective", "hh_current", "m6_states", "m6_objective", "s00_tile", "s00_tile32", "tiny64", "tiny16", "s09"])
+def test_launch_order_is_a_schedule_not_a_permutation_of_the_results(ion, gpu, case):
+    """ionode_desc.launch_order (ABI 6): launch slot s integrates trajectory order[s]; inputs and outputs stay at the trajectory's
+    own index.  Every kernel family, ragged last tile / wavefront: a random order returns the bits of index order -- states, current,
+    fused objective, status, statistics."""
+    capi = ion.capi
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(len(case))
+    pvs = np.stack([K.activation(v)[1][:1501] for v in (-40, -10, 20, 40)])
+    te = torch.arange(0, 1500, 2.5, dtype=torch.float64, device=dev)
+    kw = dict(prot_t0=0.0, prot_dt=1.0)
+    if case.startswith("hh"):
+        model, p0, y0, B = capi.MODEL_HH2, K.P_HH, [0.0, 1.0], 3 * 64 + 37
+    elif case.startswith("m6"):
+        model, p0, y0, B = capi.MODEL_MARKOV6, K.P_M6, [0.0, 1.0, 0, 0, 0, 0], 2 * 64 + 5
+    else:
+        model, p0, y0 = capi.MODEL_NNF, K.P_HH, [0.0, 1.0]
+        L, N, B = {"s00_tile": (5, 200, 16 * 5 + 3), "s00_tile32": (2, 200, 32 * 3 + 7), "tiny64": (5, 10, 64 * 2 + 9),
+                   "tiny16": (5, 10, 16 * 4 + 2), "s09": (5, 100, 16 * 3 + 1)}[case]
+        w = np.random.default_rng(3).normal(0, 0.1, 2 * N + N + L * (N * N + N) + N + 1).astype(np.float32)
+        kw.update(mlp_packed=torch.from_numpy(capi.mlp_pack(w, L, N)).to(dev), mlp_layers=L, mlp_width=N,
+                  tile_waves={"s00_tile": 4, "s00_tile32": 8, "tiny64": 64, "tiny16": 1, "s09": 0}[case])
+    if case.endswith("objective"):
+        kw.update(sse_ref=torch.from_numpy(rng.normal(0, 0.3, (4, te.numel()))).to(dev), states=False)
+    if case.endswith("current") or case.startswith("s00") or case == "s09":
+        kw.update(current=True)
+    if case.startswith("hh") or case.startswith("m6"):
+        kw.update(tile_waves=64)
+    params = torch.from_numpy(p0[None, :] * rng.uniform(0.8, 1.25, (B, p0.size))).to(dev)
+    pv = torch.from_numpy(pvs).to(dev)
+    y0t = torch.tensor([y0], dtype=torch.float64, device=dev).repeat(B, 1).contiguous()
+    pot = torch.from_numpy(rng.integers(0, 4, B).astype(np.int32)).to(dev)
+    base = capi.dopri5(model, params, pv, y0t, te, prot_of_traj=pot, launch_order=None, **kw)
+    order = torch.from_numpy(rng.permutation(B).astype(np.int32)).to(dev)
+    perm = capi.dopri5(model, params, pv, y0t, te, prot_of_traj=pot, launch_order=order, **kw)
+    auto = capi.dopri5(model, params, pv, y0t, te, prot_of_traj=pot, launch_order=capi._protocol_major(pot), **kw)
+    assert perm["kernel"] == base["kernel"]
+    for other in (perm, auto):
+        for k in ("y", "i", "sse", "status", "stats"):
+            if base.get(k) is not None:
+                assert torch.equal(base[k], other[k]), (case, k)
+    assert bool((base["status"] == 0).all())
+
+
+def test_solve_launch_order_keeps_the_callers_order(ion, gpu):
+    """batched.solve(launch_order=perm): the schedule of solve(order=perm) without the gather -- every field of the Solution is in
+    the caller's order and equals the plain launch bit for bit; cost-sorted order from the previous solve's own counters."""
+    B, Nt = 80, 6001
+    pv = ion.protocols.sinewave(ion.protocols.sinewave_scales(0, B), n_samples=Nt, dt=0.1, xp=torch, device=gpu)
+    params = np.tile(K.P_HH, (B, 1))
+    te = np.arange(0, Nt, 10) * 0.1
+    kw = dict(weights=K.load_weights("s1"), mlp_layers=5, mlp_width=200, prot_t0=0.0, prot_dt=0.1, current=True)
+    y0 = torch.tensor([[0.0, 1.0]], dtype=torch.float64)
+    plain = ion.solve(K.MODEL_NNF, params, pv, y0, te, **kw)
+    srt = ion.solve(K.MODEL_NNF, params, pv, y0, te, launch_order=ion.schedule.lpt_order(plain.stats[:, 2]), **kw)
+    assert srt.order is None
+    for name in ("y", "i", "status", "stats"):
+        assert torch.equal(getattr(plain, name), getattr(srt, name)), name
+    with pytest.raises(ion.IonodeError):
+        ion.solve(K.MODEL_NNF, params, pv, y0, te, launch_order=np.zeros(B, dtype=np.int64), **kw)
+    with pytest.raises(ion.IonodeError):
+        ion.solve(K.MODEL_NNF, params, pv, y0, te, launch_order=np.arange(B), order=np.arange(B), **kw)
