@@ -282,9 +282,11 @@ def closed_form_legs(ion, dev, weights):
     w10 = np.random.default_rng(1).normal(0, 0.1, 2 * N10 + N10 + L10 * (N10 * N10 + N10) + N10 + 1).astype(np.float32)
     legs = {}
     for name, model, p0, y0, B, mlp, f32 in (("hh2", capi.MODEL_HH2, P_HH, [0.0, 1.0], 262144, None, False),
-                                        # the same launch with the trajectories of a protocol adjacent (schedule.protocol_order): the 64 lanes of
-                                        # a wavefront read ONE protocol instead of 64 (the 10 MB of protocols exceed an XCD's 4 MB L2)
-                                        ("hh2_two_full_rounds_protocol_major", capi.MODEL_HH2, P_HH, [0.0, 1.0], 393216, None, False),
+                                        # the library's default for the one-trajectory-per-lane kernels is a protocol-major LAUNCH ORDER
+                                        # (ionode_desc.launch_order, in-kernel: inputs and outputs stay where they are): the 64 lanes of a
+                                        # wavefront read ONE protocol instead of 64 (the 10 MB of protocols exceed an XCD's 4 MB L2).
+                                        # This leg switches it off: trajectory b in launch slot b
+                                        ("hh2_two_full_rounds_index_order", capi.MODEL_HH2, P_HH, [0.0, 1.0], 393216, None, False),
                                         # the 6-state model beyond two residency rounds: its two-wavefronts-per-SIMD build
                                         ("markov6_262144", capi.MODEL_MARKOV6, p_m6, [0.0, 1.0, 0, 0, 0, 0], 262144, None, False),
                                         # 12 resident wavefronts per CU x 256 CUs x 64 trajectories = 196 608 per "round":
@@ -303,9 +305,9 @@ def closed_form_legs(ion, dev, weights):
         params = torch.from_numpy(p0[None, :] * rng.uniform(0.8, 1.25, (B, p0.size))).to(dev)
         y0t = torch.tensor([y0], dtype=torch.float32 if f32 else torch.float64, device=dev).repeat(B, 1).contiguous()
         pot = (torch.arange(B, dtype=torch.int32, device=dev) % n_prot).contiguous()
-        if name.endswith("protocol_major"):
-            pot = pot[ion.schedule.protocol_order(pot)].contiguous()
         kw = dict(prot_t0=0.0, prot_dt=0.1, prot_of_traj=pot, t_eval_hint=(0.0, 0.1), t_eval_exact=True)
+        if name.endswith("index_order"):
+            kw["launch_order"] = None
         if mlp:
             kw.update(mlp_packed=torch.from_numpy(capi.mlp_pack(mlp[0], mlp[1], mlp[2])).to(dev), mlp_layers=mlp[1], mlp_width=mlp[2])
         o = {}
@@ -320,6 +322,7 @@ def closed_form_legs(ion, dev, weights):
         legs[name] = {"kernel": hold["r"]["kernel"], "trajectories": B, "n_out": Nt, "state": "f32" if f32 else "f64", "kernel_ms": ms,
                       "trajectories_per_s": B / ms * 1e3, "bound": "hbm", "achieved": nbytes / ms / 1e6, "peak": PEAK_HBM_GBS,
                       "unit": "GB/s", "frac": nbytes / ms / 1e6 / PEAK_HBM_GBS, "mean_nfe": float(st[:, 2].mean()),
+                      "launch_order": "index" if name.endswith("index_order") else "auto (protocol-major, in-kernel)",
                       "ok": int((hold["r"]["status"] == 0).sum().item())}
         del params, y0t, o, hold
         torch.cuda.empty_cache()
@@ -425,7 +428,7 @@ def config3_leg(ion, dev, weights):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         sol = ion.solve(capi.MODEL_NND, params, pv, y0, te, weights=w, mlp_layers=MLP_L, mlp_width=MLP_N, weights_key="bench-d2",
-                        prot_t0=0.0, prot_dt=0.1, t_eval_hint=(0.0, 0.1), order=order)
+                        prot_t0=0.0, prot_dt=0.1, t_eval_hint=(0.0, 0.1), launch_order=order)
         e1.record()
         torch.cuda.synchronize()
         nfe = sol.to_original(sol.stats[:, 2]).double()
@@ -510,7 +513,7 @@ def launch_order_leg(ion, dev, weights):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         sol = ion.solve(capi.MODEL_NNF, params, pv, y0, te, weights=weights, mlp_layers=MLP_L, mlp_width=MLP_N,
-                        weights_key="bench-s00", prot_t0=0.0, prot_dt=0.1, t_eval_hint=(0.0, 0.1), order=order)
+                        weights_key="bench-s00", prot_t0=0.0, prot_dt=0.1, t_eval_hint=(0.0, 0.1), launch_order=order)
         e1.record()
         torch.cuda.synchronize()
         nfe = sol.to_original(sol.stats[:, 2]).double()

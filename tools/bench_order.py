@@ -41,7 +41,7 @@ def run(order):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     sol = ion.solve(ion.capi.MODEL_NNF, params, pv, y0, te, weights=weights, mlp_layers=5, mlp_width=200, weights_key="s1",
-                    prot_t0=0.0, prot_dt=0.1, t_eval_hint=(0.0, 0.1), order=order)
+                    prot_t0=0.0, prot_dt=0.1, t_eval_hint=(0.0, 0.1), launch_order=order)
     e1.record()
     torch.cuda.synchronize()
     nfe = sol.to_original(sol.stats[:, 2]).double()
