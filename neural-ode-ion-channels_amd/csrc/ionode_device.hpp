@@ -207,6 +207,21 @@ __device__ __forceinline__ double div_by(double a, double b, double rb) {
   return (aq > 0.0 && aq < __builtin_inf()) ? q1 : q0;
 }
 
+// a / b for 0 <= a <= b with b a finite positive step length (every dense-output sample: x = (t_k - t0) / (t1 - t0), t_k in
+// (t0, t1]): the quotient is 0 or in [2^-70, 1], so the pass-through guard of div_by() -- four vector instructions of the ~45 a
+// dense-output sample costs -- is dead weight.  A zero stays +0 through both fma.
+#ifndef IONODE_DIV_POS
+#define IONODE_DIV_POS 1
+#endif
+__device__ __forceinline__ double div_pos(double a, double b, double rb) {
+#if IONODE_DIV_POS
+  const double q0 = a * rb;
+  return fma(fma(-b, q0, a), rb, q0);
+#else
+  return div_by(a, b, rb);
+#endif
+}
+
 // a / b for a compile-time constant b (rb = RN(1 / b)): the same correction step, with the true division kept for the quotients
 // the proof excludes (zero, subnormal range, overflow).  fp32: checked against x / 1000.0f for all 2^32 inputs -- they differ only
 // where |quotient| < 2^-126 (67 108 inputs, all |x| < 9.5e-38); the guards below are far inside the safe range.
@@ -1275,12 +1290,16 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
 #ifndef IONODE_BATCH_LOOKUPS_ALL
 #define IONODE_BATCH_LOOKUPS_ALL 0
 #endif
-#ifndef IONODE_BATCH_LOOKUPS_M6
-#define IONODE_BATCH_LOOKUPS_M6 1   // 6-state kernel at one wavefront per SIMD (NT slot 0): registers to spare, and nothing else hides the round trips
+#ifndef IONODE_BATCH_LOOKUPS_T64
+#define IONODE_BATCH_LOOKUPS_T64 0
 #endif
-    // (tile kernels only: the lane-wise kernels run at 2-3 wavefronts per SIMD and cannot afford the 35 registers -- the N <= 16
-    // kernel at 64 per wavefront went from 251 to 272 VGPRs = one wavefront per SIMD, 58 -> 87 ms; 2-state kernel -4 %)
-    if (((MT::MLP && G > 1) || (IONODE_BATCH_LOOKUPS_M6 && !MT::MLP && D > 2 && NT == 0) || IONODE_BATCH_LOOKUPS_ALL) && a.prot_t == nullptr) {
+#ifndef IONODE_BATCH_LOOKUPS_CF
+#define IONODE_BATCH_LOOKUPS_CF 1   // closed-form kernels of NT slot 0 (6-state at one wavefront per SIMD: -4 .. -10 %; 2-state at three per
+                                    // SIMD since its no-LICM build has the registers: -2 .. -3.4 %; the 2-per-SIMD 2-state builds: not)
+#endif
+    // (not for the N <= 16 kernel at 64 per wavefront: 251 -> 272 VGPRs = one wavefront per SIMD, 58 -> 87 ms; the 2-state kernel lost
+    // 4 % with it while its build still hoisted constants and spilled)
+    if (((MT::MLP && G > 1) || (IONODE_BATCH_LOOKUPS_CF && !MT::MLP && NT == 0) || (IONODE_BATCH_LOOKUPS_T64 && T64) || IONODE_BATCH_LOOKUPS_ALL) && a.prot_t == nullptr) {
       // uniform protocol grid: five indices, five 16-byte loads back to back, then the interpolations -- ONE memory round
       // trip per attempt (protocol_v() per stage time waited for each pair of samples in turn: 5 dependent round trips,
       // ~7 k cycles of the s00 attempt)
@@ -1560,7 +1579,7 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
                   const S *ts = reinterpret_cast<const S *>(tj) + (size_t)(idx - w) * D;
                   out[0] = ts[0]; out[1] = ts[1];
                 } else {
-                  const S x = (S)div_by(te_at(idx) - t0b, denb, rdenb);  // _interp_evaluate: x in fp64, cast; running powers
+                  const S x = (S)div_pos(te_at(idx) - t0b, denb, rdenb);  // _interp_evaluate: x in fp64, cast; running powers
                   S xp = x;
 #pragma unroll
                   for (int d = 0; d < D; ++d) out[d] = cb[0][d] + x * cb[1][d];
@@ -1636,7 +1655,7 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
             double tk = tk_[k];
             if (c0 > 0 && c0 + lane < n) tk = exact ? te_at(idx) : a.t_eval[idx];
             if (c0 + lane < n) {
-              const S x = (S)div_by(tk - t0b, denb, rdenb);  // _interp_evaluate: x = (t - t0) / (t1 - t0) in fp64, cast; running powers
+              const S x = (S)div_pos(tk - t0b, denb, rdenb);  // _interp_evaluate: x = (t - t0) / (t1 - t0) in fp64, cast; running powers
               S out[D];
               S xp = x;
 #pragma unroll
@@ -1740,7 +1759,7 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
                 double rr2 = 0.0;
                 if (on) {
                   const double tk = te_at(idx);
-                  const S x = (S)div_by(tk - t0b, denb, rdenb);  // _interp_evaluate: x in fp64, cast; running powers
+                  const S x = (S)div_pos(tk - t0b, denb, rdenb);  // _interp_evaluate: x in fp64, cast; running powers
                   S out[D];
                   S xp = x;
 #pragma unroll
@@ -1849,7 +1868,7 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
           const int idx = o + c0 + lane;
           if (c0 > 0 && c0 + lane < n) tk = arith_t ? te_at(idx) : a.t_eval[idx];
           if (c0 + lane < n) {
-            const S x = (S)div_by(tk - t0b, denb, rdenb);  // _interp_evaluate: x = (t - t0) / (t1 - t0) in fp64, cast; running powers
+            const S x = (S)div_pos(tk - t0b, denb, rdenb);  // _interp_evaluate: x = (t - t0) / (t1 - t0) in fp64, cast; running powers
             S out[D];
             S xp = x;
 #pragma unroll
@@ -1941,7 +1960,7 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
           const bool ok = tk <= t1b;
           if (owner && ok) {
             // _interp_evaluate: x in fp64, cast; running powers
-            const S x = (S)div_by(tk - t0b, denb, rdenb);
+            const S x = (S)div_pos(tk - t0b, denb, rdenb);
             S out[D];
             S xp = x;
 #pragma unroll
