@@ -29,6 +29,7 @@ ap.add_argument("--layers", type=int, default=5, help="nnf: hidden layers L")
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--tpw", type=int, default=0, help="closed-form: trajectories per wavefront, 64 or 16 (0 = dispatcher default)")
 ap.add_argument("--protocol-major", action="store_true", help="trajectories of one protocol adjacent (lanes of a wavefront share it)")
+ap.add_argument("--index-order", action="store_true", help="launch_order=None: trajectory b in launch slot b (default: the library's auto = protocol-major)")
 ap.add_argument("--stamps", action="store_true", help="library built with -DIONODE_STAMPS: print the phase cycles of wavefront 0")
 a = ap.parse_args()
 
@@ -68,7 +69,7 @@ for rep in range(a.reps + 1):
     r = ion.capi.dopri5(model, params, pv, y0t, te, prot_t0=0.0, prot_dt=0.1, prot_of_traj=pot, current=a.current, tile_waves=a.tpw,
                         mlp_packed=packed, mlp_layers=a.layers if packed is not None else 0,
                         mlp_width=a.width if packed is not None else 0, t_eval_hint=(0.0, 0.1), out=None if a.sse else out,
-                        sse_ref=sse_ref, states=not a.sse, step_log=slog)
+                        sse_ref=sse_ref, states=not a.sse, step_log=slog, **({"launch_order": None} if a.index_order else {}))
     e1.record()
     torch.cuda.synchronize()
     if not a.sse:

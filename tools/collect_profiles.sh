@@ -18,9 +18,9 @@ rocprofv3 --pmc GRBM_GUI_ACTIVE FETCH_SIZE --output-format csv -d $O/pmc2 -- pyt
 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc3 -- python3 bench.py $S > /dev/null 2> $O/pmc3.err || exit 1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_INSTS_SMEM --output-format csv -d $O/pmc4 -- python3 bench.py $S > /dev/null 2> $O/pmc4.err || exit 1
 # the HBM-side kernels: HH 2-state (two residency rounds), 6-state, both N <= 16 kernels (16 / 64 trajectories per wavefront),
-# HH again in protocol-major launch order, and the 6-state two-per-SIMD build (262144)
+# HH again with the library's default (protocol-major) launch order, and the 6-state two-per-SIMD build (262144)
 i=0
-for C in "--model hh --batch 393216" "--model m6 --batch 65536" "--model nnf --batch 65536" "--model nnf --batch 262144" "--model hh --batch 393216 --protocol-major" "--model m6 --batch 262144"; do
+for C in "--model hh --batch 393216 --index-order" "--model m6 --batch 65536" "--model nnf --batch 65536" "--model nnf --batch 262144" "--model hh --batch 393216" "--model m6 --batch 262144"; do
   i=$((i+1)); A="$C --nt 20001 --reps 1"
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_WR --output-format csv -d $O/cf${i}a -- python3 tools/bench_closed_form.py $A > /dev/null 2> $O/cf${i}a.err || exit 1
   rocprofv3 --pmc GRBM_GUI_ACTIVE FETCH_SIZE --output-format csv -d $O/cf${i}b -- python3 tools/bench_closed_form.py $A > /dev/null 2> $O/cf${i}b.err || exit 1

@@ -13,9 +13,9 @@ for f in [f"{R}_bench.json", f"{R}_bench_profiled.json", f"{R}_bench_profiled_le
 names = ["pmc1", "pmc2", "pmc3", "pmc4"] + [f"cf{i}{c}" for i in (1, 2, 3, 4, 5, 6) for c in "abc"]
 summ = {p: json.load(open(f"{O}/{p}.json")) for p in names if os.path.exists(f"{O}/{p}.json")}
 summ["libionode_sha256"] = open(f"{O}/libionode.sha256").read().strip()   # the build the counters belong to (bench.py checks it)
-summ["legend"] = {"pmc1-4": "headline s00 kernel (bench.py --steps 1)", "cf1": "HH 2-state 393216 x 20001 fp64", "cf2": "6-state 65536 x 20001",
+summ["legend"] = {"pmc1-4": "headline s00 kernel (bench.py --steps 1)", "cf1": "HH 2-state 393216 x 20001 fp64, index order (launch_order=None)", "cf2": "6-state 65536 x 20001",
                   "cf3": "NN-f 5x10, 65536 (16 per wavefront)", "cf4": "NN-f 5x10, 262144 (64 per wavefront)",
-                  "cf5": "HH 2-state 393216 x 20001 fp64, protocol-major launch order", "cf6": "6-state 262144 x 20001 (two wavefronts per SIMD)",
+                  "cf5": "HH 2-state 393216 x 20001 fp64, default launch order (auto = protocol-major, in-kernel)", "cf6": "6-state 262144 x 20001 (two wavefronts per SIMD)",
                   "units": "FETCH_SIZE / WRITE_SIZE in KiB (FETCH_SIZE x2 on gfx950 for wide streaming reads); SQ_* summed over the chip"}
 json.dump(summ, open(f"profiles/{R}_pmc_summary.json", "w"), indent=1)
 b = json.load(open(f"profiles/{R}_bench.json"))
