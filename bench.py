@@ -63,6 +63,9 @@ def main():
                     help="skip the closed-form / gradient / regression measurements appended to the JSON line")
     ap.add_argument("--stamps", action="store_true", help="diagnostic build (-DIONODE_STAMPS): print phase shares")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group even at world size 1 (under torch.distributed.run): runs the RCCL collectives "
+                         "of the N > 1 path with one rank on a 1-GPU box")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="rehearsal of the N > 1 code path on a 1-GPU box: every rank uses cuda:0 (use with gloo)")
     args = ap.parse_args()
@@ -84,7 +87,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or (args.force_dist and "MASTER_ADDR" in os.environ):
         import torch.distributed as dist
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI

@@ -323,3 +323,31 @@ def test_solve_launch_order_keeps_the_callers_order(ion, gpu):
         ion.solve(K.MODEL_NNF, params, pv, y0, te, launch_order=np.zeros(B, dtype=np.int64), **kw)
     with pytest.raises(ion.IonodeError):
         ion.solve(K.MODEL_NNF, params, pv, y0, te, launch_order=np.arange(B), order=np.arange(B), **kw)
+
+
+def test_rccl_path_runs_under_the_drivers_launcher_with_one_rank(ion, gpu):
+    """The driver launches N > 1 as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py
+    --gpus N`, backend nccl (= RCCL).  A 1-GPU box cannot hold two RCCL ranks, but it can run that exact launch with one rank and the
+    process group forced on: RCCL initialises, the timing / loss / status all-reduces of the N > 1 path execute on the device, and
+    the line reports the backend and world size torch.distributed saw."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--batch", "64", "--nt", "5001",
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extra-legs"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["config"]["dist_backend"] == "nccl" and res["config"]["dist_world_size"] == 1
+    assert res["n_gpus"] == 1 and res["config"]["trajectories_ok"] == 64 and res["value"] > 0
