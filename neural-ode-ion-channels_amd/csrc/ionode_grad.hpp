@@ -42,7 +42,10 @@ struct GArgs {
   double *grad_y0;         // [B][2]
   int32_t ckpt_cap, it_begin, it_end, n_iter;
   int64_t record_floats;
+  unsigned long long *signs;  // two-phase sweep: LeakyReLU' bits of every tile evaluation, [n_tiles][it_end - it_begin][6][GRAD_SIGN_WORDS][256]
+                              // written by ionode_grad_recompute_kernel, read by the sweep (NULL: the sweep recomputes the forward itself)
 };
+constexpr int GRAD_SIGN_WORDS = 8;   // 64-bit words per lane and evaluation (Signs below)
 
 constexpr int GRAD_STATE = 12;
 
@@ -94,7 +97,9 @@ struct GradMlp {
   unsigned fwd0, bwd0;  // byte offsets of the fragment sections
   int L, wave, lane;
 
-  __device__ __forceinline__ void init(const GArgs &a, unsigned char *smem, int wave_, int lane_) {
+  // first_sec: the fragment section of the FIRST product this workgroup will run (fwd0 layer 0: one-phase sweep, regression,
+  // recompute kernel; bwd0 layer L-1: the sweep of the two-phase scheme)
+  __device__ __forceinline__ void init(const GArgs &a, unsigned char *smem, int wave_, int lane_, bool bwd_only = false) {
     L = a.k.L; wave = wave_; lane = lane_;
     Hs = reinterpret_cast<f32x4 *>(smem);
     Ds = Hs + (size_t)2 * NT * 64;
@@ -111,7 +116,8 @@ struct GradMlp {
     rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.img), 0, (int)(grad_img_floats(L, NT) * 4), 0x00020000);
     fwd0 = (unsigned)(grad_img_fwd(L, NT) * 4);
     bwd0 = (unsigned)(grad_img_bwd(L, NT) * 4);
-    refill_all(fwd0, 0);  // prime: first product of the first evaluation
+    if (bwd_only) refill_all(bwd0, L - 1);
+    else refill_all(fwd0, 0);  // prime: first product of the first evaluation
     __syncthreads();
   }
   __device__ __forceinline__ int ktile(int s) const { return (s + wave) % NT; }  // wave-uniform (scalar ALU)
@@ -127,41 +133,63 @@ struct GradMlp {
   struct Signs {  // 64-bit words, 64 / BITS layers each; scalar members (no indexed array: that would live in scratch)
     static constexpr int PER = 64 / BITS;
     unsigned long long w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0, w5 = 0, w6 = 0, w7 = 0;
-    // N = 500 (eight words): pure mask arithmetic.  A chain of eight selects over the members is folded by hipcc into ONE load
-    // with a selected address, which pins the struct in scratch (72 B per lane in round 2's builds); and/or on values cannot be.
+    // Pure mask arithmetic: a chain of selects over the members is folded by hipcc into ONE load with a selected address, which
+    // pins the struct in scratch (72 B per lane in round 2's N = 500 builds; 40 B in the N <= 16 builds once the words are passed
+    // by reference); and/or on values cannot be.
     static __device__ __forceinline__ unsigned long long on(int k, int i) { return (k == i) ? ~0ull : 0ull; }
     __device__ __forceinline__ void put(int l, unsigned bits) {
       const int sh = (l % PER) * BITS;
       const unsigned long long full = (BITS == 32) ? 0xffffffffull : 0xffffull;
       const unsigned long long m = ~(full << sh), v = (unsigned long long)bits << sh;
       const int k = l / PER;
+      w0 = (w0 & (m | ~on(k, 0))) | (v & on(k, 0));
+      w1 = (w1 & (m | ~on(k, 1))) | (v & on(k, 1));
+      w2 = (w2 & (m | ~on(k, 2))) | (v & on(k, 2));
+      w3 = (w3 & (m | ~on(k, 3))) | (v & on(k, 3));
       if constexpr (PER < 4) {
-        w0 = (w0 & (m | ~on(k, 0))) | (v & on(k, 0));
-        w1 = (w1 & (m | ~on(k, 1))) | (v & on(k, 1));
-        w2 = (w2 & (m | ~on(k, 2))) | (v & on(k, 2));
-        w3 = (w3 & (m | ~on(k, 3))) | (v & on(k, 3));
         w4 = (w4 & (m | ~on(k, 4))) | (v & on(k, 4));
         w5 = (w5 & (m | ~on(k, 5))) | (v & on(k, 5));
         w6 = (w6 & (m | ~on(k, 6))) | (v & on(k, 6));
         w7 = (w7 & (m | ~on(k, 7))) | (v & on(k, 7));
-      } else {
-        w0 = (k == 0) ? ((w0 & m) | v) : w0;
-        w1 = (k == 1) ? ((w1 & m) | v) : w1;
-        w2 = (k == 2) ? ((w2 & m) | v) : w2;
-        w3 = (k == 3) ? ((w3 & m) | v) : w3;
       }
     }
     __device__ __forceinline__ unsigned get(int l) const {
       const int k = l / PER;
-      unsigned long long w;
-      if constexpr (PER < 4)
-        w = (w0 & on(k, 0)) | (w1 & on(k, 1)) | (w2 & on(k, 2)) | (w3 & on(k, 3)) | (w4 & on(k, 4)) | (w5 & on(k, 5)) | (w6 & on(k, 6)) | (w7 & on(k, 7));
-      else
-        w = (k == 0) ? w0 : ((k == 1) ? w1 : ((k == 2) ? w2 : w3));
+      unsigned long long w = (w0 & on(k, 0)) | (w1 & on(k, 1)) | (w2 & on(k, 2)) | (w3 & on(k, 3));
+      if constexpr (PER < 4) w |= (w4 & on(k, 4)) | (w5 & on(k, 5)) | (w6 & on(k, 6)) | (w7 & on(k, 7));
       const unsigned long long full = (BITS == 32) ? 0xffffffffull : 0xffffull;
       return (unsigned)((w >> ((l % PER) * BITS)) & full);
     }
   };
+  // two-phase sweep: the sign words travel through HBM, [word][256 threads] per tile evaluation (coalesced)
+  __device__ __forceinline__ void signs_store(unsigned long long *__restrict__ dst, const Signs &mk) const {
+    const int tid = wave * 64 + lane;
+    const int nw = (L + Signs::PER) / Signs::PER;   // layers 0..L
+    dst[tid] = mk.w0;
+    if (nw > 1) dst[256 + tid] = mk.w1;
+    if (nw > 2) dst[512 + tid] = mk.w2;
+    if (nw > 3) dst[768 + tid] = mk.w3;
+    if constexpr (Signs::PER < 4) {
+      if (nw > 4) dst[1024 + tid] = mk.w4;
+      if (nw > 5) dst[1280 + tid] = mk.w5;
+      if (nw > 6) dst[1536 + tid] = mk.w6;
+      if (nw > 7) dst[1792 + tid] = mk.w7;
+    }
+  }
+  __device__ __forceinline__ void signs_load(const unsigned long long *__restrict__ src, Signs &mk) const {
+    const int tid = wave * 64 + lane;
+    const int nw = (L + Signs::PER) / Signs::PER;
+    mk.w0 = src[tid];
+    if (nw > 1) mk.w1 = src[256 + tid];
+    if (nw > 2) mk.w2 = src[512 + tid];
+    if (nw > 3) mk.w3 = src[768 + tid];
+    if constexpr (Signs::PER < 4) {
+      if (nw > 4) mk.w4 = src[1024 + tid];
+      if (nw > 5) mk.w5 = src[1280 + tid];
+      if (nw > 6) mk.w6 = src[1536 + tid];
+      if (nw > 7) mk.w7 = src[1792 + tid];
+    }
+  }
   __device__ __forceinline__ void refill_all(unsigned sec, int l) {
 #pragma unroll
     for (int s = 0; s < PD; ++s)
@@ -240,13 +268,33 @@ struct GradMlp {
   // x = (V/100, a) as the forward casts them, seed = adjoint of the net output.  Returns seed * d net / d x1.
   // rec != NULL: the (h_l, d_l) tiles and the scalars of this evaluation are streamed there for ionode_grad_reduce.
   __device__ __forceinline__ float vjp(float x0, float x1, float seed, float *__restrict__ rec) {
-    return vjp_from_output(x0, x1, rec, [seed](float) -> float { return seed; });
+    Signs mk;
+    auto fn = [seed](float) -> float { return seed; };
+    return vjp_phases<decltype(fn), 0>(x0, x1, rec, fn, mk);
+  }
+  // two-phase sweep: forward recompute only (bits to mk) / backward products only (bits from mk)
+  __device__ __forceinline__ void vjp_forward(float x0, float x1, float *__restrict__ rec, Signs &mk) {
+    auto none = [](float) -> float { return 0.0f; };
+    (void)vjp_phases<decltype(none), 1>(x0, x1, rec, none, mk);
+  }
+  __device__ __forceinline__ float vjp_backward(float seed, float *__restrict__ rec, Signs &mk) {
+    auto fn = [seed](float) -> float { return seed; };
+    return vjp_phases<decltype(fn), 2>(0.0f, 0.0f, rec, fn, mk);
   }
 
   // The same product with the seed computed from the net's output: seed = seed_of(net([x0, x1])) per lane (regression:
   // d loss / d net).  The output layer runs only when the functor needs it; a constant functor leaves it out.
+  // PHASE 0: the whole product (forward recompute + backward) in one call.  Two-phase sweep: PHASE 1 = the forward
+  // recompute only (activations to the record stream, LeakyReLU' bits to `mk`; the caller stores them: independent of the
+  // adjoint, so every step of every tile can run it at once on the whole chip); PHASE 2 = the backward products only, from the
+  // bits of PHASE 1 (the sequential part).  The arithmetic of each half is the same code, so the results are bit-identical.
   template <typename SeedFn>
   __device__ __forceinline__ float vjp_from_output(float x0, float x1, float *__restrict__ rec, SeedFn seed_of) {
+    Signs mk;
+    return vjp_phases<SeedFn, 0>(x0, x1, rec, seed_of, mk);
+  }
+  template <typename SeedFn, int PHASE>
+  __device__ __forceinline__ float vjp_phases(float x0, float x1, float *__restrict__ rec, SeedFn seed_of, Signs &mk) {
     const int q = lane >> 4;
     f32x4 *__restrict__ recH = reinterpret_cast<f32x4 *>(rec);
     f32x4 *__restrict__ recD = recH + (size_t)(L + 1) * NT * 64;
@@ -254,7 +302,8 @@ struct GradMlp {
     int par = 0;  // partial-sum buffer of the running product
     // ---- forward recompute.  The activations of layer l live in LDS buffer l & 1 (the next layer's B operand) and go to the
     // record stream as they are produced; what the backward pass needs of them afterwards is the sign, kept here ----
-    Signs mk;
+    float seed = 0.0f;
+    if constexpr (PHASE != 2) {
     auto layer0 = [&](int rt) {
       f32x4 h;
 #pragma unroll
@@ -298,7 +347,9 @@ struct GradMlp {
         const f32x4 bz = *reinterpret_cast<const f32x4 *>(biasS + (l - 1) * NP + 16 * (G * F + j) + 4 * q);
         accR[j] = (wave == 0) ? bz : f32x4{0, 0, 0, 0};  // partial sum 0 carries the bias
       }
-      product(fwd0, l - 1, l < L ? fwd0 : bwd0, l < L ? l : L - 1, Hs + (size_t)((l - 1) & 1) * NT * 64, accF, accR);
+      // (the product behind this one: the next forward layer; behind the last: the first backward product, or -- recompute
+      // kernel -- the next evaluation's first forward layer)
+      product(fwd0, l - 1, (l < L || PHASE == 1) ? fwd0 : bwd0, l < L ? l : (PHASE == 1 ? 0 : L - 1), Hs + (size_t)((l - 1) & 1) * NT * 64, accF, accR);
       f32x4 *__restrict__ Hl = Hs + (size_t)(l & 1) * NT * 64;
       unsigned b16 = 0u;
 #pragma unroll
@@ -329,8 +380,15 @@ struct GradMlp {
       mk.put(l, b16);
       par ^= 1;
     }
+    if constexpr (PHASE == 1) {
+      if (rec && wave == 0 && lane < 16) {
+        float *sc = rec + (size_t)2 * (L + 1) * NT * 256;
+        sc[lane] = x0; sc[16 + lane] = x1; sc[48 + lane] = 0.0f;   // (the seed slot is the sweep's)
+      }
+      __syncthreads();  // the next evaluation's layer 0 rewrites Hs[0]
+      return 0.0f;
+    }
     // ---- net = wl . h_L + bl (four partial chains, one per lane group, as the forward kernel's last layer), then the seed ----
-    float seed;
     {
       float part = 0.0f;
 #pragma unroll
@@ -343,19 +401,25 @@ struct GradMlp {
       const float pair = part + __shfl_xor(part, 16);
       seed = seed_of((pair + __shfl_xor(pair, 32)) + wlS[NP]);
     }
+    } else {
+      seed = seed_of(0.0f);   // PHASE 2: the ODE sweep's seed does not depend on the net's output
+    }
     // ---- backward: d_L = seed * wl * lrelu'(h_L); d_{l-1} = (W_l^T d_l) * lrelu'(h_{l-1}) ----
+    {
+      const unsigned sgL = mk.get(L);   // this wavefront's full tiles, then the remainder tiles (== h > 0 of the activations in LDS)
 #pragma unroll
     for (int i = 0; i < (NT + G - 1) / G; ++i) {
       const int rt = wave + i * G;
       if (rt < NT) {
-        const f32x4 h = Hs[((size_t)(L & 1) * NT + rt) * 64 + lane];
         const f32x4 w = *reinterpret_cast<const f32x4 *>(wlS + 16 * rt + 4 * q);
+        const int sl = (i < F) ? 4 * i : 4 * (F + rt - G * F);   // bit slot of row tile rt in this wavefront's word
         f32x4 d;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) d[r] = (seed * w[r]) * (h[r] > 0.0f ? 1.0f : 0.01f);
+        for (int r = 0; r < 4; ++r) d[r] = (seed * w[r]) * (((sgL >> (sl + r)) & 1u) ? 1.0f : 0.01f);
         Ds[((L & 1) * NT + rt) * 64 + lane] = d;
         if (rec) rec_store(recD + ((size_t)L * NT + rt) * 64, d);
       }
+    }
     }
     __syncthreads();
     for (int l = L; l >= 1; --l) {
@@ -364,7 +428,7 @@ struct GradMlp {
       for (int i = 0; i < F; ++i) accF[i] = f32x4{0, 0, 0, 0};
 #pragma unroll
       for (int j = 0; j < R; ++j) accR[j] = f32x4{0, 0, 0, 0};
-      product(bwd0, l - 1, l > 1 ? bwd0 : fwd0, l > 1 ? l - 2 : 0, Ds + (size_t)(l & 1) * NT * 64, accF, accR);
+      product(bwd0, l - 1, (l > 1 || PHASE == 2) ? bwd0 : fwd0, l > 1 ? l - 2 : (PHASE == 2 ? L - 1 : 0), Ds + (size_t)(l & 1) * NT * 64, accF, accR);
       const unsigned sg = mk.get(l - 1);  // signs of h_{l-1}: this wavefront's full tiles, then the remainder tiles
 #pragma unroll
       for (int i = 0; i < F; ++i) {
@@ -401,14 +465,15 @@ struct GradMlp {
     const float out = pair + __shfl_xor(pair, 32);
     if (rec && wave == 0 && lane < 16) {
       float *sc = rec + (size_t)2 * (L + 1) * NT * 256;
-      sc[lane] = x0; sc[16 + lane] = x1; sc[32 + lane] = seed; sc[48 + lane] = 0.0f;
+      if constexpr (PHASE == 2) sc[32 + lane] = seed;
+      else { sc[lane] = x0; sc[16 + lane] = x1; sc[32 + lane] = seed; sc[48 + lane] = 0.0f; }
     }
     __syncthreads();  // the next evaluation's layer 0 rewrites Hs[0] / Ds
     return out;
   }
 };
 
-template <int MODEL, typename S, int NT>
+template <int MODEL, typename S, int NT, int TWO = 0>
 __global__ void __launch_bounds__(256) ionode_dopri5_backward_kernel(const GArgs a) {
   constexpr int D = ModelTraits<MODEL>::D, NPAR = ModelTraits<MODEL>::NPAR;
   constexpr bool M6 = MODEL == IONODE_MODEL_MARKOV6;  // 6-state model (train-d1.py:165-187): f = M(rates(V)) y, closed form
@@ -430,7 +495,7 @@ __global__ void __launch_bounds__(256) ionode_dopri5_backward_kernel(const GArgs
   GradMlp<NT> mlp;
   double *__restrict__ Gs = reinterpret_cast<double *>(smem);  // [16][5 * D] fp64 scratch
   if constexpr (HAS_MLP) {
-    mlp.init(a, smem, wave, lane);
+    mlp.init(a, smem, wave, lane, TWO != 0);
     Gs = mlp.gs();
   }
 
@@ -605,7 +670,17 @@ __global__ void __launch_bounds__(256) ionode_dopri5_backward_kernel(const GArgs
       const float x0 = (float)(v / 100.0), x1 = (float)av;
       const float seedf = (float)(seed[0] / 1000.0);
       float dx1 = 0.0f;
-      if constexpr (HAS_MLP) dx1 = mlp.vjp(x0, x1, seedf, rec_it ? rec_it + (size_t)e * a.record_floats : nullptr);
+      if constexpr (HAS_MLP) {
+        float *__restrict__ rec_e = rec_it ? rec_it + (size_t)e * a.record_floats : nullptr;
+        if constexpr (TWO) {
+          // two-phase sweep: the forward recompute of this evaluation ran in ionode_grad_recompute_kernel; its LeakyReLU' bits
+          typename GradMlp<NT>::Signs mk;
+          mlp.signs_load(a.signs + (((size_t)blockIdx.x * (a.it_end - a.it_begin) + (it - a.it_begin)) * 6 + e) * (GRAD_SIGN_WORDS * 256), mk);
+          dx1 = mlp.vjp_backward(seedf, rec_e, mk);
+        } else {
+          dx1 = mlp.vjp(x0, x1, seedf, rec_e);
+        }
+      }
       // closed-form terms of the RHS and their parameter gradients
       const double e3 = det_exp(p[5] * v), e4 = det_exp(-p[7] * v);
       const double k3 = p[4] * e3, k4 = p[6] * e4;
@@ -662,6 +737,83 @@ __global__ void __launch_bounds__(256) ionode_dopri5_backward_kernel(const GArgs
       for (int i = 0; i < NPAR; ++i) a.grad_params[(size_t)traj * NPAR + i] = gp[i];
 #pragma unroll
       for (int d = 0; d < D; ++d) a.grad_y0[(size_t)traj * D + d] = lam[d] + (double)gy[d];  // solution[0] = y0
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Two-phase sweep, phase A.  The stage inputs of an accepted step come from its checkpoint alone (Y_i = y + dt sum_j beta_ij k_j),
+// not from the adjoint: the forward half of every vector-Jacobian product -- half the MFMA work of the sweep -- is independent
+// across steps AND tiles.  The one-phase sweep runs it inside the sequential walk, one workgroup per tile: 64 of 256 compute
+// units at BASELINE configs[4]'s per-GPU batch.  This kernel runs it for every (tile, step) at once: grid = (tiles, blocks of
+// IB iterations), activations into the record stream (for ionode_grad_reduce), LeakyReLU' bits into `signs` for the sweep, which
+// then only walks the backward products.  Same code as the one-phase product (GradMlp::vjp_from_output), same bits.
+// ---------------------------------------------------------------------------------------------
+constexpr int GRAD_RECOMPUTE_IB = 4;   // iterations per workgroup
+
+template <int MODEL, typename S, int NT>
+__global__ void __launch_bounds__(256) ionode_grad_recompute_kernel(const GArgs a) {
+  constexpr int D = ModelTraits<MODEL>::D;
+  static_assert(ModelTraits<MODEL>::MLP && D == 2, "NN-f / NN-d");
+  using R = Real<S>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15;
+  const int traj_raw = blockIdx.x * 16 + j;
+  const bool valid = traj_raw < a.k.B;
+  const int traj = valid ? traj_raw : a.k.B - 1;
+  GradMlp<NT> mlp;
+  mlp.init(a, smem, wave, lane);
+  const int pidx = a.k.prot_of_traj ? a.k.prot_of_traj[traj] : (traj % a.k.P);
+  const double *__restrict__ pv = a.k.prot_v + (size_t)pidx * a.k.Np;
+  const int nst = valid ? a.nacc[traj] : 0;
+  const int RECW = 4 + 8 * D;
+  const double *__restrict__ ck = a.ckpt + (size_t)traj * a.ckpt_cap * RECW;
+  const int it_lo = a.it_begin + (int)blockIdx.y * GRAD_RECOMPUTE_IB;
+  const int it_hi = (it_lo + GRAD_RECOMPUTE_IB < a.it_end) ? it_lo + GRAD_RECOMPUTE_IB : a.it_end;
+  for (int it = it_lo; it < it_hi; ++it) {
+    // (the same reconstruction as the sweep's: ionode_dopri5_backward_kernel)
+    const int s = nst - 1 - it;
+    const bool step = s >= 0;
+    const bool initev = (s == -1) && nst > 0;
+    double t0 = 0.0, dt = 1.0, y[D], k[7][D];
+    {
+      const double *rec = ck + (size_t)(step ? s : 0) * RECW;
+      const bool ld = step || initev;
+      if (ld) { t0 = rec[0]; dt = rec[1]; }
+#pragma unroll
+      for (int d = 0; d < D; ++d) y[d] = ld ? rec[4 + d] : 0.0;
+#pragma unroll
+      for (int jx = 0; jx < 7; ++jx)
+#pragma unroll
+        for (int d = 0; d < D; ++d) k[jx][d] = step ? rec[4 + D + jx * D + d] : 0.0;
+    }
+    const double t1 = t0 + dt;
+    const S t0s = (S)t0, dts_s = (S)dt, t1s = (S)t1;
+    const double dts = (double)dts_s;
+    const size_t ev0 = ((size_t)blockIdx.x * (a.it_end - a.it_begin) + (it - a.it_begin)) * 6;
+#pragma unroll 1
+    for (int e = 0; e < 6; ++e) {
+      const int i = 5 - e;
+      double Y0;
+      double tq;
+      if (step) {
+        double sacc = 0.0;
+        for (int jx = 0; jx <= i; ++jx) sacc += k[jx][0] * (kBeta[i][jx] * dts);
+        Y0 = y[0] + sacc;
+        const S ti = (i >= 4) ? R::prev_(t1s) : t0s + (S)kAlpha[i] * dts_s;
+        tq = (double)ti;
+      } else {
+        Y0 = y[0];
+        tq = (double)(S)a.k.t_eval[0];
+      }
+      double v;
+      protocol_v(a.k, pv, tq, v);
+      const float x0 = (float)(v / 100.0), x1 = (float)Y0;
+      typename GradMlp<NT>::Signs mk;
+      mlp.vjp_forward(x0, x1, a.records ? a.records + (ev0 + e) * a.record_floats : nullptr, mk);
+      mlp.signs_store(a.signs + (ev0 + e) * (GRAD_SIGN_WORDS * 256), mk);
     }
   }
 }

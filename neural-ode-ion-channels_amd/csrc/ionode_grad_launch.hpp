@@ -8,9 +8,28 @@ namespace ionode {
 
 using SweepFn = void (*)(const GArgs &, unsigned grid, size_t lds, hipStream_t);
 
+// a.signs == NULL: the one-phase sweep (forward recompute inside the walk).  a.signs given and a.grad_y == NULL: phase A of the
+// two-phase sweep (ionode_grad_recompute_kernel, every (tile, step) at once); a.signs and a.grad_y: phase B (backward products only).
 template <int MODEL, typename S, int NT>
 void launch_sweep(const GArgs &a, unsigned grid, size_t lds, hipStream_t s) {
-  auto kern = ionode_dopri5_backward_kernel<MODEL, S, NT>;
+  if constexpr (ModelTraits<MODEL>::MLP) {
+    if (a.signs != nullptr && a.grad_y == nullptr) {
+      auto kern = ionode_grad_recompute_kernel<MODEL, S, NT>;
+      if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      const unsigned nb = (unsigned)((a.it_end - a.it_begin + GRAD_RECOMPUTE_IB - 1) / GRAD_RECOMPUTE_IB);
+      hipLaunchKernelGGL(kern, dim3(grid, nb), dim3(256), lds, s, a);
+      return;
+    }
+    if (a.signs != nullptr) {
+      auto kern = ionode_dopri5_backward_kernel<MODEL, S, NT, 1>;
+      if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
+      return;
+    }
+  }
+  auto kern = ionode_dopri5_backward_kernel<MODEL, S, NT, 0>;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);

@@ -18,6 +18,7 @@ Three launches per backward (csrc/ionode_grad.hpp, ionode_grad_reduce.hpp), all 
 There is no CPU fallback: without libionode.so or a HIP device every call raises.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -167,33 +168,70 @@ class _Solve(torch.autograd.Function):
         chunk = n_iter if not need_w else max(1, min(n_iter, budget // (tiles * 6 * recf * 4)))
         acc = torch.zeros(partf, dtype=torch.float64, device=dev) if need_w else None
         main = torch.cuda.current_stream(dev)
-        stream = main.cuda_stream
-        # Two record buffers and a side stream: the reduction of chunk k (whole chip, HBM-bound) runs beside the sweep of chunk
-        # k + 1 (one workgroup per 16-trajectory tile: 64 of 256 CUs at config 5's per-GPU batch).
+        # Two-phase sweep (NN models; csrc/ionode_grad.hpp): the forward half of every vector-Jacobian product needs
+        # the step's checkpoint only, so phase A (ionode_dopri5_backward_recompute) runs it for every (tile, step) of a chunk at
+        # once on the whole chip, on its own stream, one chunk AHEAD of phase B (ionode_dopri5_backward_sweep: the sequential walk
+        # with the backward products only, one workgroup per tile); the reduction of a finished chunk runs on a third stream.
+        # Buffers (records, sign words) are double: chunk k + 1's phase A fills one pair while chunk k's walk / reduce use the other.
+        two_phase = bool(cfg.get("two_phase", os.environ.get("IONODE_GRAD_ONE_PHASE", "0") != "1")) and image is not None
         n_chunks = (n_iter + chunk - 1) // chunk
-        n_buf = 2 if (need_w and n_chunks > 1) else 1
+        n_buf = 2 if (n_chunks > 1 and (need_w or two_phase)) else 1
         if need_w and n_buf == 2:
             chunk = max(1, min(n_iter, (budget // 2) // (tiles * 6 * recf * 4)))
-        records = [torch.empty(tiles * chunk * 6 * recf, dtype=torch.float32, device=dev) for _ in range(n_buf)] if need_w else [None]
-        side = torch.cuda.Stream(dev) if n_buf == 2 else main
-        free = [None] * n_buf   # event: the reduce that last read this buffer has finished
+        elif two_phase and not need_w:
+            chunk = max(1, min(n_iter, 256))      # nothing to budget but the sign words: bounded chunks keep phase A ahead of the walk
+            n_chunks = (n_iter + chunk - 1) // chunk
+            n_buf = 2 if n_chunks > 1 else 1
+        records = [torch.empty(tiles * chunk * 6 * recf, dtype=torch.float32, device=dev) for _ in range(n_buf)] if need_w else [None] * n_buf
+        sgw = int(lib.ionode_grad_sign_words()) if two_phase else 0
+        signs = [torch.empty(tiles * chunk * 6 * sgw, dtype=torch.int64, device=dev) for _ in range(n_buf)] if two_phase else [None] * n_buf
+        side = torch.cuda.Stream(dev) if (need_w and n_buf == 2) else main          # reductions
+        pre = torch.cuda.Stream(dev) if (two_phase and n_buf == 2) else main         # phase A
+        if pre is not main:
+            pre.wait_stream(main)    # gy / state / inputs were produced on the caller's stream
+        free = [None] * n_buf   # event: the reduce (or, without weight gradients, the walk) that last used this buffer pair has finished
+        ready = [None] * n_buf  # event: phase A has filled this buffer pair
         desc.ckpt, desc.ckpt_cap = ckpt.data_ptr(), ckpt.shape[1]
-        for k, it0 in enumerate(range(0, n_iter, chunk)):
-            it1 = min(n_iter, it0 + chunk)
-            rec = records[k % n_buf]
-            if free[k % n_buf] is not None:
-                main.wait_event(free[k % n_buf])
-            rc = lib.ionode_dopri5_backward(C.byref(desc), it0, it1, n_iter, _ptr(image), _ptr(params), _ptr(cfg["prot_v"]),
-                                            _ptr(cfg.get("prot_t")), _ptr(cfg.get("prot_of_traj")), _ptr(cfg["t_eval"]),
-                                            _ptr(n_acc), _ptr(gy), _ptr(state), _ptr(rec), _ptr(g_params), _ptr(g_y0),
-                                            C.c_void_p(stream))
+        common = (_ptr(image), _ptr(params), _ptr(cfg["prot_v"]), _ptr(cfg.get("prot_t")), _ptr(cfg.get("prot_of_traj")),
+                  _ptr(cfg["t_eval"]), _ptr(n_acc))
+        bounds = [(it0, min(n_iter, it0 + chunk)) for it0 in range(0, n_iter, chunk)]
+
+        def phase_a(k):
+            it0, it1 = bounds[k]
+            b = k % n_buf
+            if free[b] is not None:
+                pre.wait_event(free[b])
+            rc = lib.ionode_dopri5_backward_recompute(C.byref(desc), it0, it1, n_iter, *common, _ptr(records[b]), _ptr(signs[b]),
+                                                      C.c_void_p(pre.cuda_stream))
             if rc != 0:
-                raise capi.IonodeError(f"ionode_dopri5_backward failed ({rc}): {lib.ionode_grad_last_error().decode()}")
+                raise capi.IonodeError(f"ionode_dopri5_backward_recompute failed ({rc}): {lib.ionode_grad_last_error().decode()}")
+            ev = torch.cuda.Event()
+            ev.record(pre)
+            ready[b] = ev
+
+        if two_phase:
+            phase_a(0)
+        for k, (it0, it1) in enumerate(bounds):
+            b = k % n_buf
+            rec = records[b]
+            if two_phase:
+                if k + 1 < len(bounds) and n_buf == 2:
+                    phase_a(k + 1)                      # one chunk ahead, beside this chunk's walk
+                main.wait_event(ready[b])
+                rc = lib.ionode_dopri5_backward_sweep(C.byref(desc), it0, it1, n_iter, *common, _ptr(gy), _ptr(state), _ptr(rec),
+                                                      _ptr(signs[b]), _ptr(g_params), _ptr(g_y0), C.c_void_p(main.cuda_stream))
+            else:
+                if free[b] is not None:
+                    main.wait_event(free[b])
+                rc = lib.ionode_dopri5_backward(C.byref(desc), it0, it1, n_iter, *common, _ptr(gy), _ptr(state), _ptr(rec),
+                                                _ptr(g_params), _ptr(g_y0), C.c_void_p(main.cuda_stream))
+            if rc != 0:
+                raise capi.IonodeError(f"backward sweep failed ({rc}): {lib.ionode_grad_last_error().decode()}")
+            swept = torch.cuda.Event()
+            swept.record(main)
             if need_w:
                 n_rec = tiles * (it1 - it0) * 6
                 n_slabs = int(max(1, min(256 // (L + 2), n_rec // 4)))
-                swept = torch.cuda.Event()
-                swept.record(main)
                 side.wait_event(swept)
                 with torch.cuda.stream(side):
                     partials = torch.empty((n_slabs, partf), dtype=torch.float32, device=dev)
@@ -203,9 +241,15 @@ class _Solve(torch.autograd.Function):
                     acc += partials.double().sum(0)
                     done = torch.cuda.Event()
                     done.record(side)
-                free[k % n_buf] = done
+                free[b] = done
+            else:
+                free[b] = swept
+            if two_phase and n_buf == 1 and k + 1 < len(bounds):
+                phase_a(k + 1)                          # single buffer: strictly alternate
         if need_w and side is not main:
             main.wait_stream(side)
+        if pre is not main:
+            main.wait_stream(pre)
         g_params[failed] = 0.0
         g_y0[failed] = 0.0
         g_w = unpack_partial(acc, L, N).to(torch.float32) if need_w else None
