@@ -226,10 +226,14 @@ struct GradMlp {
   // right behind the MFMAs that read them (PD == NT); with the short ring the steps s + PD < NT of THIS product come first.
   __device__ __forceinline__ void product(unsigned csec, int cl, unsigned nsec, int nl, const f32x4 *__restrict__ B,
                                           f32x4 (&accF)[FP], f32x4 (&accR)[RP]) {
+    // the B operand of step s + 1 is read from LDS before the MFMAs of step s (the sched_barrier at the end of a step would
+    // otherwise pin every read directly in front of its MFMAs: ~100 cycles of LDS latency per step, 13 steps per product)
+    f32x4 b_nxt = B[ktile(0) * 64 + lane];
 #pragma unroll
     for (int s = 0; s < NT; ++s) {
       const int kt = ktile(s);
-      const f32x4 b = B[kt * 64 + lane];
+      const f32x4 b = b_nxt;
+      if (s + 1 < NT) b_nxt = B[ktile(s + 1) * 64 + lane];
       // k-step outer, row tile inner: consecutive MFMAs go to different accumulators (issue every 32 cycles, result after 40)
 #pragma unroll
       for (int r = 0; r < 4; ++r)

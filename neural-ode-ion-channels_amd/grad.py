@@ -259,7 +259,7 @@ class _Solve(torch.autograd.Function):
 def solve(model, weights_flat, params, prot_v, y0, t_eval, *, mlp_layers=0, mlp_width=0, prot_t=None, prot_t0=0.0,
           prot_dt=1.0, prot_of_traj=None, rtol=1e-7, atol=1e-9, v_oob=-80.0, max_steps=0, max_total_steps=0, max_step=0.0,
           ckpt_cap=None, record_budget_bytes=None, weights_key=None, t_eval_hint="auto", order=None, tile_waves=0,
-          ckpt_budget_bytes=None):
+          ckpt_budget_bytes=None, two_phase=None):
     """Differentiable batched solve.  weights_flat [n] fp32 (reference state-dict order; None for the closed-form HH 2-state
     and 6-state models, whose params are [B, 8] / [B, 12] and y0 [B, 2] / [B, 6]), params [B, 8] fp64, y0 [B, 2]
     fp32 | fp64 (the state dtype) -- device tensors, any of which may require grad; prot_v [P, Np], t_eval [Nt] fp64 device
@@ -312,6 +312,8 @@ def solve(model, weights_flat, params, prot_v, y0, t_eval, *, mlp_layers=0, mlp_
                atol=float(atol), v_oob=float(v_oob), max_steps=int(max_steps), max_total_steps=int(max_total_steps),
                max_step=float(max_step), ckpt_cap=ckpt_cap, record_budget_bytes=record_budget_bytes, weights_key=weights_key, t_eval_hint=t_eval_hint,
                tile_waves=int(tile_waves), ckpt_budget_bytes=ckpt_budget_bytes)
+    if two_phase is not None:   # None: the two-phase sweep unless IONODE_GRAD_ONE_PHASE=1; results are the same bits
+        cfg["two_phase"] = bool(two_phase)
     return _Solve.apply(weights_flat, params, y0.contiguous(), cfg)
 
 

@@ -351,3 +351,41 @@ def test_rccl_path_runs_under_the_drivers_launcher_with_one_rank(ion, gpu):
     res = json.loads(lines[0])
     assert res["config"]["dist_backend"] == "nccl" and res["config"]["dist_world_size"] == 1
     assert res["n_gpus"] == 1 and res["config"]["trajectories_ok"] == 64 and res["value"] > 0
+
+
+@pytest.mark.parametrize("model_name", ["s1", "d2"])
+def test_two_phase_sweep_is_the_one_phase_sweep_bit_for_bit(ion, gpu, model_name):
+    """grad.solve(two_phase=...): the forward halves of the vector-Jacobian products run ahead on the whole chip
+    (ionode_dopri5_backward_recompute), the walk keeps the backward products (ionode_dopri5_backward_sweep).  Same code per half:
+    dL/dW, dL/dp, dL/dy0 equal the one-phase sweep's bitwise -- with one chunk, and with a record budget small enough for several
+    chunks (double-buffered records and sign words, phase A one chunk ahead), ragged last tile, fp32 and fp64 state."""
+    grad = importlib.import_module("neural-ode-ion-channels_amd.grad")
+    capi = ion.capi
+    B, Nt = 37, 4001
+    P = ion.protocols
+    pv = P.sinewave(P.sinewave_scales(0, B), n_samples=Nt, xp=torch, device=gpu)
+    model = capi.MODEL_NNF if model_name == "s1" else capi.MODEL_NND
+    p0 = K.MODELS[model_name][4]
+    te = torch.arange(0, Nt, 4, dtype=torch.float64, device=gpu) * 0.1
+    for sdt in (torch.float32, torch.float64):
+        got = {}
+        small = 3 * 6 * 40 * int(capi.lib().ionode_grad_record_floats(5, 200)) * 4     # ~20 iterations per chunk and buffer
+        for tag, kw in (("one", dict(two_phase=False)), ("two", dict(two_phase=True)),
+                        ("one_chunked", dict(two_phase=False, record_budget_bytes=small)),
+                        ("two_chunked", dict(two_phase=True, record_budget_bytes=small))):
+            w = torch.from_numpy(K.load_weights(model_name).copy()).to(gpu).requires_grad_(True)
+            params = torch.from_numpy(np.tile(p0, (B, 1)) * np.random.default_rng(5).uniform(0.9, 1.1, (B, 8))).to(gpu).requires_grad_(True)
+            y0 = torch.tensor([[0.0, 1.0]], dtype=sdt, device=gpu).repeat(B, 1).requires_grad_(True)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", RuntimeWarning)
+                y, status = grad.solve(model, w, params, pv, y0, te, mlp_layers=5, mlp_width=200, prot_t0=0.0, prot_dt=0.1, **kw)
+            assert bool((status == 0).all())
+            (y[..., 0] * y[..., 1]).double().sum().backward()
+            got[tag] = (w.grad.clone(), params.grad.clone(), y0.grad.clone())
+        for ref, tag in (("one", "two"), ("one_chunked", "two_chunked")):
+            for a, b in zip(got[ref], got[tag]):
+                assert torch.equal(a, b), (tag, sdt)
+        # (chunking itself changes the slab partition of the weight-gradient reduction, not dL/dp and dL/dy0)
+        assert torch.equal(got["one"][1], got["one_chunked"][1]) and torch.equal(got["one"][2], got["one_chunked"][2])
+        dw, dwc = got["one"][0].double(), got["one_chunked"][0].double()
+        assert float((dw - dwc).norm() / dw.norm()) < 1e-5

@@ -26,6 +26,7 @@ ap.add_argument("--f64", action="store_true")
 ap.add_argument("--budget-gb", type=float, default=24.0)
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--model", default="s1", choices=["s1", "d2"])
+ap.add_argument("--no-weight-grad", action="store_true", help="dL/dp and dL/dy0 only: no record stream, no reduce (timing experiment)")
 ap.add_argument("--max-step", type=float, default=0.0, help="ms; 0 = off (the reference's dopri5)")
 a = ap.parse_args()
 
@@ -44,7 +45,7 @@ i_ref = torch.zeros((B, Nt), dtype=torch.float64, device=dev)
 vobs = pv + 86.0
 res = []
 for rep in range(a.reps + 1):
-    w = torch.from_numpy(K.load_weights(a.model).copy()).to(dev).requires_grad_(True)
+    w = torch.from_numpy(K.load_weights(a.model).copy()).to(dev).requires_grad_(not a.no_weight_grad)
     params = torch.from_numpy(np.tile(p0, (B, 1))).to(dev).requires_grad_(True)
     y0 = torch.tensor([[0.0, 1.0]], dtype=sdt, device=dev).repeat(B, 1).requires_grad_(True)
     torch.cuda.synchronize()
@@ -59,7 +60,7 @@ for rep in range(a.reps + 1):
     t2 = time.perf_counter()
     if rep:
         res.append((t1 - t0, t2 - t1))
-    gnorm = float(w.grad.double().norm())
+    gnorm = float(w.grad.double().norm()) if w.grad is not None else 0.0
     del y, loss
 fwd, bwd = float(np.mean([r[0] for r in res])), float(np.mean([r[1] for r in res]))
 print(json.dumps({"workload": f"configs[4]: gradient through odeint, NN-f s00, {B} trajectories (1/8 of 8192), "
