@@ -218,21 +218,27 @@ int ionode_dopri5_backward(const ionode_desc *d, int32_t it_begin, int32_t it_en
                            float *records, double *grad_params, double *grad_y0, void *stream);
 
 /*
- * Two-phase form of the same sweep (NN-f / NN-d; same results bit for bit).  The forward half of every vector-Jacobian product
- * depends on the step's checkpoint only, not on the adjoint: ionode_dopri5_backward_recompute() runs it for EVERY (tile, step) of
- * the chunk at once -- the whole chip instead of one workgroup per 16-trajectory tile -- writing the activation halves of the
- * records and, per tile evaluation, ionode_grad_sign_words() 64-bit words of LeakyReLU' bits into `signs`
- * ([ceil(B/16)][it_end - it_begin][6][ionode_grad_sign_words()] uint64); ionode_dopri5_backward_sweep() then walks the steps
- * with the backward products only (it completes the records).  Call order per chunk: recompute, sweep, reduce.
+ * Two-phase form of the same sweep (NN-f / NN-d; same results bit for bit).  Per accepted step the sweep does three kinds of work:
+ * what depends on the step's checkpoint only (stage inputs, protocol voltages, rate exponentials, the reduction of the step's
+ * output gradients, and the FORWARD half of every vector-Jacobian product), the adjoint algebra, and the BACKWARD products.  Only
+ * the last two are sequential.  ionode_dopri5_backward_recompute() runs the first kind for EVERY (tile, step) of the chunk at once
+ * -- the whole chip instead of one workgroup per 16-trajectory tile -- writing the activation halves of the records, per tile
+ * evaluation ionode_grad_sign_words() 64-bit words of LeakyReLU' bits (`signs`: [ceil(B/16)][it_end - it_begin][6][words]), and
+ * per tile and step ionode_grad_packet_doubles() doubles of scalars (`packets`: [ceil(B/16)][it_end - it_begin][doubles]);
+ * ionode_dopri5_backward_sweep() then walks the steps with the adjoint algebra and the backward products (it completes the
+ * records).  Call order per chunk: recompute, sweep, reduce; recompute of chunk k + 1 may run beside the sweep of chunk k.
  */
 size_t ionode_grad_sign_words(void);
+size_t ionode_grad_packet_doubles(void);
 int ionode_dopri5_backward_recompute(const ionode_desc *d, int32_t it_begin, int32_t it_end, int32_t n_iter, const float *grad_image,
                                      const double *params, const double *prot_v, const double *prot_t, const int32_t *prot_of_traj,
-                                     const double *t_eval, const int32_t *n_accepted, float *records, uint64_t *signs, void *stream);
+                                     const double *t_eval, const int32_t *n_accepted, const void *grad_y, float *records,
+                                     uint64_t *signs, double *packets, void *stream);
 int ionode_dopri5_backward_sweep(const ionode_desc *d, int32_t it_begin, int32_t it_end, int32_t n_iter, const float *grad_image,
                                  const double *params, const double *prot_v, const double *prot_t, const int32_t *prot_of_traj,
                                  const double *t_eval, const int32_t *n_accepted, const void *grad_y, double *state,
-                                 float *records, const uint64_t *signs, double *grad_params, double *grad_y0, void *stream);
+                                 float *records, const uint64_t *signs, const double *packets, double *grad_params, double *grad_y0,
+                                 void *stream);
 
 /* floats of one slab's partial gradient: [NP][4]{db0, dW0[.][0], dW0[.][1], 0} | L x (dW_l [NP][NP] + db_l [NP]) | dwl [NP] +
  * {dbl, 0, 0, 0}, NP = 16 * ceil(N / 16), rows/columns >= N are padding */

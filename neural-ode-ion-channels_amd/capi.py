@@ -27,7 +27,7 @@ EXPORTS = (
     "ionode_abi_version", "ionode_last_error", "ionode_mlp_packed_floats", "ionode_mlp_pack",
     "ionode_launch_geometry", "ionode_kernel_name", "ionode_last_kernel_name", "ionode_dopri5", "ionode_protocol_at_outputs",
     "ionode_grad_image_floats", "ionode_grad_pack", "ionode_grad_record_floats", "ionode_dopri5_backward",
-    "ionode_grad_sign_words", "ionode_dopri5_backward_recompute", "ionode_dopri5_backward_sweep",
+    "ionode_grad_sign_words", "ionode_grad_packet_doubles", "ionode_dopri5_backward_recompute", "ionode_dopri5_backward_sweep",
     "ionode_grad_partial_floats", "ionode_grad_reduce", "ionode_grad_last_error",
     "ionode_regress_step", "ionode_adam_step", "ionode_image_refresh",
 )
@@ -95,9 +95,11 @@ def lib():
         L.ionode_grad_sign_words.restype = C.c_size_t
         L.ionode_grad_sign_words.argtypes = []
         L.ionode_dopri5_backward_recompute.restype = C.c_int
-        L.ionode_dopri5_backward_recompute.argtypes = [C.POINTER(IonodeDesc), C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 10
+        L.ionode_grad_packet_doubles.restype = C.c_size_t
+        L.ionode_grad_packet_doubles.argtypes = []
+        L.ionode_dopri5_backward_recompute.argtypes = [C.POINTER(IonodeDesc), C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 12
         L.ionode_dopri5_backward_sweep.restype = C.c_int
-        L.ionode_dopri5_backward_sweep.argtypes = [C.POINTER(IonodeDesc), C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 14
+        L.ionode_dopri5_backward_sweep.argtypes = [C.POINTER(IonodeDesc), C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 15
         L.ionode_grad_reduce.restype = C.c_int
         L.ionode_grad_reduce.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
         L.ionode_regress_step.restype = C.c_int

@@ -42,10 +42,15 @@ struct GArgs {
   double *grad_y0;         // [B][2]
   int32_t ckpt_cap, it_begin, it_end, n_iter;
   int64_t record_floats;
+  double *packets;            // two-phase sweep: the adjoint-independent scalars of every (tile, step): [n_tiles][it_end - it_begin][16][GRAD_PACKET] fp64
+  int32_t phase;              // 0: one-phase sweep; 1: phase A (recompute kernel); 2: phase B (walk kernel)
   unsigned long long *signs;  // two-phase sweep: LeakyReLU' bits of every tile evaluation, [n_tiles][it_end - it_begin][6][GRAD_SIGN_WORDS][256]
                               // written by ionode_grad_recompute_kernel, read by the sweep (NULL: the sweep recomputes the forward itself)
 };
 constexpr int GRAD_SIGN_WORDS = 8;   // 64-bit words per lane and evaluation (Signs below)
+// packet of one trajectory and step (doubles): [0] dts, [1] step, [2] initev, [4 + c*2 + d] G_c (interpolant-coefficient adjoint
+// sums), [16 + 8 e + {0..6}] stage e: V, Y_i[0], Y_i[1], exp(p6 V), exp(-p8 V), exp(p2 V), exp(-p4 V)
+constexpr int GRAD_PACKET = 64;
 
 constexpr int GRAD_STATE = 12;
 
@@ -477,7 +482,7 @@ struct GradMlp {
   }
 };
 
-template <int MODEL, typename S, int NT, int TWO = 0>
+template <int MODEL, typename S, int NT>
 __global__ void __launch_bounds__(256) ionode_dopri5_backward_kernel(const GArgs a) {
   constexpr int D = ModelTraits<MODEL>::D, NPAR = ModelTraits<MODEL>::NPAR;
   constexpr bool M6 = MODEL == IONODE_MODEL_MARKOV6;  // 6-state model (train-d1.py:165-187): f = M(rates(V)) y, closed form
@@ -499,7 +504,7 @@ __global__ void __launch_bounds__(256) ionode_dopri5_backward_kernel(const GArgs
   GradMlp<NT> mlp;
   double *__restrict__ Gs = reinterpret_cast<double *>(smem);  // [16][5 * D] fp64 scratch
   if constexpr (HAS_MLP) {
-    mlp.init(a, smem, wave, lane, TWO != 0);
+    mlp.init(a, smem, wave, lane);
     Gs = mlp.gs();
   }
 
@@ -676,14 +681,7 @@ __global__ void __launch_bounds__(256) ionode_dopri5_backward_kernel(const GArgs
       float dx1 = 0.0f;
       if constexpr (HAS_MLP) {
         float *__restrict__ rec_e = rec_it ? rec_it + (size_t)e * a.record_floats : nullptr;
-        if constexpr (TWO) {
-          // two-phase sweep: the forward recompute of this evaluation ran in ionode_grad_recompute_kernel; its LeakyReLU' bits
-          typename GradMlp<NT>::Signs mk;
-          mlp.signs_load(a.signs + (((size_t)blockIdx.x * (a.it_end - a.it_begin) + (it - a.it_begin)) * 6 + e) * (GRAD_SIGN_WORDS * 256), mk);
-          dx1 = mlp.vjp_backward(seedf, rec_e, mk);
-        } else {
-          dx1 = mlp.vjp(x0, x1, seedf, rec_e);
-        }
+        dx1 = mlp.vjp(x0, x1, seedf, rec_e);
       }
       // closed-form terms of the RHS and their parameter gradients
       const double e3 = det_exp(p[5] * v), e4 = det_exp(-p[7] * v);
@@ -746,19 +744,24 @@ __global__ void __launch_bounds__(256) ionode_dopri5_backward_kernel(const GArgs
 }
 
 // ---------------------------------------------------------------------------------------------
-// Two-phase sweep, phase A.  The stage inputs of an accepted step come from its checkpoint alone (Y_i = y + dt sum_j beta_ij k_j),
-// not from the adjoint: the forward half of every vector-Jacobian product -- half the MFMA work of the sweep -- is independent
-// across steps AND tiles.  The one-phase sweep runs it inside the sequential walk, one workgroup per tile: 64 of 256 compute
-// units at BASELINE configs[4]'s per-GPU batch.  This kernel runs it for every (tile, step) at once: grid = (tiles, blocks of
-// IB iterations), activations into the record stream (for ionode_grad_reduce), LeakyReLU' bits into `signs` for the sweep, which
-// then only walks the backward products.  Same code as the one-phase product (GradMlp::vjp_from_output), same bits.
+// Two-phase sweep (NN-f / NN-d).  The one-phase sweep above does, per accepted step of a tile, three kinds of work in one
+// sequential walk on one compute unit: (1) what depends on the checkpoint only -- the stage inputs Y_i, the protocol voltages,
+// the rate exponentials, the reduction of the step's output gradients into the interpolant-coefficient adjoints G_c, and the
+// FORWARD half of every vector-Jacobian product; (2) the adjoint algebra; (3) the BACKWARD products.  Only (2) and (3) are
+// sequential.  Phase A (ionode_grad_recompute_kernel) runs (1) for every (tile, step) of a chunk at once -- grid = (tiles, blocks of
+// IB iterations), the whole chip instead of 64 of 256 compute units at BASELINE configs[4]'s per-GPU batch -- and leaves, per tile
+// evaluation, the activation halves of the records (for ionode_grad_reduce) and the LeakyReLU' bits (`signs`), and per trajectory
+// and step a 64-double packet (GRAD_PACKET).  Phase B (ionode_grad_walk_kernel) walks the steps with (2) and (3): one 8 KiB packet
+// burst per step instead of checkpoint loads, protocol lookups, exps and a 480-shuffle reduction.  Every value is computed by the
+// same expressions as in the one-phase kernel, so the gradients are bit-identical.
 // ---------------------------------------------------------------------------------------------
 constexpr int GRAD_RECOMPUTE_IB = 4;   // iterations per workgroup
 
 template <int MODEL, typename S, int NT>
 __global__ void __launch_bounds__(256) ionode_grad_recompute_kernel(const GArgs a) {
-  constexpr int D = ModelTraits<MODEL>::D;
+  constexpr int D = ModelTraits<MODEL>::D, NPAR = ModelTraits<MODEL>::NPAR;
   static_assert(ModelTraits<MODEL>::MLP && D == 2, "NN-f / NN-d");
+  constexpr bool NND = MODEL == IONODE_MODEL_NND;
   using R = Real<S>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
@@ -769,23 +772,31 @@ __global__ void __launch_bounds__(256) ionode_grad_recompute_kernel(const GArgs 
   const int traj = valid ? traj_raw : a.k.B - 1;
   GradMlp<NT> mlp;
   mlp.init(a, smem, wave, lane);
+  double *__restrict__ Gs = mlp.gs();
+  double p[NPAR];
+#pragma unroll
+  for (int i = 0; i < NPAR; ++i) p[i] = a.k.params[(size_t)traj * a.k.n_params + i];
   const int pidx = a.k.prot_of_traj ? a.k.prot_of_traj[traj] : (traj % a.k.P);
   const double *__restrict__ pv = a.k.prot_v + (size_t)pidx * a.k.Np;
   const int nst = valid ? a.nacc[traj] : 0;
   const int RECW = 4 + 8 * D;
   const double *__restrict__ ck = a.ckpt + (size_t)traj * a.ckpt_cap * RECW;
+  const int Nt = a.k.Nt;
+  const bool pk_writer = wave == 0 && lane < 16;
   const int it_lo = a.it_begin + (int)blockIdx.y * GRAD_RECOMPUTE_IB;
   const int it_hi = (it_lo + GRAD_RECOMPUTE_IB < a.it_end) ? it_lo + GRAD_RECOMPUTE_IB : a.it_end;
   for (int it = it_lo; it < it_hi; ++it) {
-    // (the same reconstruction as the sweep's: ionode_dopri5_backward_kernel)
+    // ---- checkpoint of my step: as in ionode_dopri5_backward_kernel ----
     const int s = nst - 1 - it;
     const bool step = s >= 0;
     const bool initev = (s == -1) && nst > 0;
     double t0 = 0.0, dt = 1.0, y[D], k[7][D];
+    int oi = 0, nout = 0;
     {
       const double *rec = ck + (size_t)(step ? s : 0) * RECW;
       const bool ld = step || initev;
       if (ld) { t0 = rec[0]; dt = rec[1]; }
+      if (step) { oi = (int)rec[2]; nout = (int)rec[3]; }
 #pragma unroll
       for (int d = 0; d < D; ++d) y[d] = ld ? rec[4 + d] : 0.0;
 #pragma unroll
@@ -796,28 +807,221 @@ __global__ void __launch_bounds__(256) ionode_grad_recompute_kernel(const GArgs 
     const double t1 = t0 + dt;
     const S t0s = (S)t0, dts_s = (S)dt, t1s = (S)t1;
     const double dts = (double)dts_s;
-    const size_t ev0 = ((size_t)blockIdx.x * (a.it_end - a.it_begin) + (it - a.it_begin)) * 6;
+    const size_t tstep = (size_t)blockIdx.x * (a.it_end - a.it_begin) + (it - a.it_begin);
+    double *__restrict__ pk = a.packets + (tstep * 16 + j) * GRAD_PACKET;
+
+    // ---- adjoints of the interpolant coefficients: G_c = sum_k gy[k] * x_k^c over the step's output samples (verbatim) ----
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int jj = wave + 4 * u;
+      const int n = __builtin_amdgcn_readlane(nout, jj);
+      double P[5][D];
+#pragma unroll
+      for (int c = 0; c < 5; ++c)
+#pragma unroll
+        for (int d = 0; d < D; ++d) P[c][d] = 0.0;
+      if (n > 0) {
+        const int o = __builtin_amdgcn_readlane(oi, jj);
+        const int tr = __builtin_amdgcn_readlane(traj, jj);
+        const double t0b = bcast_f64(t0, jj), t1b = bcast_f64(t1, jj);
+        const S *__restrict__ gyb = reinterpret_cast<const S *>(a.grad_y) + (size_t)tr * Nt * D;
+        for (int c0 = 0; c0 < n; c0 += 64) {
+          if (c0 + lane < n) {
+            const int idx = o + c0 + lane;
+            const double tk = a.k.t_eval[idx];
+            const double x = (double)(S)((tk - t0b) / (t1b - t0b));
+            double xp = 1.0;
+#pragma unroll
+            for (int c = 0; c < 5; ++c) {
+#pragma unroll
+              for (int d = 0; d < D; ++d) P[c][d] += (double)gyb[(size_t)idx * D + d] * xp;
+              xp *= x;
+            }
+          }
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+          for (int c = 0; c < 5; ++c)
+#pragma unroll
+            for (int d = 0; d < D; ++d) P[c][d] += __shfl_xor(P[c][d], m);
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < 5; ++c)
+#pragma unroll
+          for (int d = 0; d < D; ++d) Gs[jj * (5 * D) + c * D + d] = P[c][d];
+      }
+    }
+    __syncthreads();
+    if (pk_writer) {
+      pk[0] = dts; pk[1] = step ? 1.0 : 0.0; pk[2] = initev ? 1.0 : 0.0; pk[3] = 0.0;
+#pragma unroll
+      for (int c = 0; c < 5; ++c)
+#pragma unroll
+        for (int d = 0; d < D; ++d) pk[4 + c * D + d] = Gs[j * (5 * D) + c * D + d];
+    }
 #pragma unroll 1
     for (int e = 0; e < 6; ++e) {
       const int i = 5 - e;
-      double Y0;
+      double Yi[D];
       double tq;
       if (step) {
-        double sacc = 0.0;
-        for (int jx = 0; jx <= i; ++jx) sacc += k[jx][0] * (kBeta[i][jx] * dts);
-        Y0 = y[0] + sacc;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          double sacc = 0.0;
+          for (int jx = 0; jx <= i; ++jx) sacc += k[jx][d] * (kBeta[i][jx] * dts);
+          Yi[d] = y[d] + sacc;
+        }
         const S ti = (i >= 4) ? R::prev_(t1s) : t0s + (S)kAlpha[i] * dts_s;
         tq = (double)ti;
       } else {
-        Y0 = y[0];
+#pragma unroll
+        for (int d = 0; d < D; ++d) Yi[d] = y[d];
         tq = (double)(S)a.k.t_eval[0];
       }
       double v;
       protocol_v(a.k, pv, tq, v);
-      const float x0 = (float)(v / 100.0), x1 = (float)Y0;
+      const float x0 = (float)(v / 100.0), x1 = (float)Yi[0];
+      const double e3 = det_exp(p[5] * v), e4 = det_exp(-p[7] * v);
+      double e1 = 0.0, e2 = 0.0;
+      if constexpr (NND) { e1 = det_exp(p[1] * v); e2 = det_exp(-p[3] * v); }
+      if (pk_writer) {
+        double *q8 = pk + 16 + 8 * e;
+        q8[0] = v; q8[1] = Yi[0]; q8[2] = Yi[1]; q8[3] = e3; q8[4] = e4; q8[5] = e1; q8[6] = e2; q8[7] = 0.0;
+      }
       typename GradMlp<NT>::Signs mk;
-      mlp.vjp_forward(x0, x1, a.records ? a.records + (ev0 + e) * a.record_floats : nullptr, mk);
-      mlp.signs_store(a.signs + (ev0 + e) * (GRAD_SIGN_WORDS * 256), mk);
+      mlp.vjp_forward(x0, x1, a.records ? a.records + (tstep * 6 + e) * a.record_floats : nullptr, mk);
+      mlp.signs_store(a.signs + (tstep * 6 + e) * (GRAD_SIGN_WORDS * 256), mk);
+    }
+  }
+}
+
+// Phase B: the sequential walk -- adjoint algebra + backward products.  LDS: the GradMlp region, then [16][GRAD_PACKET] doubles.
+template <int MODEL, typename S, int NT>
+__global__ void __launch_bounds__(256) ionode_grad_walk_kernel(const GArgs a) {
+  constexpr int D = ModelTraits<MODEL>::D, NPAR = ModelTraits<MODEL>::NPAR;
+  static_assert(ModelTraits<MODEL>::MLP && D == 2, "NN-f / NN-d");
+  constexpr bool NND = MODEL == IONODE_MODEL_NND;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15;
+  const int traj_raw = blockIdx.x * 16 + j;
+  const bool valid = traj_raw < a.k.B;
+  const int traj = valid ? traj_raw : a.k.B - 1;
+  const bool writer = valid && wave == 0 && lane < 16;
+  GradMlp<NT> mlp;
+  mlp.init(a, smem, wave, lane, true);
+  double *__restrict__ pkl = reinterpret_cast<double *>(smem + ((grad_lds_bytes(a.k.L, NT) + 15) & ~(size_t)15));
+
+  double p[NPAR];
+#pragma unroll
+  for (int i = 0; i < NPAR; ++i) p[i] = a.k.params[(size_t)traj * a.k.n_params + i];
+  const S *__restrict__ gy = reinterpret_cast<const S *>(a.grad_y) + (size_t)traj * a.k.Nt * D;
+  constexpr int STATE = 2 * D + NPAR;
+  double lam[D], mu[D], gp[NPAR];
+  {
+    const double *st = a.state + (size_t)traj * STATE;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { lam[d] = a.it_begin > 0 ? st[d] : 0.0; mu[d] = a.it_begin > 0 ? st[D + d] : 0.0; }
+#pragma unroll
+    for (int i = 0; i < NPAR; ++i) gp[i] = a.it_begin > 0 ? st[2 * D + i] : 0.0;
+  }
+  const int tid = wave * 64 + lane;
+  for (int it = a.it_begin; it < a.it_end; ++it) {
+    const size_t tstep = (size_t)blockIdx.x * (a.it_end - a.it_begin) + (it - a.it_begin);
+    // ---- the tile's packets of this step: one 8 KiB burst into LDS (the previous step's last reader is behind a barrier of its
+    // last product) ----
+    {
+      const double2 *src = reinterpret_cast<const double2 *>(a.packets + tstep * 16 * GRAD_PACKET) + 2 * tid;
+      const double2 v0 = src[0], v1 = src[1];
+      double2 *dst = reinterpret_cast<double2 *>(pkl) + 2 * tid;
+      dst[0] = v0; dst[1] = v1;
+    }
+    __syncthreads();
+    const double *__restrict__ pk = pkl + j * GRAD_PACKET;
+    const double dts = pk[0];
+    const bool step = pk[1] != 0.0, initev = pk[2] != 0.0;
+    double Gc[5][D];
+#pragma unroll
+    for (int c = 0; c < 5; ++c)
+#pragma unroll
+      for (int d = 0; d < D; ++d) Gc[c][d] = pk[4 + c * D + d];
+
+    // ---- interpolant adjoint -> (Y0, Y1, k1..k7); FSAL carry (as in the one-phase kernel) ----
+    double aY0[D], aY1[D], ak[7][D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const double g0 = Gc[0][d], g1 = Gc[1][d], g2 = Gc[2][d], g3 = Gc[3][d], g4 = Gc[4][d];
+      const double aYM = 16.0 * g4 - 32.0 * g3 + 16.0 * g2;
+      aY0[d] = g0 - 8.0 * g4 + 18.0 * g3 - 11.0 * g2 + aYM;
+      aY1[d] = -8.0 * g4 + 14.0 * g3 - 5.0 * g2 + lam[d];
+#pragma unroll
+      for (int jx = 0; jx < 7; ++jx) ak[jx][d] = (kCmid[jx] * dts) * aYM;
+      ak[0][d] += dts * (-2.0 * g4 + 5.0 * g3 - 4.0 * g2 + g1);
+      ak[6][d] += dts * (2.0 * g4 - 3.0 * g3 + g2) + mu[d];
+    }
+    float *__restrict__ rec_it = a.records ? a.records + tstep * 6 * a.record_floats : nullptr;
+#pragma unroll 1
+    for (int e = 0; e < 6; ++e) {
+      const int i = 5 - e;
+      const double *__restrict__ q8 = pk + 16 + 8 * e;
+      const double v = q8[0], av = q8[1], rv = q8[2], e3 = q8[3], e4 = q8[4];
+      double seed[D];
+#pragma unroll
+      for (int d = 0; d < D; ++d) seed[d] = step ? ak[i + 1][d] : ((initev && e == 0) ? mu[d] : 0.0);
+      const float seedf = (float)(seed[0] / 1000.0);
+      typename GradMlp<NT>::Signs mk;
+      // (tried: all six evaluations' words in the step's burst, through LDS -- no change, 0.500 vs 0.513 s)
+      mlp.signs_load(a.signs + (tstep * 6 + e) * (GRAD_SIGN_WORDS * 256), mk);
+      const float dx1 = mlp.vjp_backward(seedf, rec_it ? rec_it + (size_t)e * a.record_floats : nullptr, mk);
+      // closed-form terms of the RHS and their parameter gradients (the one-phase kernel's expressions)
+      double w[D];
+      const double k3 = p[4] * e3, k4 = p[6] * e4;
+      w[0] = (double)dx1;
+      w[1] = -seed[1] * (k3 + k4);
+      gp[4] += seed[1] * (-e3 * rv);
+      gp[5] += seed[1] * (-k3 * v * rv);
+      gp[6] += seed[1] * (e4 * (1.0 - rv));
+      gp[7] += seed[1] * (-k4 * v * (1.0 - rv));
+      if constexpr (NND) {
+        const double e1 = q8[5], e2 = q8[6];
+        const double k1 = p[0] * e1, k2 = p[2] * e2;
+        w[0] += -seed[0] * (k1 + k2);
+        gp[0] += seed[0] * (e1 * (1.0 - av));
+        gp[1] += seed[0] * (k1 * v * (1.0 - av));
+        gp[2] += seed[0] * (-e2 * av);
+        gp[3] += seed[0] * (k2 * v * av);
+      }
+      if (step) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          const double wd = (i == 5) ? w[d] + aY1[d] : w[d];
+          aY0[d] += wd;
+          for (int jx = 0; jx <= i; ++jx) ak[jx][d] += (kBeta[i][jx] * dts) * wd;
+        }
+      } else if (initev && e == 0) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) lam[d] += w[d];
+      }
+    }
+    if (step) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) { lam[d] = aY0[d]; mu[d] = ak[0][d]; }
+    }
+  }
+  if (writer) {
+    double *st = a.state + (size_t)traj * STATE;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { st[d] = lam[d]; st[D + d] = mu[d]; }
+#pragma unroll
+    for (int i = 0; i < NPAR; ++i) st[2 * D + i] = gp[i];
+    if (a.it_end >= a.n_iter) {
+#pragma unroll
+      for (int i = 0; i < NPAR; ++i) a.grad_params[(size_t)traj * NPAR + i] = gp[i];
+#pragma unroll
+      for (int d = 0; d < D; ++d) a.grad_y0[(size_t)traj * D + d] = lam[d] + (double)gy[d];  // solution[0] = y0
     }
   }
 }

@@ -86,14 +86,14 @@ int ionode_grad_pack(const float *w, int32_t L, int32_t N, float *out) {
 static int backward_impl(int mode, const ionode_desc *d, int32_t it_begin, int32_t it_end, int32_t n_iter, const float *grad_image,
                          const double *params, const double *prot_v, const double *prot_t, const int32_t *prot_of_traj,
                          const double *t_eval, const int32_t *n_accepted, const void *grad_y, double *state,
-                         float *records, uint64_t *signs, double *grad_params, double *grad_y0, void *stream) {
+                         float *records, uint64_t *signs, double *packets, double *grad_params, double *grad_y0, void *stream) {
   if (!d) { gerr("null descriptor"); return IONODE_ERR_ARG; }
-  if (mode != 0 && (!signs || (d->model != IONODE_MODEL_NNF && d->model != IONODE_MODEL_NND))) {
-    gerr("two-phase sweep: NN-f / NN-d only, `signs` required"); return IONODE_ERR_ARG;
+  if (mode != 0 && (!signs || !packets || (d->model != IONODE_MODEL_NNF && d->model != IONODE_MODEL_NND))) {
+    gerr("two-phase sweep: NN-f / NN-d only, `signs` and `packets` required"); return IONODE_ERR_ARG;
   }
-  if (mode == 1) {   // phase A reads no adjoint: stand-ins so that the shared checks pass (never dereferenced)
+  if (mode == 1) {   // phase A carries no adjoint state: stand-ins so that the shared checks pass (never dereferenced)
     static double dummy;
-    grad_y = nullptr; state = &dummy; grad_params = &dummy; grad_y0 = &dummy;
+    state = &dummy; grad_params = &dummy; grad_y0 = &dummy;
   }
   const bool m6 = d->model == IONODE_MODEL_MARKOV6;
   const bool hh2 = d->model == IONODE_MODEL_HH2 || m6;  // closed-form models: no MLP image, no records
@@ -101,7 +101,7 @@ static int backward_impl(int mode, const ionode_desc *d, int32_t it_begin, int32
   if (d->n_state != (m6 ? 6 : 2) || d->n_traj < 1 || d->n_out < 1 || d->n_prot < 1 || d->prot_n < 2 || d->n_params < (m6 ? 12 : 8) || !(d->prot_dt > 0)) {
     gerr("inconsistent descriptor"); return IONODE_ERR_ARG;
   }
-  if ((!grad_image && !hh2) || !params || !prot_v || !t_eval || !n_accepted || (!grad_y && mode != 1) || !state || !grad_params || !grad_y0 || !d->ckpt || d->ckpt_cap < 1) {
+  if ((!grad_image && !hh2) || !params || !prot_v || !t_eval || !n_accepted || !grad_y || !state || !grad_params || !grad_y0 || !d->ckpt || d->ckpt_cap < 1) {
     gerr("ionode_dopri5_backward: required buffer is NULL (ckpt / ckpt_cap come from the descriptor)"); return IONODE_ERR_ARG;
   }
   if (it_begin < 0 || it_end <= it_begin || it_end > n_iter) { gerr("bad iteration range"); return IONODE_ERR_ARG; }
@@ -127,6 +127,9 @@ static int backward_impl(int mode, const ionode_desc *d, int32_t it_begin, int32
   a.it_begin = it_begin; a.it_end = it_end; a.n_iter = n_iter;
   a.record_floats = ionode::grad_record_floats(L, NT);
   a.signs = reinterpret_cast<unsigned long long *>(mode != 0 ? signs : nullptr);
+  a.packets = mode != 0 ? packets : nullptr;
+  a.phase = mode;
+  if (mode != 0 && ionode::grad_lds_bytes(L, NT) + 16 + 16 * ionode::GRAD_PACKET * 8 > 160 * 1024) { gerr("two-phase sweep: LDS"); return IONODE_ERR_UNSUPPORTED; }
   fn(a, (unsigned)((d->n_traj + 15) / 16), lds, reinterpret_cast<hipStream_t>(stream));
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { gerr(hipGetErrorString(e)); return IONODE_ERR_LAUNCH; }
@@ -138,24 +141,27 @@ int ionode_dopri5_backward(const ionode_desc *d, int32_t it_begin, int32_t it_en
                            const double *t_eval, const int32_t *n_accepted, const void *grad_y, double *state,
                            float *records, double *grad_params, double *grad_y0, void *stream) {
   return backward_impl(0, d, it_begin, it_end, n_iter, grad_image, params, prot_v, prot_t, prot_of_traj, t_eval, n_accepted, grad_y,
-                       state, records, nullptr, grad_params, grad_y0, stream);
+                       state, records, nullptr, nullptr, grad_params, grad_y0, stream);
 }
 
 size_t ionode_grad_sign_words(void) { return (size_t)ionode::GRAD_SIGN_WORDS * 256; }
+size_t ionode_grad_packet_doubles(void) { return (size_t)16 * ionode::GRAD_PACKET; }
 
 int ionode_dopri5_backward_recompute(const ionode_desc *d, int32_t it_begin, int32_t it_end, int32_t n_iter, const float *grad_image,
                                      const double *params, const double *prot_v, const double *prot_t, const int32_t *prot_of_traj,
-                                     const double *t_eval, const int32_t *n_accepted, float *records, uint64_t *signs, void *stream) {
-  return backward_impl(1, d, it_begin, it_end, n_iter, grad_image, params, prot_v, prot_t, prot_of_traj, t_eval, n_accepted, nullptr,
-                       nullptr, records, signs, nullptr, nullptr, stream);
+                                     const double *t_eval, const int32_t *n_accepted, const void *grad_y, float *records,
+                                     uint64_t *signs, double *packets, void *stream) {
+  return backward_impl(1, d, it_begin, it_end, n_iter, grad_image, params, prot_v, prot_t, prot_of_traj, t_eval, n_accepted, grad_y,
+                       nullptr, records, signs, packets, nullptr, nullptr, stream);
 }
 
 int ionode_dopri5_backward_sweep(const ionode_desc *d, int32_t it_begin, int32_t it_end, int32_t n_iter, const float *grad_image,
                                  const double *params, const double *prot_v, const double *prot_t, const int32_t *prot_of_traj,
                                  const double *t_eval, const int32_t *n_accepted, const void *grad_y, double *state,
-                                 float *records, const uint64_t *signs, double *grad_params, double *grad_y0, void *stream) {
+                                 float *records, const uint64_t *signs, const double *packets, double *grad_params, double *grad_y0,
+                                 void *stream) {
   return backward_impl(2, d, it_begin, it_end, n_iter, grad_image, params, prot_v, prot_t, prot_of_traj, t_eval, n_accepted, grad_y,
-                       state, records, const_cast<uint64_t *>(signs), grad_params, grad_y0, stream);
+                       state, records, const_cast<uint64_t *>(signs), const_cast<double *>(packets), grad_params, grad_y0, stream);
 }
 
 int ionode_grad_reduce(int32_t L, int32_t N, const float *records, int64_t n_records, int32_t n_slabs, float *partials,

@@ -8,12 +8,12 @@ namespace ionode {
 
 using SweepFn = void (*)(const GArgs &, unsigned grid, size_t lds, hipStream_t);
 
-// a.signs == NULL: the one-phase sweep (forward recompute inside the walk).  a.signs given and a.grad_y == NULL: phase A of the
-// two-phase sweep (ionode_grad_recompute_kernel, every (tile, step) at once); a.signs and a.grad_y: phase B (backward products only).
+// a.phase 0: the one-phase sweep.  1: phase A of the two-phase sweep (ionode_grad_recompute_kernel, every (tile, step) at once);
+// 2: phase B (ionode_grad_walk_kernel: adjoint algebra + backward products; + 8 KiB of LDS for the step's packets).
 template <int MODEL, typename S, int NT>
 void launch_sweep(const GArgs &a, unsigned grid, size_t lds, hipStream_t s) {
   if constexpr (ModelTraits<MODEL>::MLP) {
-    if (a.signs != nullptr && a.grad_y == nullptr) {
+    if (a.phase == 1) {
       auto kern = ionode_grad_recompute_kernel<MODEL, S, NT>;
       if (lds > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -21,15 +21,16 @@ void launch_sweep(const GArgs &a, unsigned grid, size_t lds, hipStream_t s) {
       hipLaunchKernelGGL(kern, dim3(grid, nb), dim3(256), lds, s, a);
       return;
     }
-    if (a.signs != nullptr) {
-      auto kern = ionode_dopri5_backward_kernel<MODEL, S, NT, 1>;
-      if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
+    if (a.phase == 2) {
+      auto kern = ionode_grad_walk_kernel<MODEL, S, NT>;
+      const size_t lds2 = ((lds + 15) & ~(size_t)15) + (size_t)16 * GRAD_PACKET * 8;
+      if (lds2 > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds2, s, a);
       return;
     }
   }
-  auto kern = ionode_dopri5_backward_kernel<MODEL, S, NT, 0>;
+  auto kern = ionode_dopri5_backward_kernel<MODEL, S, NT>;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
