@@ -179,7 +179,10 @@ class _Solve(torch.autograd.Function):
         if need_w and n_buf == 2:
             chunk = max(1, min(n_iter, (budget // 2) // (tiles * 6 * recf * 4)))
         elif two_phase and not need_w:
-            chunk = max(1, min(n_iter, 256))      # nothing to budget but the sign words: bounded chunks keep phase A ahead of the walk
+            # no record stream: the sign words and packets are what a chunk holds (two buffers of each); bounded chunks also keep
+            # phase A one chunk ahead of the walk
+            per_it = tiles * (6 * int(lib.ionode_grad_sign_words()) + int(lib.ionode_grad_packet_doubles())) * 8
+            chunk = max(1, min(n_iter, 256, (budget // 2) // per_it))
             n_chunks = (n_iter + chunk - 1) // chunk
             n_buf = 2 if n_chunks > 1 else 1
         records = [torch.empty(tiles * chunk * 6 * recf, dtype=torch.float32, device=dev) for _ in range(n_buf)] if need_w else [None] * n_buf
