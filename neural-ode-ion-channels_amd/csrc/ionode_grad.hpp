@@ -58,7 +58,8 @@ constexpr int GRAD_STATE = 12;
 __host__ __device__ constexpr int64_t grad_record_floats(int L, int NT) { return (int64_t)2 * (L + 1) * NT * 256 + 64; }
 __host__ __device__ constexpr size_t grad_lds_bytes(int L, int NT) {
   // two activation buffers + two gradient buffers (ping-pong over the layers, whatever L is) + remainder partial sums + small vectors
-  return ((size_t)4 * NT * 64 + (size_t)2 * (NT % 4) * 4 * 64 + 16 * NT) * 16 + ((size_t)L * 16 * NT + 16 * NT + 4) * 4 + 16 * 10 * 8;
+  // (+ the input layer's second weight column as a contiguous vector: the closing dot product d net / d x1)
+  return ((size_t)4 * NT * 64 + (size_t)2 * (NT % 4) * 4 * 64 + 16 * NT) * 16 + ((size_t)L * 16 * NT + 16 * NT + 4) * 4 + 16 * 10 * 8 + (NT <= 13 ? (size_t)16 * NT * 4 : 0);   // (N = 500 with 10 layers fills the 160 KiB without it)
 }
 // image offsets (floats): rows of layer 0 {b0, w00, w01, 0} | hidden biases | wl, bl | forward fragments | transposed fragments
 __host__ __device__ constexpr size_t grad_img_bias(int NT) { return (size_t)4 * 16 * NT; }
@@ -67,6 +68,9 @@ __host__ __device__ constexpr size_t grad_img_fwd(int L, int NT) { return grad_i
 __host__ __device__ constexpr size_t grad_img_bwd(int L, int NT) { return grad_img_fwd(L, NT) + (size_t)L * NT * NT * 256; }
 __host__ __device__ constexpr size_t grad_img_floats(int L, int NT) { return grad_img_bwd(L, NT) + (size_t)L * NT * NT * 256; }
 
+#ifndef IONODE_GRAD_OWN0
+#define IONODE_GRAD_OWN0 1
+#endif
 template <int NT>
 struct GradMlp {
   static constexpr int G = 4;
@@ -98,14 +102,23 @@ struct GradMlp {
   const f32x4 *W0s;   // LDS [NP] {b0, w00, w01, 0}
   const float *biasS; // LDS [L][NP]
   const float *wlS;   // LDS [NP] + bl
+  const float *w01S;  // LDS [NP]: W0[k][1]
   __amdgpu_buffer_rsrc_t rsrc;
   unsigned fwd0, bwd0;  // byte offsets of the fragment sections
   int L, wave, lane;
+  int roff;           // this lane's float offset inside a record tile (rec_store)
+#ifdef IONODE_STAMPS   // diagnostic build: phase stamps of workgroup 0 / wavefront 0 of the walk kernel (ionode_grad_capi.hip prints them)
+  Stamps *gsp;
+#define GSTAMP(slot) STAMP(*gsp, slot)
+#else
+#define GSTAMP(slot) do { } while (0)
+#endif
 
   // first_sec: the fragment section of the FIRST product this workgroup will run (fwd0 layer 0: one-phase sweep, regression,
   // recompute kernel; bwd0 layer L-1: the sweep of the two-phase scheme)
   __device__ __forceinline__ void init(const GArgs &a, unsigned char *smem, int wave_, int lane_, bool bwd_only = false) {
     L = a.k.L; wave = wave_; lane = lane_;
+    roff = 64 * (lane & 3) + 16 * (lane >> 4) + ((lane & 15) >> 2);
     Hs = reinterpret_cast<f32x4 *>(smem);
     Ds = Hs + (size_t)2 * NT * 64;
     Ps = Ds + 2 * NT * 64;
@@ -118,6 +131,12 @@ struct GradMlp {
     for (int i = tid; i < L * NP; i += 64 * G) bs[i] = a.img[grad_img_bias(NT) + i];
     for (int i = tid; i < NP + 4; i += 64 * G) ws[i] = a.img[grad_img_wl(L, NT) + i];
     W0s = w0; biasS = bs; wlS = ws;
+    // w01[k] = W0[k][1] contiguous (13 x 16-byte reads in the closing dot product instead of 52 rows of {b0, w00, w01, 0})
+    if constexpr (NT <= 13) {
+      float *w01 = reinterpret_cast<float *>(reinterpret_cast<double *>(ws + NP + 4) + 16 * 10);
+      for (int i = tid; i < NP; i += 64 * G) w01[i] = a.img[4 * i + 2];
+      w01S = w01;
+    }
     rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.img), 0, (int)(grad_img_floats(L, NT) * 4), 0x00020000);
     fwd0 = (unsigned)(grad_img_fwd(L, NT) * 4);
     bwd0 = (unsigned)(grad_img_bwd(L, NT) * 4);
@@ -219,8 +238,7 @@ struct GradMlp {
   // Record tiles are stored in the A/B-operand layout of ionode_grad_reduce's MFMAs (contraction over the 16 trajectories):
   // G[16*kk + m][c] = X[row 16*rt + m][trajectory 4*c + kk].  This lane holds rows 4q + r of trajectory n = lane & 15.
   __device__ __forceinline__ void rec_store(f32x4 *tile, const f32x4 &v) const {
-    const int q = lane >> 4, n = lane & 15;
-    float *p = reinterpret_cast<float *>(tile) + 64 * (n & 3) + 16 * q + (n >> 2);
+    float *p = reinterpret_cast<float *>(tile) + roff;   // 64 * (n & 3) + 16 * q + (n >> 2), q = lane >> 4, n = lane & 15
     // written once, read once by ionode_grad_reduce: non-temporal, so the stream does not evict the weight image from L2
     __builtin_nontemporal_store(v[0], p); __builtin_nontemporal_store(v[1], p + 4);
     __builtin_nontemporal_store(v[2], p + 8); __builtin_nontemporal_store(v[3], p + 12);
@@ -229,16 +247,25 @@ struct GradMlp {
   // accF[i] += A(csec, cl)[row tile wave + 4i][:] . B[:] over all k-tiles; accR[j] += the owned K-slice of remainder tile j.
   // B is read from LDS in accumulator layout.  (nsec, nl): the product that follows -- its fragments replace this one's
   // right behind the MFMAs that read them (PD == NT); with the short ring the steps s + PD < NT of THIS product come first.
-  __device__ __forceinline__ void product(unsigned csec, int cl, unsigned nsec, int nl, const f32x4 *__restrict__ B,
-                                          f32x4 (&accF)[FP], f32x4 (&accR)[RP]) {
+  // The workgroup barrier between two products is NOT in front of this one: step 0's B operand is the wavefront's own first
+  // tile (k-tile `wave` of the rotated walk), handed over in registers (`own`), and `after0` -- the barrier, then whatever had
+  // to wait for it (the fold of the previous product's remainder tile) -- runs BEHIND step 0's MFMAs, so the LDS round trip
+  // and the wait for the slowest wavefront overlap with them (the forward kernel's arrangement, ionode_device.hpp).  Widths
+  // without a full tile per wavefront (N <= 48) run `after0` first and read every operand from LDS.
+  static constexpr bool OWN0 = (F >= 1) && IONODE_GRAD_OWN0;
+  template <typename After0>
+  __device__ __forceinline__ void product(unsigned csec, int cl, unsigned nsec, int nl, const f32x4 *__restrict__ B, const f32x4 &own,
+                                          After0 after0, f32x4 (&accF)[FP], f32x4 (&accR)[RP]) {
     // the B operand of step s + 1 is read from LDS before the MFMAs of step s (the sched_barrier at the end of a step would
     // otherwise pin every read directly in front of its MFMAs: ~100 cycles of LDS latency per step, 13 steps per product)
-    f32x4 b_nxt = B[ktile(0) * 64 + lane];
+    f32x4 b_nxt;
+    if constexpr (OWN0) b_nxt = own;
+    else { after0(); b_nxt = B[ktile(0) * 64 + lane]; }
 #pragma unroll
     for (int s = 0; s < NT; ++s) {
       const int kt = ktile(s);
       const f32x4 b = b_nxt;
-      if (s + 1 < NT) b_nxt = B[ktile(s + 1) * 64 + lane];
+      if (s + 1 < NT && !(OWN0 && s == 0)) b_nxt = B[ktile(s + 1) * 64 + lane];
       // k-step outer, row tile inner: consecutive MFMAs go to different accumulators (issue every 32 cycles, result after 40)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
@@ -258,6 +285,12 @@ struct GradMlp {
       for (int i = 0; i < F; ++i) {
         if constexpr (PD == NT) ringF[s][i] = frag(nsec, nl, wave + G * i, kt);
         else ringF[s % PD][i] = (s + PD < NT) ? frag(csec, cl, wave + G * i, ktile(s + PD)) : frag(nsec, nl, wave + G * i, ktile(s + PD - NT));
+      }
+      if constexpr (OWN0) {
+        if (s == 0) {
+          after0();
+          if (NT > 1) b_nxt = B[ktile(1) * 64 + lane];
+        }
       }
       __builtin_amdgcn_sched_barrier(0);  // keep the refills here (hipcc otherwise sinks them behind the product)
     }
@@ -312,6 +345,7 @@ struct GradMlp {
     // ---- forward recompute.  The activations of layer l live in LDS buffer l & 1 (the next layer's B operand) and go to the
     // record stream as they are produced; what the backward pass needs of them afterwards is the sign, kept here ----
     float seed = 0.0f;
+    f32x4 own = f32x4{0, 0, 0, 0};   // this wavefront's first tile of the running activation / gradient: B operand of the next product's step 0
     if constexpr (PHASE != 2) {
     auto layer0 = [&](int rt) {
       f32x4 h;
@@ -332,6 +366,7 @@ struct GradMlp {
         const f32x4 h = layer0(rt);
         b16 |= bits_of(h) << (4 * i);
         Hs[rt * 64 + lane] = h;
+        if (i == 0) own = h;
         if (rec) rec_store(recH + rt * 64, h);
       }
 #pragma unroll
@@ -346,7 +381,8 @@ struct GradMlp {
       }
       mk.put(0, b16);
     }
-    __syncthreads();
+    bool pend = false;     // the previous layer's remainder tiles are still partial sums in Ps (folded behind the next barrier)
+    unsigned b16p = 0u;    // ... and the sign bits of that layer's full tiles wait for theirs
     for (int l = 1; l <= L; ++l) {
       f32x4 accF[FP], accR[RP];
 #pragma unroll
@@ -358,7 +394,31 @@ struct GradMlp {
       }
       // (the product behind this one: the next forward layer; behind the last: the first backward product, or -- recompute
       // kernel -- the next evaluation's first forward layer)
-      product(fwd0, l - 1, (l < L || PHASE == 1) ? fwd0 : bwd0, l < L ? l : (PHASE == 1 ? 0 : L - 1), Hs + (size_t)((l - 1) & 1) * NT * 64, accF, accR);
+      // the layer barrier; behind it every wavefront folds the previous layer's remainder tiles itself and writes the (identical)
+      // activations into that layer's slot -- each reads them back only after its own write, so no second barrier; wavefront 0
+      // also streams the record
+      auto fold_prev = [&](int lp) {   // lp: the layer whose partial sums wait in Ps[par ^ 1]
+        __syncthreads();
+        if (R > 0 && pend) {
+          f32x4 *__restrict__ Hp = Hs + (size_t)(lp & 1) * NT * 64;
+          unsigned b16 = b16p;
+#pragma unroll
+          for (int j = 0; j < R; ++j) {
+            const f32x4 z = fold(Ps + (par ^ 1) * pstride, j);
+            f32x4 h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[r] = lrelu(z[r]);
+            b16 |= bits_of(h) << (4 * (F + j));
+            Hp[(G * F + j) * 64 + lane] = h;
+            if (rec && wave == 0) rec_store(recH + ((size_t)lp * NT + G * F + j) * 64, h);
+          }
+          mk.put(lp, b16);
+        }
+      };
+      // (the product behind this one: the next forward layer; behind the last: the first backward product, or -- recompute
+      // kernel -- the next evaluation's first forward layer)
+      product(fwd0, l - 1, (l < L || PHASE == 1) ? fwd0 : bwd0, l < L ? l : (PHASE == 1 ? 0 : L - 1), Hs + (size_t)((l - 1) & 1) * NT * 64,
+              own, [&] { fold_prev(l - 1); }, accF, accR);
       f32x4 *__restrict__ Hl = Hs + (size_t)(l & 1) * NT * 64;
       unsigned b16 = 0u;
 #pragma unroll
@@ -369,26 +429,16 @@ struct GradMlp {
         for (int r = 0; r < 4; ++r) h[r] = lrelu(accF[i][r]);
         b16 |= bits_of(h) << (4 * i);
         Hl[rt * 64 + lane] = h;
+        if (i == 0) own = h;
         if (rec) rec_store(recH + ((size_t)l * NT + rt) * 64, h);
       }
 #pragma unroll
       for (int j = 0; j < R; ++j) Ps[par * pstride + (j * G + wave) * 64 + lane] = accR[j];
-      __syncthreads();
-      // every wavefront folds the remainder tiles itself and writes the (identical) activations into the layer's slot:
-      // each reads them back only after its own write, so no second barrier; wavefront 0 also streams the record
-#pragma unroll
-      for (int j = 0; j < R; ++j) {
-        const f32x4 z = fold(Ps + par * pstride, j);
-        f32x4 h;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) h[r] = lrelu(z[r]);
-        b16 |= bits_of(h) << (4 * (F + j));
-        Hl[(G * F + j) * 64 + lane] = h;
-        if (rec && wave == 0) rec_store(recH + ((size_t)l * NT + G * F + j) * 64, h);
-      }
-      mk.put(l, b16);
+      if (R > 0) { pend = true; b16p = b16; } else mk.put(l, b16);
       par ^= 1;
+      if (l == L) fold_prev(L);   // behind the last layer: nothing to hide the barrier behind
     }
+    if (L == 0) __syncthreads();
     if constexpr (PHASE == 1) {
       if (rec && wave == 0 && lane < 16) {
         float *sc = rec + (size_t)2 * (L + 1) * NT * 256;
@@ -426,18 +476,38 @@ struct GradMlp {
 #pragma unroll
         for (int r = 0; r < 4; ++r) d[r] = (seed * w[r]) * (((sgL >> (sl + r)) & 1u) ? 1.0f : 0.01f);
         Ds[((L & 1) * NT + rt) * 64 + lane] = d;
+        if (i == 0) own = d;
         if (rec) rec_store(recD + ((size_t)L * NT + rt) * 64, d);
       }
     }
     }
-    __syncthreads();
+    GSTAMP(3);   // slot 3: d_L
+    bool pendb = false;   // the previous product's remainder tiles are still partial sums in Ps
+    unsigned sgp = 0u;    // ... to be masked with these bits
+    if (L == 0) __syncthreads();
     for (int l = L; l >= 1; --l) {
       f32x4 accF[FP], accR[RP];
 #pragma unroll
       for (int i = 0; i < F; ++i) accF[i] = f32x4{0, 0, 0, 0};
 #pragma unroll
       for (int j = 0; j < R; ++j) accR[j] = f32x4{0, 0, 0, 0};
-      product(bwd0, l - 1, (l > 1 || PHASE == 2) ? bwd0 : fwd0, l > 1 ? l - 2 : (PHASE == 2 ? L - 1 : 0), Ds + (size_t)(l & 1) * NT * 64, accF, accR);
+      auto fold_prev = [&](int lp) {   // lp: the layer whose gradient's remainder tiles wait in Ps[par ^ 1]
+        __syncthreads();
+        if (R > 0 && pendb) {
+#pragma unroll
+          for (int j = 0; j < R; ++j) {
+            const f32x4 z = fold(Ps + (par ^ 1) * pstride, j);
+            f32x4 d;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d[r] = z[r] * (((sgp >> (4 * (F + j) + r)) & 1u) ? 1.0f : 0.01f);
+            Ds[((lp & 1) * NT + G * F + j) * 64 + lane] = d;
+            if (rec && wave == 0) rec_store(recD + ((size_t)lp * NT + G * F + j) * 64, d);
+          }
+        }
+      };
+      product(bwd0, l - 1, (l > 1 || PHASE == 2) ? bwd0 : fwd0, l > 1 ? l - 2 : (PHASE == 2 ? L - 1 : 0), Ds + (size_t)(l & 1) * NT * 64,
+              own, [&] { fold_prev(l); }, accF, accR);
+      GSTAMP(4);   // slot 4: the product's MFMA steps (+ barrier and fold behind step 0)
       const unsigned sg = mk.get(l - 1);  // signs of h_{l-1}: this wavefront's full tiles, then the remainder tiles
 #pragma unroll
       for (int i = 0; i < F; ++i) {
@@ -446,29 +516,29 @@ struct GradMlp {
 #pragma unroll
         for (int r = 0; r < 4; ++r) d[r] = accF[i][r] * (((sg >> (4 * i + r)) & 1u) ? 1.0f : 0.01f);
         Ds[(((l - 1) & 1) * NT + rt) * 64 + lane] = d;
+        if (i == 0) own = d;
         if (rec) rec_store(recD + ((size_t)(l - 1) * NT + rt) * 64, d);
       }
 #pragma unroll
       for (int j = 0; j < R; ++j) Ps[par * pstride + (j * G + wave) * 64 + lane] = accR[j];
-      __syncthreads();
-#pragma unroll
-      for (int j = 0; j < R; ++j) {
-        const f32x4 z = fold(Ps + par * pstride, j);
-        f32x4 d;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) d[r] = z[r] * (((sg >> (4 * (F + j) + r)) & 1u) ? 1.0f : 0.01f);
-        Ds[(((l - 1) & 1) * NT + G * F + j) * 64 + lane] = d;
-        if (rec && wave == 0) rec_store(recD + ((size_t)(l - 1) * NT + G * F + j) * 64, d);
-      }
+      pendb = R > 0; sgp = sg;
       par ^= 1;
+      if (l == 1) fold_prev(0);   // behind the last product: the input-layer dot product below reads every tile
+      GSTAMP(5);   // slot 5: mask, LDS / record stores, partial sums
     }
     // ---- d net / d x1 = sum_k W0[k][1] d_0[k]  (x0 is the voltage: a constant of the differentiation) ----
     float part = 0.0f;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
       const f32x4 d = Ds[kt * 64 + lane];
+      if constexpr (NT <= 13) {
+        const f32x4 w = *reinterpret_cast<const f32x4 *>(w01S + 16 * kt + 4 * q);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) part = fmaf(W0s[16 * kt + 4 * q + r][2], d[r], part);
+        for (int r = 0; r < 4; ++r) part = fmaf(w[r], d[r], part);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part = fmaf(W0s[16 * kt + 4 * q + r][2], d[r], part);
+      }
     }
     const float pair = part + __shfl_xor(part, 16);
     const float out = pair + __shfl_xor(pair, 32);
@@ -478,6 +548,7 @@ struct GradMlp {
       else { sc[lane] = x0; sc[16 + lane] = x1; sc[32 + lane] = seed; sc[48 + lane] = 0.0f; }
     }
     __syncthreads();  // the next evaluation's layer 0 rewrites Hs[0] / Ds
+    GSTAMP(6);   // slot 6: input-layer dot product + closing barrier
     return out;
   }
 };
@@ -913,6 +984,15 @@ __global__ void __launch_bounds__(256) ionode_grad_walk_kernel(const GArgs a) {
   const bool writer = valid && wave == 0 && lane < 16;
   GradMlp<NT> mlp;
   mlp.init(a, smem, wave, lane, true);
+#ifdef IONODE_STAMPS
+  Stamps gst;
+  for (int i_ = 0; i_ < 16; ++i_) gst.acc[i_] = 0;
+  gst.last = stamp_now();
+  mlp.gsp = &gst;
+#define WSTAMP(slot) STAMP(gst, slot)
+#else
+#define WSTAMP(slot) do { } while (0)
+#endif
   double *__restrict__ pkl = reinterpret_cast<double *>(smem + ((grad_lds_bytes(a.k.L, NT) + 15) & ~(size_t)15));
 
   double p[NPAR];
@@ -940,6 +1020,7 @@ __global__ void __launch_bounds__(256) ionode_grad_walk_kernel(const GArgs a) {
       dst[0] = v0; dst[1] = v1;
     }
     __syncthreads();
+    WSTAMP(0);   // slot 0: packet burst + barrier
     const double *__restrict__ pk = pkl + j * GRAD_PACKET;
     const double dts = pk[0];
     const bool step = pk[1] != 0.0, initev = pk[2] != 0.0;
@@ -963,6 +1044,11 @@ __global__ void __launch_bounds__(256) ionode_grad_walk_kernel(const GArgs a) {
       ak[6][d] += dts * (2.0 * g4 - 3.0 * g3 + g2) + mu[d];
     }
     float *__restrict__ rec_it = a.records ? a.records + tstep * 6 * a.record_floats : nullptr;
+    WSTAMP(1);   // slot 1: interpolant adjoint
+    // the LeakyReLU' words of an evaluation are loaded one evaluation ahead (their first use is the first instruction of the
+    // backward products: a load issued there waits its full HBM round trip, 2.6 k cycles per stage by the stamps)
+    typename GradMlp<NT>::Signs mk_nxt;
+    mlp.signs_load(a.signs + (tstep * 6) * (GRAD_SIGN_WORDS * 256), mk_nxt);
 #pragma unroll 1
     for (int e = 0; e < 6; ++e) {
       const int i = 5 - e;
@@ -972,9 +1058,10 @@ __global__ void __launch_bounds__(256) ionode_grad_walk_kernel(const GArgs a) {
 #pragma unroll
       for (int d = 0; d < D; ++d) seed[d] = step ? ak[i + 1][d] : ((initev && e == 0) ? mu[d] : 0.0);
       const float seedf = (float)(seed[0] / 1000.0);
-      typename GradMlp<NT>::Signs mk;
+      typename GradMlp<NT>::Signs mk = mk_nxt;
       // (tried: all six evaluations' words in the step's burst, through LDS -- no change, 0.500 vs 0.513 s)
-      mlp.signs_load(a.signs + (tstep * 6 + e) * (GRAD_SIGN_WORDS * 256), mk);
+      if (e < 5) mlp.signs_load(a.signs + (tstep * 6 + e + 1) * (GRAD_SIGN_WORDS * 256), mk_nxt);
+      WSTAMP(2);   // slot 2: stage scalars before the products (+ the previous stage's tail)
       const float dx1 = mlp.vjp_backward(seedf, rec_it ? rec_it + (size_t)e * a.record_floats : nullptr, mk);
       // closed-form terms of the RHS and their parameter gradients (the one-phase kernel's expressions)
       double w[D];
@@ -1024,6 +1111,12 @@ __global__ void __launch_bounds__(256) ionode_grad_walk_kernel(const GArgs a) {
       for (int d = 0; d < D; ++d) a.grad_y0[(size_t)traj * D + d] = lam[d] + (double)gy[d];  // solution[0] = y0
     }
   }
+#ifdef IONODE_STAMPS
+  if (blockIdx.x == 0 && threadIdx.x == 0 && a.packets != nullptr) {
+    double *dbg = a.packets;   // diagnostic build only: the first 16 doubles of the (consumed) packet buffer carry the stamps out
+    for (int i_ = 0; i_ < 16; ++i_) dbg[i_] = (double)gst.acc[i_];
+  }
+#endif
 }
 
 }  // namespace ionode
