@@ -253,7 +253,10 @@ struct GradMlp {
   // and the wait for the slowest wavefront overlap with them (the forward kernel's arrangement, ionode_device.hpp).  Widths
   // without a full tile per wavefront (N <= 48) run `after0` first and read every operand from LDS.
   static constexpr bool OWN0 = (F >= 1) && IONODE_GRAD_OWN0;
-  template <typename After0>
+  // SCHED: what may cross the end of a k-tile step in hipcc's scheduler (sched_barrier mask).  0: nothing -- the refills stay where
+  // they are issued; 0xF: ALU and MFMA may, memory operations may not: -3.5 % on the walk (0.473 -> 0.456 s), +5.8 % on the
+  // regression step (1.94 -> 2.05 ms), so only the walk's products use it.
+  template <int SCHED, typename After0>
   __device__ __forceinline__ void product(unsigned csec, int cl, unsigned nsec, int nl, const f32x4 *__restrict__ B, const f32x4 &own,
                                           After0 after0, f32x4 (&accF)[FP], f32x4 (&accR)[RP]) {
     // the B operand of step s + 1 is read from LDS before the MFMAs of step s (the sched_barrier at the end of a step would
@@ -292,7 +295,7 @@ struct GradMlp {
           if (NT > 1) b_nxt = B[ktile(1) * 64 + lane];
         }
       }
-      __builtin_amdgcn_sched_barrier(0);  // keep the refills here (hipcc otherwise sinks them behind the product)
+      __builtin_amdgcn_sched_barrier(SCHED);  // keep the refills here (hipcc otherwise sinks them behind the product)
     }
   }
 
@@ -417,7 +420,7 @@ struct GradMlp {
       };
       // (the product behind this one: the next forward layer; behind the last: the first backward product, or -- recompute
       // kernel -- the next evaluation's first forward layer)
-      product(fwd0, l - 1, (l < L || PHASE == 1) ? fwd0 : bwd0, l < L ? l : (PHASE == 1 ? 0 : L - 1), Hs + (size_t)((l - 1) & 1) * NT * 64,
+      product<0>(fwd0, l - 1, (l < L || PHASE == 1) ? fwd0 : bwd0, l < L ? l : (PHASE == 1 ? 0 : L - 1), Hs + (size_t)((l - 1) & 1) * NT * 64,
               own, [&] { fold_prev(l - 1); }, accF, accR);
       f32x4 *__restrict__ Hl = Hs + (size_t)(l & 1) * NT * 64;
       unsigned b16 = 0u;
@@ -505,7 +508,7 @@ struct GradMlp {
           }
         }
       };
-      product(bwd0, l - 1, (l > 1 || PHASE == 2) ? bwd0 : fwd0, l > 1 ? l - 2 : (PHASE == 2 ? L - 1 : 0), Ds + (size_t)(l & 1) * NT * 64,
+      product<(PHASE == 2 ? 0xF : 0)>(bwd0, l - 1, (l > 1 || PHASE == 2) ? bwd0 : fwd0, l > 1 ? l - 2 : (PHASE == 2 ? L - 1 : 0), Ds + (size_t)(l & 1) * NT * 64,
               own, [&] { fold_prev(l); }, accF, accR);
       GSTAMP(4);   // slot 4: the product's MFMA steps (+ barrier and fold behind step 0)
       const unsigned sg = mk.get(l - 1);  // signs of h_{l-1}: this wavefront's full tiles, then the remainder tiles
