@@ -1322,10 +1322,13 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
       inst[i] = protocol_v(a, pv, (double)ti, vst[i]);
     }
   };
+#ifndef IONODE_CARRY_V_TINY16
+#define IONODE_CARRY_V_TINY16 1   // the N <= 16 kernel at 16 trajectories per wavefront: next attempt's lookups before the emission (25.9 -> 23.5 ms at 65 536)
+#endif
 #ifndef IONODE_CARRY_V_MLP
 #define IONODE_CARRY_V_MLP 0  // tried for the MLP kernels too: +1 % time (372.6 -> 376.2 ms same box), kept off
 #endif
-  constexpr bool CARRY_V = (LW && D == 2) || (MT::MLP && IONODE_CARRY_V_MLP);  // (6-state: +50 % at 2 wavefronts per SIMD, no change at 1 per SIMD -- 38.0 vs 37.9 ms)
+  constexpr bool CARRY_V = (LW && D == 2) || (MT::MLP && (IONODE_CARRY_V_MLP || (IONODE_CARRY_V_TINY16 && G == 1)));  // (6-state: +50 % at 2 wavefronts per SIMD, no change at 1 per SIMD -- 38.0 vs 37.9 ms)
   if constexpr (CARRY_V) lookup_stages(t, dt);
 
   for (;;) {
