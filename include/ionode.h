@@ -218,15 +218,18 @@ int ionode_dopri5_backward(const ionode_desc *d, int32_t it_begin, int32_t it_en
                            float *records, double *grad_params, double *grad_y0, void *stream);
 
 /*
- * Two-phase form of the same sweep (NN-f / NN-d; same results bit for bit).  Per accepted step the sweep does three kinds of work:
- * what depends on the step's checkpoint only (stage inputs, protocol voltages, rate exponentials, the reduction of the step's
- * output gradients, and the FORWARD half of every vector-Jacobian product), the adjoint algebra, and the BACKWARD products.  Only
- * the last two are sequential.  ionode_dopri5_backward_recompute() runs the first kind for EVERY (tile, step) of the chunk at once
- * -- the whole chip instead of one workgroup per 16-trajectory tile -- writing the activation halves of the records, per tile
- * evaluation ionode_grad_sign_words() 64-bit words of LeakyReLU' bits (`signs`: [ceil(B/16)][it_end - it_begin][6][words]), and
- * per tile and step ionode_grad_packet_doubles() doubles of scalars (`packets`: [ceil(B/16)][it_end - it_begin][doubles]);
- * ionode_dopri5_backward_sweep() then walks the steps with the adjoint algebra and the backward products (it completes the
- * records).  Call order per chunk: recompute, sweep, reduce; recompute of chunk k + 1 may run beside the sweep of chunk k.
+ * Two-phase form of the same sweep (NN-f / NN-d).  A stage's vector-Jacobian product is LINEAR in its seed, and the seed is a scalar
+ * per trajectory: product(seed) = seed * product(1).  Everything else the product needs -- the stage inputs, protocol voltages, rate
+ * exponentials -- and the reduction of the step's output gradients depend on the step's checkpoint only.  So
+ *   ionode_dopri5_backward_recompute()  runs, for EVERY (tile, step) of the chunk at once (the whole chip instead of one workgroup per
+ *       16-trajectory tile), the unit-seed product of all six stages: records with unit-seed D tiles, and per tile and step
+ *       ionode_grad_packet_doubles() doubles of scalars (`packets`: [ceil(B/16)][it_end - it_begin][doubles]);
+ *   ionode_dopri5_backward_sweep()      walks the steps with the adjoint algebra alone (one wavefront per tile, no MLP work) and
+ *       writes each evaluation's seed into its record;
+ *   ionode_grad_reduce_unit()           contracts such records, scaling the D tiles by the seeds while staging them.
+ * Same gradients as ionode_dopri5_backward() up to fp32 rounding (the seed multiplies at the end of the product instead of at its
+ * start).  Call order per chunk: recompute, sweep, reduce_unit; recompute of chunk k + 1 may run beside the sweep of chunk k.
+ * `signs` is unused (kept for ABI 6 callers; may be NULL).
  */
 size_t ionode_grad_sign_words(void);
 size_t ionode_grad_packet_doubles(void);
@@ -239,6 +242,8 @@ int ionode_dopri5_backward_sweep(const ionode_desc *d, int32_t it_begin, int32_t
                                  const double *t_eval, const int32_t *n_accepted, const void *grad_y, double *state,
                                  float *records, const uint64_t *signs, const double *packets, double *grad_params, double *grad_y0,
                                  void *stream);
+int ionode_grad_reduce_unit(int32_t mlp_layers, int32_t mlp_width, const float *records, int64_t n_records, int32_t n_slabs,
+                            float *partials, void *stream);
 
 /* floats of one slab's partial gradient: [NP][4]{db0, dW0[.][0], dW0[.][1], 0} | L x (dW_l [NP][NP] + db_l [NP]) | dwl [NP] +
  * {dbl, 0, 0, 0}, NP = 16 * ceil(N / 16), rows/columns >= N are padding */

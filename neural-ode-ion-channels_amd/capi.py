@@ -28,7 +28,7 @@ EXPORTS = (
     "ionode_launch_geometry", "ionode_kernel_name", "ionode_last_kernel_name", "ionode_dopri5", "ionode_protocol_at_outputs",
     "ionode_grad_image_floats", "ionode_grad_pack", "ionode_grad_record_floats", "ionode_dopri5_backward",
     "ionode_grad_sign_words", "ionode_grad_packet_doubles", "ionode_dopri5_backward_recompute", "ionode_dopri5_backward_sweep",
-    "ionode_grad_partial_floats", "ionode_grad_reduce", "ionode_grad_last_error",
+    "ionode_grad_partial_floats", "ionode_grad_reduce", "ionode_grad_reduce_unit", "ionode_grad_last_error",
     "ionode_regress_step", "ionode_adam_step", "ionode_image_refresh",
 )
 
@@ -102,6 +102,8 @@ def lib():
         L.ionode_dopri5_backward_sweep.argtypes = [C.POINTER(IonodeDesc), C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 15
         L.ionode_grad_reduce.restype = C.c_int
         L.ionode_grad_reduce.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
+        L.ionode_grad_reduce_unit.restype = C.c_int
+        L.ionode_grad_reduce_unit.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
         L.ionode_regress_step.restype = C.c_int
         L.ionode_regress_step.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                           C.c_float, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]

@@ -971,39 +971,31 @@ __global__ void __launch_bounds__(256) ionode_grad_recompute_kernel(const GArgs 
         double *q8 = pk + 16 + 8 * e;
         q8[0] = v; q8[1] = Yi[0]; q8[2] = Yi[1]; q8[3] = e3; q8[4] = e4; q8[5] = e1; q8[6] = e2; q8[7] = 0.0;
       }
-      typename GradMlp<NT>::Signs mk;
-      mlp.vjp_forward(x0, x1, a.records ? a.records + (tstep * 6 + e) * a.record_floats : nullptr, mk);
-      mlp.signs_store(a.signs + (tstep * 6 + e) * (GRAD_SIGN_WORDS * 256), mk);
+      // the WHOLE vector-Jacobian product with seed 1 (it is linear in the seed, a scalar per trajectory): record with unit-seed
+      // D tiles, and c = d net / d x1 for the walk
+      const float c1 = mlp.vjp(x0, x1, 1.0f, a.records ? a.records + (tstep * 6 + e) * a.record_floats : nullptr);
+      if (pk_writer) pk[16 + 8 * e + 7] = (double)c1;
     }
   }
 }
 
-// Phase B: the sequential walk -- adjoint algebra + backward products.  LDS: the GradMlp region, then [16][GRAD_PACKET] doubles.
-template <int MODEL, typename S, int NT>
-__global__ void __launch_bounds__(256) ionode_grad_walk_kernel(const GArgs a) {
+// Phase B: the sequential walk.  NO MLP work is left in it: the vector-Jacobian product of a stage is seed * (unit-seed product),
+// the seed a scalar per trajectory, so the walk multiplies the stage's c = d net / d x1 (packet) by its seed, writes the seed into
+// the record's scalar block for ionode_grad_reduce (which scales the unit-seed D tiles while staging them), and does the adjoint
+// algebra.  One wavefront per 16-trajectory tile (lanes replicate it 4x); LDS: the step's 16 packets.
+template <int MODEL, typename S>
+__global__ void __launch_bounds__(64) ionode_grad_walk_kernel(const GArgs a) {
   constexpr int D = ModelTraits<MODEL>::D, NPAR = ModelTraits<MODEL>::NPAR;
   static_assert(ModelTraits<MODEL>::MLP && D == 2, "NN-f / NN-d");
   constexpr bool NND = MODEL == IONODE_MODEL_NND;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15;
   const int traj_raw = blockIdx.x * 16 + j;
   const bool valid = traj_raw < a.k.B;
   const int traj = valid ? traj_raw : a.k.B - 1;
-  const bool writer = valid && wave == 0 && lane < 16;
-  GradMlp<NT> mlp;
-  mlp.init(a, smem, wave, lane, true);
-#ifdef IONODE_STAMPS
-  Stamps gst;
-  for (int i_ = 0; i_ < 16; ++i_) gst.acc[i_] = 0;
-  gst.last = stamp_now();
-  mlp.gsp = &gst;
-#define WSTAMP(slot) STAMP(gst, slot)
-#else
-#define WSTAMP(slot) do { } while (0)
-#endif
-  double *__restrict__ pkl = reinterpret_cast<double *>(smem + ((grad_lds_bytes(a.k.L, NT) + 15) & ~(size_t)15));
+  const bool writer = valid && lane < 16;
+  double *__restrict__ pkl = reinterpret_cast<double *>(smem);   // [16][GRAD_PACKET]
 
   double p[NPAR];
 #pragma unroll
@@ -1018,19 +1010,18 @@ __global__ void __launch_bounds__(256) ionode_grad_walk_kernel(const GArgs a) {
 #pragma unroll
     for (int i = 0; i < NPAR; ++i) gp[i] = a.it_begin > 0 ? st[2 * D + i] : 0.0;
   }
-  const int tid = wave * 64 + lane;
+  const size_t sc_off = (size_t)2 * (a.k.L + 1) * a.k.NT * 256 + 32;   // the seeds inside a record's scalar block
+  const double2 *__restrict__ psrc = reinterpret_cast<const double2 *>(a.packets + (size_t)blockIdx.x * (a.it_end - a.it_begin) * 16 * GRAD_PACKET) + 8 * lane;
   for (int it = a.it_begin; it < a.it_end; ++it) {
     const size_t tstep = (size_t)blockIdx.x * (a.it_end - a.it_begin) + (it - a.it_begin);
-    // ---- the tile's packets of this step: one 8 KiB burst into LDS (the previous step's last reader is behind a barrier of its
-    // last product) ----
+    __syncthreads();   // (one wavefront: orders the LDS reads of the previous step before these writes)
     {
-      const double2 *src = reinterpret_cast<const double2 *>(a.packets + tstep * 16 * GRAD_PACKET) + 2 * tid;
-      const double2 v0 = src[0], v1 = src[1];
-      double2 *dst = reinterpret_cast<double2 *>(pkl) + 2 * tid;
-      dst[0] = v0; dst[1] = v1;
+      const double2 *__restrict__ src = psrc + (size_t)(it - a.it_begin) * (16 * GRAD_PACKET / 2);
+      double2 *dst = reinterpret_cast<double2 *>(pkl) + 8 * lane;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) dst[u] = src[u];
     }
     __syncthreads();
-    WSTAMP(0);   // slot 0: packet burst + barrier
     const double *__restrict__ pk = pkl + j * GRAD_PACKET;
     const double dts = pk[0];
     const bool step = pk[1] != 0.0, initev = pk[2] != 0.0;
@@ -1054,25 +1045,18 @@ __global__ void __launch_bounds__(256) ionode_grad_walk_kernel(const GArgs a) {
       ak[6][d] += dts * (2.0 * g4 - 3.0 * g3 + g2) + mu[d];
     }
     float *__restrict__ rec_it = a.records ? a.records + tstep * 6 * a.record_floats : nullptr;
-    WSTAMP(1);   // slot 1: interpolant adjoint
-    // the LeakyReLU' words of an evaluation are loaded one evaluation ahead (their first use is the first instruction of the
-    // backward products: a load issued there waits its full HBM round trip, 2.6 k cycles per stage by the stamps)
-    typename GradMlp<NT>::Signs mk_nxt;
-    mlp.signs_load(a.signs + (tstep * 6) * (GRAD_SIGN_WORDS * 256), mk_nxt);
-#pragma unroll 1
-    for (int e = 0; e < 6; ++e) {
-      const int i = 5 - e;
+    // (six compile-time instances: no collective in here any more, and ak[][] must stay register-indexed)
+    auto stage = [&](auto ec) {
+      constexpr int e = decltype(ec)::value;
+      constexpr int i = 5 - e;
       const double *__restrict__ q8 = pk + 16 + 8 * e;
       const double v = q8[0], av = q8[1], rv = q8[2], e3 = q8[3], e4 = q8[4];
       double seed[D];
 #pragma unroll
       for (int d = 0; d < D; ++d) seed[d] = step ? ak[i + 1][d] : ((initev && e == 0) ? mu[d] : 0.0);
       const float seedf = (float)(seed[0] / 1000.0);
-      typename GradMlp<NT>::Signs mk = mk_nxt;
-      // (tried: all six evaluations' words in the step's burst, through LDS -- no change, 0.500 vs 0.513 s)
-      if (e < 5) mlp.signs_load(a.signs + (tstep * 6 + e + 1) * (GRAD_SIGN_WORDS * 256), mk_nxt);
-      WSTAMP(2);   // slot 2: stage scalars before the products (+ the previous stage's tail)
-      const float dx1 = mlp.vjp_backward(seedf, rec_it ? rec_it + (size_t)e * a.record_floats : nullptr, mk);
+      if (rec_it && lane < 16) rec_it[(size_t)e * a.record_floats + sc_off + lane] = seedf;
+      const float dx1 = seedf * (float)q8[7];
       // closed-form terms of the RHS and their parameter gradients (the one-phase kernel's expressions)
       double w[D];
       const double k3 = p[4] * e3, k4 = p[6] * e4;
@@ -1096,13 +1080,16 @@ __global__ void __launch_bounds__(256) ionode_grad_walk_kernel(const GArgs a) {
         for (int d = 0; d < D; ++d) {
           const double wd = (i == 5) ? w[d] + aY1[d] : w[d];
           aY0[d] += wd;
+#pragma unroll
           for (int jx = 0; jx <= i; ++jx) ak[jx][d] += (kBeta[i][jx] * dts) * wd;
         }
       } else if (initev && e == 0) {
 #pragma unroll
         for (int d = 0; d < D; ++d) lam[d] += w[d];
       }
-    }
+    };
+    stage(std::integral_constant<int, 0>{}); stage(std::integral_constant<int, 1>{}); stage(std::integral_constant<int, 2>{});
+    stage(std::integral_constant<int, 3>{}); stage(std::integral_constant<int, 4>{}); stage(std::integral_constant<int, 5>{});
     if (step) {
 #pragma unroll
       for (int d = 0; d < D; ++d) { lam[d] = aY0[d]; mu[d] = ak[0][d]; }
@@ -1121,12 +1108,6 @@ __global__ void __launch_bounds__(256) ionode_grad_walk_kernel(const GArgs a) {
       for (int d = 0; d < D; ++d) a.grad_y0[(size_t)traj * D + d] = lam[d] + (double)gy[d];  // solution[0] = y0
     }
   }
-#ifdef IONODE_STAMPS
-  if (blockIdx.x == 0 && threadIdx.x == 0 && a.packets != nullptr) {
-    double *dbg = a.packets;   // diagnostic build only: the first 16 doubles of the (consumed) packet buffer carry the stamps out
-    for (int i_ = 0; i_ < 16; ++i_) dbg[i_] = (double)gst.acc[i_];
-  }
-#endif
 }
 
 }  // namespace ionode

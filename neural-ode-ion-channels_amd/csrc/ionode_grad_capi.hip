@@ -88,8 +88,8 @@ static int backward_impl(int mode, const ionode_desc *d, int32_t it_begin, int32
                          const double *t_eval, const int32_t *n_accepted, const void *grad_y, double *state,
                          float *records, uint64_t *signs, double *packets, double *grad_params, double *grad_y0, void *stream) {
   if (!d) { gerr("null descriptor"); return IONODE_ERR_ARG; }
-  if (mode != 0 && (!signs || !packets || (d->model != IONODE_MODEL_NNF && d->model != IONODE_MODEL_NND))) {
-    gerr("two-phase sweep: NN-f / NN-d only, `signs` and `packets` required"); return IONODE_ERR_ARG;
+  if (mode != 0 && (!packets || (d->model != IONODE_MODEL_NNF && d->model != IONODE_MODEL_NND))) {
+    gerr("two-phase sweep: NN-f / NN-d only, `packets` required"); return IONODE_ERR_ARG;
   }
   if (mode == 1) {   // phase A carries no adjoint state: stand-ins so that the shared checks pass (never dereferenced)
     static double dummy;
@@ -177,14 +177,24 @@ int ionode_dopri5_backward_sweep(const ionode_desc *d, int32_t it_begin, int32_t
                        state, records, const_cast<uint64_t *>(signs), const_cast<double *>(packets), grad_params, grad_y0, stream);
 }
 
-int ionode_grad_reduce(int32_t L, int32_t N, const float *records, int64_t n_records, int32_t n_slabs, float *partials,
-                       void *stream) {
+static int reduce_impl(int32_t L, int32_t N, const float *records, int64_t n_records, int32_t n_slabs, float *partials, void *stream,
+                       int unit_seed) {
   if (!records || !partials || n_records < 1 || n_slabs < 1 || L < 1 || N < 1) { gerr("ionode_grad_reduce: bad argument"); return IONODE_ERR_ARG; }
   const int NT = np_of(N) / 16;
-  const hipError_t e = ionode::launch_grad_reduce(L, NT, records, n_records, n_slabs, partials, reinterpret_cast<hipStream_t>(stream));
+  const hipError_t e = ionode::launch_grad_reduce(L, NT, records, n_records, n_slabs, partials, reinterpret_cast<hipStream_t>(stream), unit_seed);
   if (e == hipErrorInvalidValue) { gerr("ionode_grad_reduce: width outside the compiled variants"); return IONODE_ERR_UNSUPPORTED; }
   if (e != hipSuccess) { gerr(hipGetErrorString(e)); return IONODE_ERR_LAUNCH; }
   return IONODE_OK;
+}
+
+int ionode_grad_reduce(int32_t L, int32_t N, const float *records, int64_t n_records, int32_t n_slabs, float *partials,
+                       void *stream) {
+  return reduce_impl(L, N, records, n_records, n_slabs, partials, stream, 0);
+}
+
+int ionode_grad_reduce_unit(int32_t L, int32_t N, const float *records, int64_t n_records, int32_t n_slabs, float *partials,
+                            void *stream) {
+  return reduce_impl(L, N, records, n_records, n_slabs, partials, stream, 1);
 }
 
 int ionode_regress_step(int32_t L, int32_t N, const float *grad_image, const float *x, const float *offset, const float *y,

@@ -22,11 +22,8 @@ void launch_sweep(const GArgs &a, unsigned grid, size_t lds, hipStream_t s) {
       return;
     }
     if (a.phase == 2) {
-      auto kern = ionode_grad_walk_kernel<MODEL, S, NT>;
-      const size_t lds2 = ((lds + 15) & ~(size_t)15) + (size_t)16 * GRAD_PACKET * 8;
-      if (lds2 > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds2, s, a);
+      auto kern = ionode_grad_walk_kernel<MODEL, S>;   // one wavefront per tile, the step's 16 packets in LDS
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(64), (size_t)16 * GRAD_PACKET * 8, s, a);
       return;
     }
   }

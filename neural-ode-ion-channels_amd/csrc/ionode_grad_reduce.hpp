@@ -24,8 +24,10 @@ __host__ __device__ constexpr size_t grad_partial_floats(int L, int NT) {
 }
 
 template <int NT>
+// unit_seed: the records' D tiles were produced with seed 1 (the factored two-phase sweep: the product is linear in the seed, a
+// scalar per trajectory, which the walk writes into the record's scalar block afterwards); they are scaled by it while staged.
 __global__ void __launch_bounds__(256) ionode_grad_reduce_kernel(const float *__restrict__ records, int64_t n_records, int n_slabs,
-                                                                 int L, float *__restrict__ partials) {
+                                                                 int L, float *__restrict__ partials, int unit_seed) {
   constexpr int NP = 16 * NT;
   constexpr int F = NT / 4;        // full row tiles per wavefront (rt = wave + 4i, every column tile)
   constexpr int R = NT - 4 * F;    // remainder row tiles, their column tiles dealt round-robin over the wavefronts
@@ -74,7 +76,11 @@ __global__ void __launch_bounds__(256) ionode_grad_reduce_kernel(const float *__
       for (int i = 0; i < RC; ++i) {
         const int rt = wave + 4 * i;
         if (rt < NT) {
-          const f32x4 t = tiles[rt * 64 + lane];
+          f32x4 t = tiles[rt * 64 + lane];
+          if (first && unit_seed) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) t[c] *= sc[32 + 4 * c + kk];   // D_0 of a unit-seed record
+          }
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             a0[i] += first ? t[c] : t[c] * s0[c];
@@ -154,10 +160,24 @@ __global__ void __launch_bounds__(256) ionode_grad_reduce_kernel(const float *__
       }
     }
     f32x4 af[F > 0 ? F : 1], ar[R > 0 ? R : 1];
+    f32x4 sd = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+    if (unit_seed) {
+      const float *sc = records + rr * RECF + (size_t)2 * (L + 1) * NT * 256 + 32;
 #pragma unroll
-    for (int i = 0; i < F; ++i) { af[i] = Db[(wave + 4 * i) * 64 + lane]; dba[i] += af[i]; }
+      for (int c = 0; c < 4; ++c) sd[c] = sc[4 * c + kk];   // this lane's component c is trajectory 4 c + kk
+    }
 #pragma unroll
-    for (int j = 0; j < R; ++j) { ar[j] = Db[(4 * F + j) * 64 + lane]; dbr[j] += ar[j]; }
+    for (int i = 0; i < F; ++i) {
+      af[i] = Db[(wave + 4 * i) * 64 + lane];
+      if (unit_seed) af[i] = af[i] * sd;
+      dba[i] += af[i];
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      ar[j] = Db[(4 * F + j) * 64 + lane];
+      if (unit_seed) ar[j] = ar[j] * sd;
+      dbr[j] += ar[j];
+    }
 #pragma unroll
     for (int ct = 0; ct < CB; ++ct) {
       const f32x4 b = Hb[ct * 64 + lane];
@@ -215,18 +235,18 @@ __global__ void __launch_bounds__(256) ionode_grad_reduce_kernel(const float *__
 }
 
 inline hipError_t launch_grad_reduce(int L, int NT, const float *records, int64_t n_records, int n_slabs, float *partials,
-                                     hipStream_t s) {
+                                     hipStream_t s, int unit_seed = 0) {
   const int CB = (NT <= 13) ? NT : 8, NCB = NT / CB;
   const unsigned grid = (unsigned)(n_slabs * (L * NCB + 2));
   const size_t lds = (size_t)2 * (NT + CB) * 64 * 16;
   switch (NT) {
-    case 1: hipLaunchKernelGGL(ionode_grad_reduce_kernel<1>, dim3(grid), dim3(256), lds, s, records, n_records, n_slabs, L, partials); break;
-    case 7: hipLaunchKernelGGL(ionode_grad_reduce_kernel<7>, dim3(grid), dim3(256), lds, s, records, n_records, n_slabs, L, partials); break;
-    case 13: hipLaunchKernelGGL(ionode_grad_reduce_kernel<13>, dim3(grid), dim3(256), lds, s, records, n_records, n_slabs, L, partials); break;
+    case 1: hipLaunchKernelGGL(ionode_grad_reduce_kernel<1>, dim3(grid), dim3(256), lds, s, records, n_records, n_slabs, L, partials, unit_seed); break;
+    case 7: hipLaunchKernelGGL(ionode_grad_reduce_kernel<7>, dim3(grid), dim3(256), lds, s, records, n_records, n_slabs, L, partials, unit_seed); break;
+    case 13: hipLaunchKernelGGL(ionode_grad_reduce_kernel<13>, dim3(grid), dim3(256), lds, s, records, n_records, n_slabs, L, partials, unit_seed); break;
     case 32: {
       auto kern = ionode_grad_reduce_kernel<32>;
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, records, n_records, n_slabs, L, partials);
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, records, n_records, n_slabs, L, partials, unit_seed);
       break;
     }
     default: return hipErrorInvalidValue;

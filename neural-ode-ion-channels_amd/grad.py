@@ -181,13 +181,12 @@ class _Solve(torch.autograd.Function):
         elif two_phase and not need_w:
             # no record stream: the sign words and packets are what a chunk holds (two buffers of each); bounded chunks also keep
             # phase A one chunk ahead of the walk
-            per_it = tiles * (6 * int(lib.ionode_grad_sign_words()) + int(lib.ionode_grad_packet_doubles())) * 8
+            per_it = tiles * int(lib.ionode_grad_packet_doubles()) * 8
             chunk = max(1, min(n_iter, 256, (budget // 2) // per_it))
             n_chunks = (n_iter + chunk - 1) // chunk
             n_buf = 2 if n_chunks > 1 else 1
         records = [torch.empty(tiles * chunk * 6 * recf, dtype=torch.float32, device=dev) for _ in range(n_buf)] if need_w else [None] * n_buf
-        sgw = int(lib.ionode_grad_sign_words()) if two_phase else 0
-        signs = [torch.empty(tiles * chunk * 6 * sgw, dtype=torch.int64, device=dev) for _ in range(n_buf)] if two_phase else [None] * n_buf
+        signs = [None] * n_buf   # (ABI 6 slot of the first two-phase form; unused by the factored one)
         pkd = int(lib.ionode_grad_packet_doubles()) if two_phase else 0
         packets = [torch.empty(tiles * chunk * pkd, dtype=torch.float64, device=dev) for _ in range(n_buf)] if two_phase else [None] * n_buf
         side = torch.cuda.Stream(dev) if (need_w and n_buf == 2) else main          # reductions
@@ -241,7 +240,8 @@ class _Solve(torch.autograd.Function):
                 side.wait_event(swept)
                 with torch.cuda.stream(side):
                     partials = torch.empty((n_slabs, partf), dtype=torch.float32, device=dev)
-                    rc = lib.ionode_grad_reduce(L, N, _ptr(rec), n_rec, n_slabs, _ptr(partials), C.c_void_p(side.cuda_stream))
+                    reduce = lib.ionode_grad_reduce_unit if two_phase else lib.ionode_grad_reduce   # unit-seed records: scaled while staged
+                    rc = reduce(L, N, _ptr(rec), n_rec, n_slabs, _ptr(partials), C.c_void_p(side.cuda_stream))
                     if rc != 0:
                         raise capi.IonodeError(f"ionode_grad_reduce failed ({rc}): {lib.ionode_grad_last_error().decode()}")
                     acc += partials.double().sum(0)
