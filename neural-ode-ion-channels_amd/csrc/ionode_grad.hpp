@@ -44,8 +44,7 @@ struct GArgs {
   int64_t record_floats;
   double *packets;            // two-phase sweep: the adjoint-independent scalars of every (tile, step): [n_tiles][it_end - it_begin][16][GRAD_PACKET] fp64
   int32_t phase;              // 0: one-phase sweep; 1: phase A (recompute kernel); 2: phase B (walk kernel)
-  unsigned long long *signs;  // two-phase sweep: LeakyReLU' bits of every tile evaluation, [n_tiles][it_end - it_begin][6][GRAD_SIGN_WORDS][256]
-                              // written by ionode_grad_recompute_kernel, read by the sweep (NULL: the sweep recomputes the forward itself)
+  unsigned long long *signs;  // (unused: slot of the first two-phase form, which passed LeakyReLU' bits from phase A to the walk)
 };
 constexpr int GRAD_SIGN_WORDS = 8;   // 64-bit words per lane and evaluation (Signs below)
 // packet of one trajectory and step (doubles): [0] dts, [1] step, [2] initev, [4 + c*2 + d] G_c (interpolant-coefficient adjoint
@@ -107,16 +106,8 @@ struct GradMlp {
   unsigned fwd0, bwd0;  // byte offsets of the fragment sections
   int L, wave, lane;
   int roff;           // this lane's float offset inside a record tile (rec_store)
-#ifdef IONODE_STAMPS   // diagnostic build: phase stamps of workgroup 0 / wavefront 0 of the walk kernel (ionode_grad_capi.hip prints them)
-  Stamps *gsp;
-#define GSTAMP(slot) STAMP(*gsp, slot)
-#else
-#define GSTAMP(slot) do { } while (0)
-#endif
 
-  // first_sec: the fragment section of the FIRST product this workgroup will run (fwd0 layer 0: one-phase sweep, regression,
-  // recompute kernel; bwd0 layer L-1: the sweep of the two-phase scheme)
-  __device__ __forceinline__ void init(const GArgs &a, unsigned char *smem, int wave_, int lane_, bool bwd_only = false) {
+  __device__ __forceinline__ void init(const GArgs &a, unsigned char *smem, int wave_, int lane_) {
     L = a.k.L; wave = wave_; lane = lane_;
     roff = 64 * (lane & 3) + 16 * (lane >> 4) + ((lane & 15) >> 2);
     Hs = reinterpret_cast<f32x4 *>(smem);
@@ -140,8 +131,7 @@ struct GradMlp {
     rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.img), 0, (int)(grad_img_floats(L, NT) * 4), 0x00020000);
     fwd0 = (unsigned)(grad_img_fwd(L, NT) * 4);
     bwd0 = (unsigned)(grad_img_bwd(L, NT) * 4);
-    if (bwd_only) refill_all(bwd0, L - 1);
-    else refill_all(fwd0, 0);  // prime: first product of the first evaluation
+    refill_all(fwd0, 0);  // prime: first product of the first evaluation
     __syncthreads();
   }
   __device__ __forceinline__ int ktile(int s) const { return (s + wave) % NT; }  // wave-uniform (scalar ALU)
@@ -185,35 +175,6 @@ struct GradMlp {
       return (unsigned)((w >> ((l % PER) * BITS)) & full);
     }
   };
-  // two-phase sweep: the sign words travel through HBM, [word][256 threads] per tile evaluation (coalesced)
-  __device__ __forceinline__ void signs_store(unsigned long long *__restrict__ dst, const Signs &mk) const {
-    const int tid = wave * 64 + lane;
-    const int nw = (L + Signs::PER) / Signs::PER;   // layers 0..L
-    dst[tid] = mk.w0;
-    if (nw > 1) dst[256 + tid] = mk.w1;
-    if (nw > 2) dst[512 + tid] = mk.w2;
-    if (nw > 3) dst[768 + tid] = mk.w3;
-    if constexpr (Signs::PER < 4) {
-      if (nw > 4) dst[1024 + tid] = mk.w4;
-      if (nw > 5) dst[1280 + tid] = mk.w5;
-      if (nw > 6) dst[1536 + tid] = mk.w6;
-      if (nw > 7) dst[1792 + tid] = mk.w7;
-    }
-  }
-  __device__ __forceinline__ void signs_load(const unsigned long long *__restrict__ src, Signs &mk) const {
-    const int tid = wave * 64 + lane;
-    const int nw = (L + Signs::PER) / Signs::PER;
-    mk.w0 = src[tid];
-    if (nw > 1) mk.w1 = src[256 + tid];
-    if (nw > 2) mk.w2 = src[512 + tid];
-    if (nw > 3) mk.w3 = src[768 + tid];
-    if constexpr (Signs::PER < 4) {
-      if (nw > 4) mk.w4 = src[1024 + tid];
-      if (nw > 5) mk.w5 = src[1280 + tid];
-      if (nw > 6) mk.w6 = src[1536 + tid];
-      if (nw > 7) mk.w7 = src[1792 + tid];
-    }
-  }
   __device__ __forceinline__ void refill_all(unsigned sec, int l) {
 #pragma unroll
     for (int s = 0; s < PD; ++s)
@@ -261,8 +222,8 @@ struct GradMlp {
   // without a full tile per wavefront (N <= 48) run `after0` first and read every operand from LDS.
   static constexpr bool OWN0 = (F >= 1) && IONODE_GRAD_OWN0;
   // SCHED: what may cross the end of a k-tile step in hipcc's scheduler (sched_barrier mask).  0: nothing -- the refills stay where
-  // they are issued; 0xF: ALU and MFMA may, memory operations may not: -3.5 % on the walk (0.473 -> 0.456 s), +5.8 % on the
-  // regression step (1.94 -> 2.05 ms), so only the walk's products use it.
+  // they are issued.  (0xF -- ALU and MFMA may, memory operations may not -- gained 3.5 % where only backward products ran and
+  // loses 5.8 % on the regression step: 1.94 -> 2.05 ms.)
   template <int SCHED, typename After0>
   __device__ __forceinline__ void product(unsigned csec, int cl, unsigned nsec, int nl, const f32x4 *__restrict__ B, const f32x4 &own,
                                           After0 after0, f32x4 (&accF)[FP], f32x4 (&accR)[RP]) {
@@ -319,34 +280,17 @@ struct GradMlp {
   // One vector-Jacobian product of the net for the 16 trajectories of the tile, all four wavefronts together.
   // x = (V/100, a) as the forward casts them, seed = adjoint of the net output.  Returns seed * d net / d x1.
   // rec != NULL: the (h_l, d_l) tiles and the scalars of this evaluation are streamed there for ionode_grad_reduce.
+  template <bool NTS = true>
   __device__ __forceinline__ float vjp(float x0, float x1, float seed, float *__restrict__ rec) {
-    Signs mk;
     auto fn = [seed](float) -> float { return seed; };
-    return vjp_phases<decltype(fn), 0>(x0, x1, rec, fn, mk);
+    return vjp_from_output<decltype(fn), NTS>(x0, x1, rec, fn);
   }
-  // two-phase sweep: forward recompute only (bits to mk) / backward products only (bits from mk)
-  __device__ __forceinline__ void vjp_forward(float x0, float x1, float *__restrict__ rec, Signs &mk) {
-    auto none = [](float) -> float { return 0.0f; };
-    (void)vjp_phases<decltype(none), 1>(x0, x1, rec, none, mk);
-  }
-  __device__ __forceinline__ float vjp_backward(float seed, float *__restrict__ rec, Signs &mk) {
-    auto fn = [seed](float) -> float { return seed; };
-    return vjp_phases<decltype(fn), 2>(0.0f, 0.0f, rec, fn, mk);
-  }
-
   // The same product with the seed computed from the net's output: seed = seed_of(net([x0, x1])) per lane (regression:
   // d loss / d net).  The output layer runs only when the functor needs it; a constant functor leaves it out.
-  // PHASE 0: the whole product (forward recompute + backward) in one call.  Two-phase sweep: PHASE 1 = the forward
-  // recompute only (activations to the record stream, LeakyReLU' bits to `mk`; the caller stores them: independent of the
-  // adjoint, so every step of every tile can run it at once on the whole chip); PHASE 2 = the backward products only, from the
-  // bits of PHASE 1 (the sequential part).  The arithmetic of each half is the same code, so the results are bit-identical.
-  template <typename SeedFn>
+  // NTS: non-temporal record stores (rec_store)
+  template <typename SeedFn, bool NTS = true>
   __device__ __forceinline__ float vjp_from_output(float x0, float x1, float *__restrict__ rec, SeedFn seed_of) {
     Signs mk;
-    return vjp_phases<SeedFn, 0>(x0, x1, rec, seed_of, mk);
-  }
-  template <typename SeedFn, int PHASE>
-  __device__ __forceinline__ float vjp_phases(float x0, float x1, float *__restrict__ rec, SeedFn seed_of, Signs &mk) {
     const int q = lane >> 4;
     f32x4 *__restrict__ recH = reinterpret_cast<f32x4 *>(rec);
     f32x4 *__restrict__ recD = recH + (size_t)(L + 1) * NT * 64;
@@ -356,7 +300,7 @@ struct GradMlp {
     // record stream as they are produced; what the backward pass needs of them afterwards is the sign, kept here ----
     float seed = 0.0f;
     f32x4 own = f32x4{0, 0, 0, 0};   // this wavefront's first tile of the running activation / gradient: B operand of the next product's step 0
-    if constexpr (PHASE != 2) {
+    {
     auto layer0 = [&](int rt) {
       f32x4 h;
 #pragma unroll
@@ -377,7 +321,7 @@ struct GradMlp {
         b16 |= bits_of(h) << (4 * i);
         Hs[rt * 64 + lane] = h;
         if (i == 0) own = h;
-        if (rec) rec_store<PHASE == 0>(recH + rt * 64, h);
+        if (rec) rec_store<NTS>(recH + rt * 64, h);
       }
 #pragma unroll
       for (int j = 0; j < R; ++j) {
@@ -386,7 +330,7 @@ struct GradMlp {
         b16 |= bits_of(h) << (4 * (F + j));
         if (wave == j) {
           Hs[rt * 64 + lane] = h;
-          if (rec) rec_store<PHASE == 0>(recH + rt * 64, h);
+          if (rec) rec_store<NTS>(recH + rt * 64, h);
         }
       }
       mk.put(0, b16);
@@ -420,14 +364,13 @@ struct GradMlp {
             for (int r = 0; r < 4; ++r) h[r] = lrelu(z[r]);
             b16 |= bits_of(h) << (4 * (F + j));
             Hp[(G * F + j) * 64 + lane] = h;
-            if (rec && wave == 0) rec_store<PHASE == 0>(recH + ((size_t)lp * NT + G * F + j) * 64, h);
+            if (rec && wave == 0) rec_store<NTS>(recH + ((size_t)lp * NT + G * F + j) * 64, h);
           }
           mk.put(lp, b16);
         }
       };
-      // (the product behind this one: the next forward layer; behind the last: the first backward product, or -- recompute
-      // kernel -- the next evaluation's first forward layer)
-      product<0>(fwd0, l - 1, (l < L || PHASE == 1) ? fwd0 : bwd0, l < L ? l : (PHASE == 1 ? 0 : L - 1), Hs + (size_t)((l - 1) & 1) * NT * 64,
+      // (the product behind this one: the next forward layer; behind the last: the first backward product)
+      product<0>(fwd0, l - 1, l < L ? fwd0 : bwd0, l < L ? l : L - 1, Hs + (size_t)((l - 1) & 1) * NT * 64,
               own, [&] { fold_prev(l - 1); }, accF, accR);
       f32x4 *__restrict__ Hl = Hs + (size_t)(l & 1) * NT * 64;
       unsigned b16 = 0u;
@@ -440,7 +383,7 @@ struct GradMlp {
         b16 |= bits_of(h) << (4 * i);
         Hl[rt * 64 + lane] = h;
         if (i == 0) own = h;
-        if (rec) rec_store<PHASE == 0>(recH + ((size_t)l * NT + rt) * 64, h);
+        if (rec) rec_store<NTS>(recH + ((size_t)l * NT + rt) * 64, h);
       }
 #pragma unroll
       for (int j = 0; j < R; ++j) Ps[par * pstride + (j * G + wave) * 64 + lane] = accR[j];
@@ -449,14 +392,6 @@ struct GradMlp {
       if (l == L) fold_prev(L);   // behind the last layer: nothing to hide the barrier behind
     }
     if (L == 0) __syncthreads();
-    if constexpr (PHASE == 1) {
-      if (rec && wave == 0 && lane < 16) {
-        float *sc = rec + (size_t)2 * (L + 1) * NT * 256;
-        sc[lane] = x0; sc[16 + lane] = x1; sc[48 + lane] = 0.0f;   // (the seed slot is the sweep's)
-      }
-      __syncthreads();  // the next evaluation's layer 0 rewrites Hs[0]
-      return 0.0f;
-    }
     // ---- net = wl . h_L + bl (four partial chains, one per lane group, as the forward kernel's last layer), then the seed ----
     {
       float part = 0.0f;
@@ -470,8 +405,6 @@ struct GradMlp {
       const float pair = part + __shfl_xor(part, 16);
       seed = seed_of((pair + __shfl_xor(pair, 32)) + wlS[NP]);
     }
-    } else {
-      seed = seed_of(0.0f);   // PHASE 2: the ODE sweep's seed does not depend on the net's output
     }
     // ---- backward: d_L = seed * wl * lrelu'(h_L); d_{l-1} = (W_l^T d_l) * lrelu'(h_{l-1}) ----
     {
@@ -487,11 +420,10 @@ struct GradMlp {
         for (int r = 0; r < 4; ++r) d[r] = (seed * w[r]) * (((sgL >> (sl + r)) & 1u) ? 1.0f : 0.01f);
         Ds[((L & 1) * NT + rt) * 64 + lane] = d;
         if (i == 0) own = d;
-        if (rec) rec_store<PHASE == 0>(recD + ((size_t)L * NT + rt) * 64, d);
+        if (rec) rec_store<NTS>(recD + ((size_t)L * NT + rt) * 64, d);
       }
     }
     }
-    GSTAMP(3);   // slot 3: d_L
     bool pendb = false;   // the previous product's remainder tiles are still partial sums in Ps
     unsigned sgp = 0u;    // ... to be masked with these bits
     if (L == 0) __syncthreads();
@@ -511,13 +443,12 @@ struct GradMlp {
 #pragma unroll
             for (int r = 0; r < 4; ++r) d[r] = z[r] * (((sgp >> (4 * (F + j) + r)) & 1u) ? 1.0f : 0.01f);
             Ds[((lp & 1) * NT + G * F + j) * 64 + lane] = d;
-            if (rec && wave == 0) rec_store<PHASE == 0>(recD + ((size_t)lp * NT + G * F + j) * 64, d);
+            if (rec && wave == 0) rec_store<NTS>(recD + ((size_t)lp * NT + G * F + j) * 64, d);
           }
         }
       };
-      product<(PHASE == 2 ? 0xF : 0)>(bwd0, l - 1, (l > 1 || PHASE == 2) ? bwd0 : fwd0, l > 1 ? l - 2 : (PHASE == 2 ? L - 1 : 0), Ds + (size_t)(l & 1) * NT * 64,
+      product<0>(bwd0, l - 1, l > 1 ? bwd0 : fwd0, l > 1 ? l - 2 : 0, Ds + (size_t)(l & 1) * NT * 64,
               own, [&] { fold_prev(l); }, accF, accR);
-      GSTAMP(4);   // slot 4: the product's MFMA steps (+ barrier and fold behind step 0)
       const unsigned sg = mk.get(l - 1);  // signs of h_{l-1}: this wavefront's full tiles, then the remainder tiles
 #pragma unroll
       for (int i = 0; i < F; ++i) {
@@ -527,14 +458,13 @@ struct GradMlp {
         for (int r = 0; r < 4; ++r) d[r] = accF[i][r] * (((sg >> (4 * i + r)) & 1u) ? 1.0f : 0.01f);
         Ds[(((l - 1) & 1) * NT + rt) * 64 + lane] = d;
         if (i == 0) own = d;
-        if (rec) rec_store<PHASE == 0>(recD + ((size_t)(l - 1) * NT + rt) * 64, d);
+        if (rec) rec_store<NTS>(recD + ((size_t)(l - 1) * NT + rt) * 64, d);
       }
 #pragma unroll
       for (int j = 0; j < R; ++j) Ps[par * pstride + (j * G + wave) * 64 + lane] = accR[j];
       pendb = R > 0; sgp = sg;
       par ^= 1;
       if (l == 1) fold_prev(0);   // behind the last product: the input-layer dot product below reads every tile
-      GSTAMP(5);   // slot 5: mask, LDS / record stores, partial sums
     }
     // ---- d net / d x1 = sum_k W0[k][1] d_0[k]  (x0 is the voltage: a constant of the differentiation) ----
     float part = 0.0f;
@@ -554,11 +484,9 @@ struct GradMlp {
     const float out = pair + __shfl_xor(pair, 32);
     if (rec && wave == 0 && lane < 16) {
       float *sc = rec + (size_t)2 * (L + 1) * NT * 256;
-      if constexpr (PHASE == 2) sc[32 + lane] = seed;
-      else { sc[lane] = x0; sc[16 + lane] = x1; sc[32 + lane] = seed; sc[48 + lane] = 0.0f; }
+      sc[lane] = x0; sc[16 + lane] = x1; sc[32 + lane] = seed; sc[48 + lane] = 0.0f;
     }
     __syncthreads();  // the next evaluation's layer 0 rewrites Hs[0] / Ds
-    GSTAMP(6);   // slot 6: input-layer dot product + closing barrier
     return out;
   }
 };
@@ -825,16 +753,18 @@ __global__ void __launch_bounds__(256) ionode_dopri5_backward_kernel(const GArgs
 }
 
 // ---------------------------------------------------------------------------------------------
-// Two-phase sweep (NN-f / NN-d).  The one-phase sweep above does, per accepted step of a tile, three kinds of work in one
-// sequential walk on one compute unit: (1) what depends on the checkpoint only -- the stage inputs Y_i, the protocol voltages,
-// the rate exponentials, the reduction of the step's output gradients into the interpolant-coefficient adjoints G_c, and the
-// FORWARD half of every vector-Jacobian product; (2) the adjoint algebra; (3) the BACKWARD products.  Only (2) and (3) are
-// sequential.  Phase A (ionode_grad_recompute_kernel) runs (1) for every (tile, step) of a chunk at once -- grid = (tiles, blocks of
-// IB iterations), the whole chip instead of 64 of 256 compute units at BASELINE configs[4]'s per-GPU batch -- and leaves, per tile
-// evaluation, the activation halves of the records (for ionode_grad_reduce) and the LeakyReLU' bits (`signs`), and per trajectory
-// and step a 64-double packet (GRAD_PACKET).  Phase B (ionode_grad_walk_kernel) walks the steps with (2) and (3): one 8 KiB packet
-// burst per step instead of checkpoint loads, protocol lookups, exps and a 480-shuffle reduction.  Every value is computed by the
-// same expressions as in the one-phase kernel, so the gradients are bit-identical.
+// Two-phase sweep (NN-f / NN-d).  The one-phase sweep above walks a tile's accepted steps on one compute unit -- 64 of 256 at
+// BASELINE configs[4]'s per-GPU batch -- and does everything inside the walk.  But (1) the stage inputs Y_i, the protocol
+// voltages, the rate exponentials and the reduction of the step's output gradients into the interpolant-coefficient adjoints G_c
+// depend on the step's CHECKPOINT only; and (2) a stage's vector-Jacobian product is LINEAR in its seed, which is a scalar per
+// trajectory: vjp(seed) = seed * vjp(1).  So nothing of the MLP depends on the adjoint except through that scalar.
+// Phase A (ionode_grad_recompute_kernel) computes, for every (tile, step) of a chunk at once -- grid = (tiles, blocks of IB
+// iterations): the whole chip -- the UNIT-SEED product of all six stages: records with unit-seed D tiles (ionode_grad_reduce scales
+// them by the seeds while staging them), and per trajectory and step a 64-double packet (GRAD_PACKET: dts, flags, G_c, and per
+// stage V, Y_i, the exponentials, c = d net / d x1 at unit seed).  Phase B (ionode_grad_walk_kernel) is what is sequential: the
+// adjoint algebra, one wavefront per tile, one 8 KiB packet burst per step, the stage's seed written into its record.
+// Against the one-phase sweep the seed multiplies at the END of the fp32 product instead of at its start: equal to fp32 rounding
+// (1e-7 relative per evaluation; tests: 1e-5 on the gradients, the checker's tolerance is 1e-4).
 // ---------------------------------------------------------------------------------------------
 constexpr int GRAD_RECOMPUTE_IB = 4;   // iterations per workgroup
 
@@ -973,7 +903,7 @@ __global__ void __launch_bounds__(256) ionode_grad_recompute_kernel(const GArgs 
       }
       // the WHOLE vector-Jacobian product with seed 1 (it is linear in the seed, a scalar per trajectory): record with unit-seed
       // D tiles, and c = d net / d x1 for the walk
-      const float c1 = mlp.vjp(x0, x1, 1.0f, a.records ? a.records + (tstep * 6 + e) * a.record_floats : nullptr);
+      const float c1 = mlp.template vjp<false>(x0, x1, 1.0f, a.records ? a.records + (tstep * 6 + e) * a.record_floats : nullptr);
       if (pk_writer) pk[16 + 8 * e + 7] = (double)c1;
     }
   }

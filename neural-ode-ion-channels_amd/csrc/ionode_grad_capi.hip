@@ -131,19 +131,6 @@ static int backward_impl(int mode, const ionode_desc *d, int32_t it_begin, int32
   a.phase = mode;
   if (mode != 0 && ionode::grad_lds_bytes(L, NT) + 16 + 16 * ionode::GRAD_PACKET * 8 > 160 * 1024) { gerr("two-phase sweep: LDS"); return IONODE_ERR_UNSUPPORTED; }
   fn(a, (unsigned)((d->n_traj + 15) / 16), lds, reinterpret_cast<hipStream_t>(stream));
-#ifdef IONODE_STAMPS   // diagnostic build: the walk kernel left its phase stamps in the first 16 doubles of the packet buffer
-  if (mode == 2) {
-    static double tot[16];
-    double h[16];
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpy(h, packets, sizeof h, hipMemcpyDeviceToHost);
-    for (int i = 0; i < 16; ++i) tot[i] += h[i];
-    const double stages = 6.0 * (it_end - it_begin);
-    fprintf(stderr, "WALK STAMPS chunk [%d, %d): cycles per stage:", it_begin, it_end);
-    for (int i = 0; i < 8; ++i) fprintf(stderr, " [%d] %.0f", i, h[i] / stages);
-    fprintf(stderr, "\n");
-  }
-#endif
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { gerr(hipGetErrorString(e)); return IONODE_ERR_LAUNCH; }
   return IONODE_OK;
