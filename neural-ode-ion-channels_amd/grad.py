@@ -10,11 +10,13 @@ same gradients.
 
 Three launches per backward (csrc/ionode_grad.hpp, ionode_grad_reduce.hpp), all through the C ABI:
   forward   ionode_dopri5 with accepted-step checkpoints (160 B per step and trajectory)
-  sweep     ionode_dopri5_backward: adjoints of y0 and p1..p8, and the (d_l, h_l) record stream of every MLP
-            vector-Jacobian product (160 KB per 16-trajectory tile evaluation for s00 -- sized for 288 GB of HBM3E and
-            chunked over iterations above `record_budget_bytes`)
-  reduce    ionode_grad_reduce: split-K fp32 MFMA GEMM of the records into per-slab partial weight gradients, summed here
-            in fp64.
+  sweep     adjoints of y0 and p1..p8, and the (d_l, h_l) record stream of every MLP vector-Jacobian product (160 KB per
+            16-trajectory tile evaluation for s00 -- sized for 288 GB of HBM3E and chunked over iterations above
+            `record_budget_bytes`).  NN models: two phases -- ionode_dopri5_backward_recompute (unit-seed products of every
+            (tile, step) at once, whole chip) one chunk ahead of ionode_dopri5_backward_sweep (the sequential walk: adjoint
+            algebra only); closed-form models and two_phase=False: ionode_dopri5_backward (everything inside the walk)
+  reduce    ionode_grad_reduce[_unit]: split-K fp32 MFMA GEMM of the records into per-slab partial weight gradients, summed
+            here in fp64.
 There is no CPU fallback: without libionode.so or a HIP device every call raises.
 """
 import ctypes as C
@@ -168,19 +170,19 @@ class _Solve(torch.autograd.Function):
         chunk = n_iter if not need_w else max(1, min(n_iter, budget // (tiles * 6 * recf * 4)))
         acc = torch.zeros(partf, dtype=torch.float64, device=dev) if need_w else None
         main = torch.cuda.current_stream(dev)
-        # Two-phase sweep (NN models; csrc/ionode_grad.hpp): the forward half of every vector-Jacobian product needs
-        # the step's checkpoint only, so phase A (ionode_dopri5_backward_recompute) runs it for every (tile, step) of a chunk at
-        # once on the whole chip, on its own stream, one chunk AHEAD of phase B (ionode_dopri5_backward_sweep: the sequential walk
-        # with the backward products only, one workgroup per tile); the reduction of a finished chunk runs on a third stream.
-        # Buffers (records, sign words) are double: chunk k + 1's phase A fills one pair while chunk k's walk / reduce use the other.
+        # Two-phase sweep (NN models; csrc/ionode_grad.hpp).  A stage's vector-Jacobian product is linear in its seed
+        # (a scalar per trajectory) and everything else it needs comes from the step's checkpoint: phase A
+        # (ionode_dopri5_backward_recompute) computes the UNIT-SEED products of every (tile, step) of a chunk at once on the whole
+        # chip, on its own stream, one chunk AHEAD of phase B (ionode_dopri5_backward_sweep: the sequential walk, adjoint algebra
+        # only, one wavefront per tile); the reduction of a finished chunk (ionode_grad_reduce_unit: records scaled by the seeds
+        # the walk wrote) runs on a third stream.  Records and packets are double-buffered.
         two_phase = bool(cfg.get("two_phase", os.environ.get("IONODE_GRAD_ONE_PHASE", "0") != "1")) and image is not None
         n_chunks = (n_iter + chunk - 1) // chunk
         n_buf = 2 if (n_chunks > 1 and (need_w or two_phase)) else 1
         if need_w and n_buf == 2:
             chunk = max(1, min(n_iter, (budget // 2) // (tiles * 6 * recf * 4)))
         elif two_phase and not need_w:
-            # no record stream: the sign words and packets are what a chunk holds (two buffers of each); bounded chunks also keep
-            # phase A one chunk ahead of the walk
+            # no record stream: the packets are what a chunk holds (two buffers); bounded chunks also keep phase A one chunk ahead
             per_it = tiles * int(lib.ionode_grad_packet_doubles()) * 8
             chunk = max(1, min(n_iter, 256, (budget // 2) // per_it))
             n_chunks = (n_iter + chunk - 1) // chunk
