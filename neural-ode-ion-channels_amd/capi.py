@@ -195,7 +195,14 @@ def _protocol_major(prot_of_traj):
         if bool((p[1:] >= p[:-1]).all()):
             hit = (None,)
         else:
-            hit = (torch.argsort(p, stable=True).to(torch.int32).contiguous(),)
+            order = torch.argsort(p, stable=True)
+            # XCD-aware: workgroups go round-robin over the 8 XCDs (each with its own 4 MB L2), so consecutive wavefronts of the
+            # protocol-sorted list would spread every protocol over all eight L2s.  Deal the sorted list out in eight contiguous
+            # parts instead -- wavefront i takes wavefront i // 8 of part i % 8 -- and an XCD sees one eighth of the protocols.
+            n = int(order.shape[0])
+            if n % (64 * 8) == 0:
+                order = order.view(8, n // (64 * 8), 64).transpose(0, 1).reshape(-1)
+            hit = (order.to(torch.int32).contiguous(),)
         if len(_order_cache) > 8:
             _order_cache.clear()
         _order_cache[key] = hit
