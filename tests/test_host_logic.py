@@ -272,3 +272,22 @@ def test_stable_step_cap_follows_the_fastest_gate(ion):
     assert np.isclose(grad.stable_step_cap(capi.MODEL_HH2, p, pv), 3.0 / max(lam_r, lam_a), rtol=1e-12)
     cap6 = grad.stable_step_cap(capi.MODEL_MARKOV6, torch.from_numpy(K.P_M6[None, :]), pv)
     assert 0.0 < cap6 < 3.0 / 0.1
+
+
+def test_protocol_major_launch_order_is_dealt_out_over_the_xcds(ion):
+    """capi._protocol_major (launch_order="auto" of the one-trajectory-per-lane kernels): a permutation; every 64-trajectory wavefront
+    holds one protocol; and the wavefronts that share an XCD (workgroup index modulo 8) hold a contiguous eighth of the protocols,
+    so that an XCD's L2 sees 8 of 64 protocols, not all of them.  Already-sorted input: no order at all."""
+    B, P = 64 * 8 * 24, 64
+    pot = (torch.arange(B, dtype=torch.int32) % P).contiguous()
+    order = ion.capi._protocol_major(pot).long()
+    assert sorted(order.tolist()) == list(range(B))
+    prot = pot[order].view(-1, 64)
+    assert bool((prot == prot[:, :1]).all())                      # one protocol per wavefront
+    per_xcd = [set(prot[i::8, 0].tolist()) for i in range(8)]
+    assert all(len(s) == P // 8 for s in per_xcd) and len(set().union(*per_xcd)) == P
+    assert all(max(per_xcd[i]) < min(per_xcd[i + 1]) for i in range(7))
+    assert ion.capi._protocol_major(torch.sort(pot).values.contiguous()) is None
+    ragged = (torch.arange(1000, dtype=torch.int32) % 7).contiguous()   # not a multiple of 512: plain protocol-major
+    o2 = ion.capi._protocol_major(ragged).long()
+    assert sorted(o2.tolist()) == list(range(1000)) and bool((ragged[o2][1:] >= ragged[o2][:-1]).all())
