@@ -77,10 +77,8 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false) {
     pl->v = find_variant(d->model, f32, 1, wslot, tpw == 64 ? 0 : 16, defer);
     pl->grid = (unsigned)((d->n_traj + tpw - 1) / tpw);
     pl->block = 64;
-    // one interpolant row per lane (dense-output broadcast through LDS) + one tail buffer per trajectory (2-state models)
-    // (the 4 KiB behind the rows: tail buffers of the deferred emission, or the fused objective's partial sums)
-    // (+ 768 B: the deferred emission's cursors, the compacted list of emitting lanes, the lanes' trajectory indices)
-    pl->lds = (size_t)64 * (4 + 5 * D) * 8 + (size_t)64 * 64 + 768;
+    // interpolant rows + tail buffers / objective partial sums + cursors + the dense-output work list (ionode_device.hpp LwLds)
+    pl->lds = (size_t)ionode::LwLds::bytes(D, defer == 1, f32 ? 4 : 8);
   } else {
     if (d->mlp_width < 1 || d->mlp_layers < 0) { set_err("bad MLP shape"); return IONODE_ERR_ARG; }
     if (d->mlp_width <= 16 && d->mlp_layers > 10) { set_err("N <= 16 kernels keep at most 10 hidden layers resident"); return IONODE_ERR_UNSUPPORTED; }
@@ -116,7 +114,7 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false) {
     pl->lds = ((size_t)2 * (NT + Gv - 1) * 64 + (size_t)2 * Rv * Gv * 64 + NP) * 16 + ((size_t)d->mlp_layers * NP + NP + 4) * 4;
     // the asm tile (N = 200): + scratch slot (+ the input exchange of the two-column-set tile), MlpTile::lds_total
     if (Gv == 4 && NT == 13) pl->lds = t32 ? ionode::MlpTile<4, 4, 13, 13, 4>::lds_total(d->mlp_layers) : ionode::MlpTile<4, 4, 13, 13, 0>::lds_total(d->mlp_layers);
-    if (t64) pl->lds = ((pl->lds + 15) & ~(size_t)15) + (size_t)64 * (4 + 5 * 2) * 8 + (size_t)64 * 64 + 768;  // + interpolant rows + tails + cursors / list / trajectory indices
+    if (t64) pl->lds = ((pl->lds + 15) & ~(size_t)15) + (size_t)ionode::LwLds::bytes(2, t64defer == 1, f32 ? 4 : 8);  // + the lane-wise kernels' region
   }
   if (!pl->v) { set_err("no kernel variant compiled for this descriptor"); return IONODE_ERR_UNSUPPORTED; }
   return IONODE_OK;

@@ -147,17 +147,43 @@ __device__ __forceinline__ double det_exp_ldexp(double x) {
   const double kf = rint(x * 0x1.71547652b82fep+0);
   double r = fma(-kf, 0x1.62e42fee00000p-1, x);
   r = fma(-kf, 0x1.a39ef35793c76p-33, r);
+  // addend constants as SCALAR operands (fma_sc): left to itself hipcc writes each of them into a VGPR pair first (v_fmac_f64 has
+  // its addend tied to the destination) -- 20 v_mov_b32 per call, a third of the closed-form stage loop's vector instructions
   double p = 1.0 / 6227020800.0;
-  p = fma(p, r, 1.0 / 479001600.0);
-  p = fma(p, r, 1.0 / 39916800.0);
-  p = fma(p, r, 1.0 / 3628800.0);
-  p = fma(p, r, 1.0 / 362880.0);
-  p = fma(p, r, 1.0 / 40320.0);
-  p = fma(p, r, 1.0 / 5040.0);
-  p = fma(p, r, 1.0 / 720.0);
-  p = fma(p, r, 1.0 / 120.0);
-  p = fma(p, r, 1.0 / 24.0);
-  p = fma(p, r, 1.0 / 6.0);
+  p = fma_sc(p, r, 1.0 / 479001600.0);
+  p = fma_sc(p, r, 1.0 / 39916800.0);
+  p = fma_sc(p, r, 1.0 / 3628800.0);
+  p = fma_sc(p, r, 1.0 / 362880.0);
+  p = fma_sc(p, r, 1.0 / 40320.0);
+  p = fma_sc(p, r, 1.0 / 5040.0);
+  p = fma_sc(p, r, 1.0 / 720.0);
+  p = fma_sc(p, r, 1.0 / 120.0);
+  p = fma_sc(p, r, 1.0 / 24.0);
+  p = fma_sc(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return __builtin_ldexp(p, (int)kf);
+}
+
+// det_exp_ldexp() for arguments already known to be in [-708, 708] (no NaN, no overflow, result normal): the same operation
+// sequence without the three range cases.  closed_rates() tests the wavefront's arguments of a stage together (one compare each,
+// one ballot) and takes this path when every lane qualifies -- always, on physical parameters.
+__device__ __forceinline__ double det_exp_inrange(double x) {
+  const double kf = rint(x * 0x1.71547652b82fep+0);
+  double r = fma(-kf, 0x1.62e42fee00000p-1, x);
+  r = fma(-kf, 0x1.a39ef35793c76p-33, r);
+  double p = 1.0 / 6227020800.0;
+  p = fma_sc(p, r, 1.0 / 479001600.0);
+  p = fma_sc(p, r, 1.0 / 39916800.0);
+  p = fma_sc(p, r, 1.0 / 3628800.0);
+  p = fma_sc(p, r, 1.0 / 362880.0);
+  p = fma_sc(p, r, 1.0 / 40320.0);
+  p = fma_sc(p, r, 1.0 / 5040.0);
+  p = fma_sc(p, r, 1.0 / 720.0);
+  p = fma_sc(p, r, 1.0 / 120.0);
+  p = fma_sc(p, r, 1.0 / 24.0);
+  p = fma_sc(p, r, 1.0 / 6.0);
   p = fma(p, r, 0.5);
   p = fma(p, r, 1.0);
   p = fma(p, r, 1.0);
@@ -315,6 +341,33 @@ __device__ __forceinline__ double group8_sum_f64(double x) {
   x = x + dpp_f64<0x141, 0xf>(x);  // row_half_mirror
   return x;
 }
+
+// Number of set bits of m below this lane (+ acc): v_mbcnt_lo / v_mbcnt_hi chain.
+__device__ __forceinline__ int mbcnt(unsigned long long m, int acc = 0) {
+  return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, acc));
+}
+
+// LDS layout of the lane-wise kernels (one trajectory per lane: closed-form models and the N <= 16 nets at 64 per wavefront),
+// behind the MlpTile region when there is one.  Shared by the kernel and the host-side plan (ionode_capi.hip).
+//   rows   [64][ROWB]  a lane's interpolant: {t0, step length} {1/step, 8 spare bytes} {5 x D coefficients}; the deferred
+//                      aligned emission (TAIL == 1) appends {w, o, end, E} (cursors of the trajectory's emission, see `defer`)
+//   aux    tail buffers of the deferred emission [64][TAILB <= 48] -- or the fused objective's partial sums [64][8] fp64
+//   owp    [64] i32    deferred emission: next sample not yet in HBM; otherwise the lane's protocol index
+//   trl    [64] i32    the lane's trajectory index (not with the deferred emission: its rows carry it)
+//   clist  [512] u16   the attempt's dense-output WORK LIST: one entry per 8-sample chunk {lane, 8 * chunk number}
+// gfx950 allocates LDS in 1280-byte granules and the 2-state kernels want 12 wavefronts per compute unit: <= 12 800 bytes.
+struct LwLds {
+  // ss = sizeof(state scalar).  Deferred emission (2 states): coefficients kept in the state dtype + 16 bytes of cursors
+  static __host__ __device__ constexpr int rowx(int D, bool defer, int ss) { return defer ? ((32 + 5 * D * ss + 15) & ~15) : (4 + 5 * D) * 8; }
+  static __host__ __device__ constexpr int rowb(int D, bool defer, int ss) { return rowx(D, defer, ss) + (defer ? 16 : 0); }
+  static __host__ __device__ constexpr int aux_bytes(bool defer, int ss) { return (defer && ss == 8) ? 64 * 48 : 64 * 64; }
+  static __host__ __device__ constexpr int aux_off(int D, bool defer, int ss) { return 64 * rowb(D, defer, ss); }
+  static __host__ __device__ constexpr int owp_off(int D, bool defer, int ss) { return aux_off(D, defer, ss) + aux_bytes(defer, ss); }
+  static __host__ __device__ constexpr int trl_off(int D, bool defer, int ss) { return owp_off(D, defer, ss) + 256; }
+  static __host__ __device__ constexpr int clist_off(int D, bool defer, int ss) { return trl_off(D, defer, ss) + (defer ? 0 : 256); }
+  static __host__ __device__ constexpr int bytes(int D, bool defer, int ss) { return clist_off(D, defer, ss) + 1024; }
+};
+static_assert(LwLds::bytes(2, true, 8) <= 12800 && LwLds::bytes(2, true, 4) <= 12800 && LwLds::bytes(2, false, 8) <= 12800, "2-state kernels: 12 wavefronts per compute unit");
 
 // Uniform protocol grid, in two halves so that a caller can issue the two sample loads of several lookups back to back:
 // the sample index (false: t outside the protocol), and the interpolation from the two samples.
@@ -1009,8 +1062,20 @@ __device__ __forceinline__ void closed_rates(const KArgs &a, const double *p, do
 #pragma unroll
     for (int i = 0; i < NR; ++i) R.kf[i] = (float)p[2 * i] * det_expf((float)((i & 1) ? -p[2 * i + 1] : p[2 * i + 1]) * vf);
   } else {
+    double x[NR];
+    bool inr = true;
 #pragma unroll
-    for (int i = 0; i < NR; ++i) R.k[i] = p[2 * i] * det_exp_ldexp(((i & 1) ? -p[2 * i + 1] : p[2 * i + 1]) * v);
+    for (int i = 0; i < NR; ++i) {
+      x[i] = ((i & 1) ? -p[2 * i + 1] : p[2 * i + 1]) * v;
+      inr = inr && (__builtin_fabs(x[i]) <= 708.0);
+    }
+    if (__ballot(!inr) == 0ull) {   // every argument of every lane in range: none of exp's special cases can apply (wave-uniform branch)
+#pragma unroll
+      for (int i = 0; i < NR; ++i) R.k[i] = p[2 * i] * det_exp_inrange(x[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NR; ++i) R.k[i] = p[2 * i] * det_exp_ldexp(x[i]);
+    }
   }
 }
 template <int MODEL, typename S>
@@ -1219,15 +1284,17 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
   constexpr int LS = 64 / (D * (int)sizeof(S));                      // samples per 64-byte sector, the unit of an L2 -> HBM
                                                                      // write request (TCC_EA0_WRREQ_64B): D == 2: 4 or 8
   constexpr int TAILB = (((LS - 1) * D * (int)sizeof(S)) + 15) & ~15;  // bytes of one trajectory's tail buffer
-  constexpr int ROWB = (4 + 5 * D) * 8;
   // compile-time variant (template parameter TAIL == 1 of a closed-form kernel); the dispatcher selects it only when
   // te_dt > 0, te_exact and i_out == NULL hold (ionode_capi.hip)
   constexpr bool defer = CF2 && TAIL == 1;
+  constexpr int SS = (int)sizeof(S);
+  constexpr int ROWB = LwLds::rowb(D, defer, SS);
+  constexpr int ROWX = LwLds::rowx(D, defer, SS);   // byte offset of the deferred emission's {w, o, end, E} inside a row
   // TAIL == 2 of a closed-form kernel: the current / objective epilogue reads V(t_k) from the pre-pass table a.v_tab (selected
   // by the dispatcher when ionode_desc.v_at_outputs is given); a compile-time variant so that neither variant carries the
   // other's code and registers
   constexpr bool VTAB = !MT::MLP && TAIL == 2;
-  unsigned char *const tails = lsm + 64 * ROWB;
+  unsigned char *const tails = lsm + LwLds::aux_off(D, defer, SS);
   double *const ssep = reinterpret_cast<double *>(tails);  // [64][8] partial sums of the fused objective (never together with defer)
   if constexpr (LW) {
     if (a.sse_out != nullptr) {
@@ -1235,17 +1302,17 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
       for (int m = 0; m < 8; ++m) ssep[lane * 8 + m] = 0.0;
     }
   }
-  // defer: owp[j] = next sample index of trajectory j not yet written to HBM (owp <= oi, oi - owp < LS); elist: the lanes that
-  // emit in the current attempt, compacted (512 bytes behind the 4 KiB of tail buffers; the dispatcher reserves them)
-  int *const owp = reinterpret_cast<int *>(tails + 64 * 64);
-  int *const elist = owp + 64;
-  int *const trl = elist + 64;   // trajectory index of every lane (the packed passes address rows per lane group)
-  if constexpr (LW) { if (lane < LPS) trl[lane] = traj; }
-  if constexpr (LW && !(CF2 && defer)) {
+  // defer: owp[j] = next sample index of trajectory j not yet written to HBM (owp <= oi, oi - owp < LS); otherwise the lane's
+  // protocol index.  trl: trajectory index of every lane (the deferred emission keeps it in the row).  clist: the work list.
+  int *const owp = reinterpret_cast<int *>(lsm + LwLds::owp_off(D, defer, SS));
+  int *const trl = reinterpret_cast<int *>(lsm + LwLds::trl_off(D, defer, SS));
+  unsigned short *const clist = reinterpret_cast<unsigned short *>(lsm + LwLds::clist_off(D, defer, SS));
+  if constexpr (LW && !defer) { if (lane < LPS) trl[lane] = traj; }
+  if constexpr (LW && !defer) {
     if (lane < LPS) owp[lane] = pidx;   // packed emission: the trajectory's protocol index, read per lane group
   }
-  if constexpr (CF2 && defer) {
-    static_assert(TAILB <= 64, "tail buffers fit the reserved 4 KiB");
+  if constexpr (defer) {
+    static_assert(64 * TAILB <= LwLds::aux_bytes(true, SS), "tail buffers fit the reserved region");
     if (lane < LPS) owp[lane] = 0;
     if (valid && lane < LPS) *reinterpret_cast<S *>(tails + lane * TAILB) = y[0], *(reinterpret_cast<S *>(tails + lane * TAILB) + 1) = y[1];
   }
@@ -1484,10 +1551,20 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
         // instead of ~29 v_readlane per emitting trajectory.  The workgroup is one wavefront: LDS is in order, no barrier.
         // The coefficients are fitted and stored two components at a time, so that at most 10 of the 5 x D are live
         // (6-state model: 60 registers fewer at the kernel's pressure peak).
-        double2 *row = reinterpret_cast<double2 *>(lsm) + lane * (ROW / 2);
+        double2 *row = reinterpret_cast<double2 *>(lsm + lane * ROWB);
         row[0] = make_double2(t0, den);
         row[1] = make_double2(rden, 0.0);
         static_assert(D % 2 == 0, "rows hold component pairs");
+        if constexpr (defer) {
+          // deferred emission: coefficients stay in the state dtype (fp32 state: 96-byte rows, five LDS reads per chunk)
+          using S2 = typename std::conditional<SS == 8, double2, float2>::type;
+          S ca[5], cb2[5];
+          fit(0, ca);
+          fit(1, cb2);
+          S2 *cr = reinterpret_cast<S2 *>(lsm + lane * ROWB + 32);
+#pragma unroll
+          for (int c = 0; c < 5; ++c) { S2 v2; v2.x = ca[c]; v2.y = cb2[c]; cr[c] = v2; }
+        } else
 #pragma unroll
         for (int d = 0; d < D; d += 2) {
           S ca[5], cb2[5];
@@ -1528,82 +1605,105 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
       }
       STAMP(stamps_, 9);  // slot 9: output cursor
       if constexpr (CF2 && defer) {
-        // ---- deferred aligned emission (closed-form, D == 2): whole 64-byte sectors, PACKED PK lanes per emitting trajectory ----
-        // A step of these kernels covers 5-10 output samples: emitting one trajectory per pass left 85-90 % of the 64 lanes idle,
-        // and the dense output was 2/3 of the kernel.  Round 3: a pass serves 64 / PK = 8 emitting trajectories, PK = 8 lanes
-        // (consecutive samples) each; everything that was wave-uniform per trajectory (interpolant row, cursor, tail pointer) is
-        // read per lane from the trajectory's LDS row, whose spare slot carries (oi, n_out); the pending-sample cursor `ow` lives
-        // in LDS next to the tail buffers.  Same samples, same arithmetic, same sector-aligned stores (PK samples = 1-2 sectors).
-        constexpr int PK = 8;
-        static_assert(PK % LS == 0 && 64 % PK == 0, "a lane group writes whole sectors");
-        unsigned long long emd = __ballot(n_out > 0 && lane < LPS);
-#ifdef IONODE_EXP_NOEMIT  // timing experiment only (wrong results): stepping cost without any dense output
-        if (n_out > 0 && lane < LPS) owp[lane] = oi + n_out;
-        emd = 0ull;
-#endif
+        // ---- deferred aligned emission (lane-wise kernels, D == 2): whole 64-byte sectors, driven by a WORK LIST of 8-sample chunks ----
+        // Steps differ wildly in the number of output samples they cover (sine-wave legs: 10 % of the accepted steps cover <= 5
+        // samples, the median 39, 10 % >= 170).  Round 3 handed each group of 8 lanes one emitting trajectory at a time and ran a
+        // pass until the longest of its 8 trajectories was done: 78 iterations per attempt where 36 would do (a CPU replay of the
+        // step logs of one wavefront), and the dense output was 72 % of the kernel (phase stamps).  Round 4: every emitting lane
+        // appends its trajectory's chunks {lane, 8 * chunk number} to a list in LDS (offsets from a ballot-plane prefix sum); a pass
+        // takes the next 8 list entries, one per group of 8 lanes, whatever trajectories they belong to.  A lane reads what used to be
+        // wave-uniform per trajectory (interpolant, cursors, trajectory index) from the owner's LDS row.  Steps of more than 8 chunks
+        // are emitted by the whole wavefront, 64 consecutive samples per pass.  Same samples, same arithmetic, same sector-aligned
+        // stores (a chunk = 8 consecutive samples from an 8-sample-aligned position = 1-2 whole sectors).
+        constexpr int PK = 8, NCH_MAX = 8;
+        static_assert(PK % LS == 0 && 64 % PK == 0, "a chunk is made of whole sectors");
+        using S2 = typename std::conditional<SS == 8, double2, float2>::type;
+        const bool em_lane = n_out > 0 && lane < LPS;
+        const unsigned long long emd = __ballot(em_lane);
         if (emd) {
-          if (n_out > 0 && lane < LPS) {
-            reinterpret_cast<int2 *>(lsm + lane * ROWB + 24)[0] = make_int2(oi, n_out);   // the row's spare slot
-            elist[__builtin_amdgcn_mbcnt_hi((unsigned)(emd >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)emd, 0))] = lane;
-          }
-          const int ne = __builtin_popcountll(emd);
-          const int slot = lane / PK, kk = lane % PK;
-          for (int g = 0; g < ne; g += 64 / PK) {
-            const bool has = g + slot < ne;
-            const int jj = elist[has ? g + slot : g];   // (idle lane groups shadow the group's first trajectory, stores masked)
-            const double2 *rj = reinterpret_cast<const double2 *>(lsm) + jj * (ROW / 2);
-            const double2 h0 = rj[0], h1 = rj[1];
-            const double t0b = h0.x, denb = h0.y, rdenb = h1.x;
-            const int2 on2 = *reinterpret_cast<const int2 *>(&h1.y);
-            const int o = on2.x, n = on2.y;
-            S cb[5][D];
-#pragma unroll
-            for (int c = 0; c < 5; ++c) {
-              const double2 cc = rj[2 + c];
-              cb[c][0] = (S)cc.x; cb[c][1] = (S)cc.y;
-            }
-            const int w = owp[jj];
-            const int tr = trl[jj];
-            const long long G0 = (long long)tr * Nt;  // global sample index of the row's first sample
-            const int end = o + n;
-            int E = Nt;                                // samples [w, E) go to HBM now, [E, end) wait in the tail buffer
-            if (end < Nt) {
-              E = (int)(((G0 + end) & ~(long long)(LS - 1)) - G0);
+          int nch = 0, E_own = 0;
+          if (em_lane) {
+            const int w = owp[lane], endx = oi + n_out;
+            const long long G0 = (long long)traj * Nt;  // global sample index of the row's first sample
+            int E = Nt;                                  // samples [w, E) go to HBM now, [E, end) wait in the tail buffer
+            if (endx < Nt) {
+              E = (int)(((G0 + endx) & ~(long long)(LS - 1)) - G0);
               if (E < w) E = w;
             }
-            S *__restrict__ yo = reinterpret_cast<S *>(a.y_out) + (size_t)tr * Nt * D;
-            unsigned char *const tj = tails + jj * TAILB;
-            int b0 = (int)(((G0 + w) & ~(long long)(PK - 1)) - G0);
-            while (__ballot(has && b0 < end) != 0ull) {
-              const int idx = b0 + kk;
-              if (has && idx >= w && idx < end) {
-                S out[D];
-                if (idx < o) {  // computed by an earlier step: parked in the tail buffer
-                  const S *ts = reinterpret_cast<const S *>(tj) + (size_t)(idx - w) * D;
-                  out[0] = ts[0]; out[1] = ts[1];
-                } else {
-                  const S x = (S)div_pos(te_at(idx) - t0b, denb, rdenb);  // _interp_evaluate: x in fp64, cast; running powers
-                  S xp = x;
-#pragma unroll
-                  for (int d = 0; d < D; ++d) out[d] = cb[0][d] + x * cb[1][d];
-#pragma unroll
-                  for (int c = 2; c < 5; ++c) {
-                    xp = xp * x;
-#pragma unroll
-                    for (int d = 0; d < D; ++d) out[d] = out[d] + xp * cb[c][d];
-                  }
-                }
-#ifdef IONODE_EXP_NOSTORE  // timing experiment only (wrong results): everything but the global stores
-                if (idx < E) { if (out[0] == (S)1.2345e-300) store_state<S, D>(yo + (size_t)idx * D, out); }
-#else
-                if (idx < E) store_state<S, D>(yo + (size_t)idx * D, out);
-#endif
-                else store_state<S, D>(reinterpret_cast<S *>(tj) + (size_t)(idx - E) * D, out);
-              }
-              b0 += PK;
-            }
-            if (has && kk == 0) owp[jj] = E;
+            const int b0 = (int)(((G0 + w) & ~(long long)(PK - 1)) - G0);   // first chunk: the aligned block that holds sample w
+            nch = (endx - b0 + PK - 1) / PK;
+            E_own = E;
+            *reinterpret_cast<int2 *>(lsm + lane * ROWB + 24) = make_int2(b0, traj);       // the row's spare slot
+            *reinterpret_cast<int4 *>(lsm + lane * ROWB + ROWX) = make_int4(w, oi, endx, E);
           }
+          // work list of the short steps: exclusive prefix sum of the chunk counts (1 .. 8) over the lanes, from ballots of the
+          // three bit planes of nch - 1 -- no cross-lane data movement
+          const bool shortl = em_lane && nch <= NCH_MAX;
+          const int x = nch - 1;
+          const unsigned long long ms = __ballot(shortl), m0 = __ballot(shortl && (x & 1)), m1 = __ballot(shortl && (x & 2)),
+                                   m2 = __ballot(shortl && (x & 4));
+          const int q = mbcnt(m0, mbcnt(ms)) + 2 * mbcnt(m1) + 4 * mbcnt(m2);
+          const int C = __builtin_popcountll(ms) + __builtin_popcountll(m0) + 2 * __builtin_popcountll(m1) + 4 * __builtin_popcountll(m2);
+#pragma unroll
+          for (int i = 0; i < NCH_MAX; ++i)
+            if (shortl && i < nch) clist[q + i] = (unsigned short)(lane | (i * PK) << 6);
+          struct Row { double t0, den, rden; int b0, tr, w, o, end, E; S cb[5][2]; };
+          auto load_row = [&](int jj) {
+            Row r;
+            const unsigned char *rp = lsm + jj * ROWB;
+            const double2 h0 = *reinterpret_cast<const double2 *>(rp);
+            r.t0 = h0.x; r.den = h0.y;
+            r.rden = *reinterpret_cast<const double *>(rp + 16);
+            const int2 bt = *reinterpret_cast<const int2 *>(rp + 24);
+            r.b0 = bt.x; r.tr = bt.y;
+            const S2 *cr = reinterpret_cast<const S2 *>(rp + 32);
+#pragma unroll
+            for (int c = 0; c < 5; ++c) { const S2 cc = cr[c]; r.cb[c][0] = cc.x; r.cb[c][1] = cc.y; }
+            const int4 cu = *reinterpret_cast<const int4 *>(rp + ROWX);
+            r.w = cu.x; r.o = cu.y; r.end = cu.z; r.E = cu.w;
+            return r;
+          };
+          auto sample = [&](bool has, int idx, const Row &r, int jj) {
+            if (has && idx >= r.w && idx < r.end) {
+              unsigned char *const tj = tails + jj * TAILB;
+              S out[D];
+              if (idx < r.o) {  // computed by an earlier step: parked in the tail buffer
+                const S *ts = reinterpret_cast<const S *>(tj) + (size_t)(idx - r.w) * D;
+                out[0] = ts[0]; out[1] = ts[1];
+              } else {
+                const S x_ = (S)div_pos(te_at(idx) - r.t0, r.den, r.rden);  // _interp_evaluate: x in fp64, cast; running powers
+                S xp = x_;
+#pragma unroll
+                for (int d = 0; d < D; ++d) out[d] = r.cb[0][d] + x_ * r.cb[1][d];
+#pragma unroll
+                for (int c = 2; c < 5; ++c) {
+                  xp = xp * x_;
+#pragma unroll
+                  for (int d = 0; d < D; ++d) out[d] = out[d] + xp * r.cb[c][d];
+                }
+              }
+              if (idx < r.E) store_state<S, D>(reinterpret_cast<S *>(a.y_out) + ((size_t)r.tr * Nt + idx) * D, out);
+              else store_state<S, D>(reinterpret_cast<S *>(tj) + (size_t)(idx - r.E) * D, out);
+            }
+          };
+          const int slot = lane / PK, kk = lane % PK;
+          for (int c0 = 0; c0 < C; c0 += 64 / PK) {
+            const bool has = c0 + slot < C;
+            const unsigned e = clist[has ? c0 + slot : c0];   // (idle lane groups shadow the pass's first chunk, stores masked)
+            const int jj = (int)(e & 63u);
+            const Row r = load_row(jj);
+            sample(has, r.b0 + (int)(e >> 6) + kk, r, jj);
+          }
+          // long steps (more than 64 samples): the whole wavefront, 64 consecutive samples per pass, rows at uniform addresses
+          unsigned long long lm = __ballot(em_lane && !shortl);
+          while (lm) {
+            const int jj = __builtin_ctzll(lm);
+            lm &= lm - 1;
+            const Row r = load_row(jj);
+            const int b0u = __builtin_amdgcn_readfirstlane(r.b0), endu = __builtin_amdgcn_readfirstlane(r.end);
+            for (int b = b0u; b < endu; b += 64) sample(true, b + lane, r, jj);
+          }
+          if (em_lane) owp[lane] = E_own;
         }
         oi += n_out;
       } else if constexpr (!LW && G > 1) {
@@ -1692,16 +1792,15 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
       }
       oi += n_out;
       } else {
-      // ---- round 3, lane-wise kernels on a verified uniform output grid: PACKED emission.  A step of the 6-state model covers
-      // ~20 output samples (2-state: ~34), so one emitting trajectory per pass left 1/2 - 2/3 of the lanes idle, and the dense
-      // output was 70 % of the 6-state kernel's cycles (stamps, 65 536 x 20 001: 55.8 k of 79.8 k per attempt).  A pass serves
-      // 64 / PK emitting trajectories, PK = 8 consecutive samples each per iteration; what was wave-uniform per trajectory
-      // (interpolant row, cursor, protocol) is read per lane from LDS: the trajectory's row, whose spare slot carries
-      // (oi, n_out), and the protocol index parked in the cursor array of the deferred variant.  Same samples, same arithmetic;
-      // the fused objective keeps its summation order (8-lane groups = the same 8 consecutive samples, partial sum number
-      // (k / 8) mod 8 -- which is why, with the objective, steps of more than 64 samples take the one-trajectory-per-pass loop below); V(t_k) and the
-      // reference current of the next iteration are loaded before this iteration's stores.
-      bool packed_lane = false;   // my trajectory's samples are emitted by the packed pass (the others: the loop below)
+      // ---- lane-wise kernels on a verified uniform output grid: WORK-LIST emission (see the deferred variant above for the why).
+      // A step of the 6-state model covers ~20 output samples (2-state: ~34), with a long-tailed spread.  Every emitting lane
+      // appends its step's 8-sample chunks {lane, 8 * chunk number} to the LDS work list; a pass takes the next 8 entries, one per
+      // group of 8 lanes; what used to be wave-uniform per trajectory (interpolant row, cursor, protocol, trajectory index) is read
+      // per lane from LDS: the owner's row, whose spare slot carries (oi, n_out), the protocol index parked in `owp`, the
+      // trajectory index in `trl`.  Same samples, same arithmetic; the fused objective keeps its summation order (a chunk = the same
+      // 8 consecutive samples as before, partial sum number = chunk number -- which is why steps of more than 64 samples take the
+      // one-trajectory-per-pass loop below); V(t_k) and the reference current of the NEXT pass are loaded before this pass's stores.
+      bool packed_lane = false;   // my trajectory's samples are emitted by the work-list passes (the others: the loop below)
       if constexpr (LW && (VTAB || D > 2)) {
         constexpr int PK = 8;
         const bool want_i = (a.i_out != nullptr) || (a.sse_out != nullptr);
@@ -1710,39 +1809,50 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
         // (2-state kernels that also store the states keep the loop below: at ~34 samples per step its 64 consecutive samples per
         // store instruction touch half the cache lines of 8 x 8, and that path is store-bound: 41.5 against 44.7 ms packed)
         if (a.te_exact && (VTAB ? (want_i && (D > 2 || a.y_out == nullptr)) : (!want_i && a.y_out != nullptr))) {
-          packed_lane = n_out > 0 && lane < LPS && (n_out <= 64 || a.sse_out == nullptr);
+          packed_lane = n_out > 0 && lane < LPS && n_out <= 64;
           const unsigned long long emd = __ballot(packed_lane);
           auto emit_packed = [&](auto wi_tag) {
             constexpr bool WI = decltype(wi_tag)::value;
-            if (packed_lane) {
-              reinterpret_cast<int2 *>(lsm + lane * ROWB + 24)[0] = make_int2(oi, n_out);   // the row's spare slot
-              elist[__builtin_amdgcn_mbcnt_hi((unsigned)(emd >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)emd, 0))] = lane;
-            }
-            const int ne = __builtin_popcountll(emd);
+            const int nch = (n_out + PK - 1) / PK;   // 1 .. 8 for the listed lanes
+            if (packed_lane) *reinterpret_cast<int2 *>(lsm + lane * ROWB + 24) = make_int2(oi, oi + n_out);   // the row's spare slot
+            const int x = nch - 1;
+            const unsigned long long m0 = __ballot(packed_lane && (x & 1)), m1 = __ballot(packed_lane && (x & 2)), m2 = __ballot(packed_lane && (x & 4));
+            const int q = mbcnt(m0, mbcnt(emd)) + 2 * mbcnt(m1) + 4 * mbcnt(m2);
+            const int C = __builtin_popcountll(emd) + __builtin_popcountll(m0) + 2 * __builtin_popcountll(m1) + 4 * __builtin_popcountll(m2);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+              if (packed_lane && i < nch) clist[q + i] = (unsigned short)(lane | (i * PK) << 6);
             const int slot = lane / PK, kk = lane % PK;
-            for (int g = 0; g < ne; g += 64 / PK) {
-              const bool has = g + slot < ne;
-              const int jj = elist[has ? g + slot : g];   // (idle lane groups shadow the group's first trajectory, stores masked)
-              const double2 *rj = reinterpret_cast<const double2 *>(lsm) + jj * (ROW / 2);
-              const double2 h0 = rj[0], h1 = rj[1];
-              const double t0b = h0.x, denb = h0.y, rdenb = h1.x;
-              const int2 on2 = *reinterpret_cast<const int2 *>(&h1.y);
-              const int end = on2.x + on2.y;
-              int idx = on2.x + kk;
-              const int tr = trl[jj];
-              double *__restrict__ io = nullptr;
-              const double *__restrict__ pvb = nullptr, *__restrict__ refb = nullptr, *__restrict__ vtb = nullptr;
-              double vk_nxt = 0.0, rf_nxt = 0.0;
-              if constexpr (WI) {
-                const int pj = owp[jj];
-                if (a.i_out) io = a.i_out + (size_t)tr * Nt;
-                pvb = a.prot_v + (size_t)pj * a.Np;
-                if (a.sse_out) refb = a.sse_ref + (size_t)pj * Nt;
-                if constexpr (VTAB) {
-                  vtb = a.v_tab + (size_t)pj * Nt;
-                  if (has && idx < end) { vk_nxt = vtb[idx]; if (refb) rf_nxt = refb[idx]; }
+            // decode of a list entry: trajectory lane, first sample of the lane, and (table variant) the loads of V(t_k) / reference
+            struct Ent { int jj, idx, end, part; bool on; double vk, rf; };
+            auto decode = [&](int c0) {
+              Ent t;
+              const bool has = c0 + slot < C;
+              const unsigned e = clist[has ? c0 + slot : (c0 < C ? c0 : 0)];
+              t.jj = (int)(e & 63u);
+              t.part = (int)(e >> 9);   // chunk number: the objective's partial-sum slot
+              const int2 on2 = *reinterpret_cast<const int2 *>(lsm + t.jj * ROWB + 24);
+              t.idx = on2.x + (int)(e >> 6) + kk;
+              t.end = on2.y;
+              t.on = has && t.idx < t.end;
+              t.vk = 0.0; t.rf = 0.0;
+              if constexpr (VTAB && WI) {
+                if (t.on) {
+                  const int pj = owp[t.jj];
+                  t.vk = a.v_tab[(size_t)pj * Nt + t.idx];
+                  if (a.sse_out) t.rf = a.sse_ref[(size_t)pj * Nt + t.idx];
                 }
               }
+              return t;
+            };
+            Ent nx = decode(0);
+            for (int c0 = 0; c0 < C; c0 += 64 / PK) {
+              const Ent cur = nx;
+              if (c0 + 64 / PK < C) nx = decode(c0 + 64 / PK);
+              const int jj = cur.jj, idx = cur.idx;
+              const double2 *rj = reinterpret_cast<const double2 *>(lsm + jj * ROWB);
+              const double2 h0 = rj[0];
+              const double t0b = h0.x, denb = h0.y, rdenb = rj[1].x;
               S cb[5][D];
 #pragma unroll
               for (int c = 0; c < 5; ++c)
@@ -1751,47 +1861,37 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
                   const double2 cc = rj[2 + (c * D + d) / 2];
                   cb[c][d] = (S)cc.x; cb[c][d + 1] = (S)cc.y;
                 }
-              S *__restrict__ yo = a.y_out ? reinterpret_cast<S *>(a.y_out) + (size_t)tr * Nt * D : nullptr;
-              int part = 0;   // partial sum of the objective this iteration's 8 samples belong to
-              while (__ballot(has && idx < end) != 0ull) {
-                const bool on = has && idx < end;
-                const double vk_cur = vk_nxt, rf_cur = rf_nxt;
-                if constexpr (VTAB && WI) {
-                  if (has && idx + PK < end) { vk_nxt = vtb[idx + PK]; if (refb) rf_nxt = refb[idx + PK]; }
-                }
-                double rr2 = 0.0;
-                if (on) {
-                  const double tk = te_at(idx);
-                  const S x = (S)div_pos(tk - t0b, denb, rdenb);  // _interp_evaluate: x in fp64, cast; running powers
-                  S out[D];
-                  S xp = x;
+              const int tr = trl[jj];
+              double rr2 = 0.0;
+              if (cur.on) {
+                const double tk = te_at(idx);
+                const S x_ = (S)div_pos(tk - t0b, denb, rdenb);  // _interp_evaluate: x in fp64, cast; running powers
+                S out[D];
+                S xp = x_;
 #pragma unroll
-                  for (int d = 0; d < D; ++d) out[d] = cb[0][d] + x * cb[1][d];
+                for (int d = 0; d < D; ++d) out[d] = cb[0][d] + x_ * cb[1][d];
 #pragma unroll
-                  for (int c = 2; c < 5; ++c) {
-                    xp = xp * x;
+                for (int c = 2; c < 5; ++c) {
+                  xp = xp * x_;
 #pragma unroll
-                    for (int d = 0; d < D; ++d) out[d] = out[d] + xp * cb[c][d];
-                  }
-                  if (!WI || yo) store_state<S, D>(yo + (size_t)idx * D, out);
-                  if constexpr (WI) {
-                    double vk;
-                    if constexpr (VTAB) vk = vk_cur;  // == protocol_v(a, pvb, t_eval[idx]), evaluated once per protocol by the pre-pass
-                    else protocol_v(a, pvb, tk, vk);
-                    S gate;
-                    if (a.obs_open) gate = out[D - 1]; else gate = out[0] * out[1];
-                    if (a.obs_g != 1.0) gate = (S)a.obs_g * gate;
-                    const double ik = (double)gate * (vk - a.obs_e);
-                    if (io) io[idx] = ik;
-                    if (refb) { const double rr = ik - (VTAB ? rf_cur : refb[idx]); rr2 = rr * rr; }
-                  }
+                  for (int d = 0; d < D; ++d) out[d] = out[d] + xp * cb[c][d];
                 }
-                if (WI && a.sse_out) {
-                  const double g8 = group8_sum_f64(rr2);
-                  if (kk == 0 && has) ssep[jj * 8 + part] += g8;
-                  part = (part + 1) & 7;
+                if (!WI || a.y_out) store_state<S, D>(reinterpret_cast<S *>(a.y_out) + ((size_t)tr * Nt + idx) * D, out);
+                if constexpr (WI) {
+                  double vk;
+                  if constexpr (VTAB) vk = cur.vk;  // == protocol_v(a, pvb, t_eval[idx]), evaluated once per protocol by the pre-pass
+                  else protocol_v(a, a.prot_v + (size_t)owp[jj] * a.Np, tk, vk);
+                  S gate;
+                  if (a.obs_open) gate = out[D - 1]; else gate = out[0] * out[1];
+                  if (a.obs_g != 1.0) gate = (S)a.obs_g * gate;
+                  const double ik = (double)gate * (vk - a.obs_e);
+                  if (a.i_out) a.i_out[(size_t)tr * Nt + idx] = ik;
+                  if (a.sse_out) { const double rr = ik - (VTAB ? cur.rf : a.sse_ref[(size_t)owp[jj] * Nt + idx]); rr2 = rr * rr; }
                 }
-                idx += PK;
+              }
+              if (WI && a.sse_out) {
+                const double g8 = group8_sum_f64(rr2);
+                if (kk == 0 && c0 + slot < C) ssep[jj * 8 + cur.part] += g8;
               }
             }
           };

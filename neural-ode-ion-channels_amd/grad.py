@@ -31,6 +31,19 @@ _image_cache = {}
 DEFAULT_CKPT_CAP = 4096
 DEFAULT_RECORD_BUDGET = 64 << 30   # of 288 GB HBM3E per GPU: two record buffers of half of it (24 GB: +1.5 % sweep time; 96 GB: -0.5 %)
 DEFAULT_CKPT_BUDGET = 96 << 30   # bytes of accepted-step checkpoints one forward may allocate (a third of the 288 GB of HBM3E)
+MAX_RECOMPUTE_ITERS = 65535 * 4  # phase A launches dim3(tiles, ceil(iterations / GRAD_RECOMPUTE_IB = 4)): HIP caps grid.y at 65535
+
+
+def _bounded_budget(requested, default, dev, share):
+    """An explicit budget is taken as given; the default (tuned for an empty 288 GB MI355X) is capped at `share` of the memory
+    that is free on `dev` right now, so that a smaller or partly occupied GPU gets smaller chunks instead of an allocator failure."""
+    if requested:
+        return int(requested)
+    try:
+        free, _total = torch.cuda.mem_get_info(dev)
+    except Exception:  # no device query available: keep the default
+        return int(default)
+    return int(max(1 << 28, min(default, share * free)))
 
 
 def stable_step_cap(model, params, prot_v, v_oob=-80.0, safety=3.0):
@@ -114,6 +127,10 @@ class _Solve(torch.autograd.Function):
             w_np = weights_flat.detach().to(torch.float32).cpu().numpy()
             from . import batched  # packed forward image: shared cache with the plain solve
             packed = batched.packed_weights(w_np, L, N, dev, key=cfg.get("weights_key"))
+        limit = _bounded_budget(cfg.get("ckpt_budget_bytes"), DEFAULT_CKPT_BUDGET, dev, 0.6)
+        row_bytes = B * (4 + 8 * y0.shape[1]) * 8
+        if cap * row_bytes > limit:   # the FIRST allocation obeys the budget too (a huge batch on a small or occupied GPU)
+            cap = max(1, limit // row_bytes)
         while True:
             ckpt = torch.empty((B, cap, 4 + 8 * y0.shape[1]), dtype=torch.float64, device=dev)
             r = capi.dopri5(cfg["model"], params.detach(), cfg["prot_v"], y0.detach(), cfg["t_eval"], mlp_packed=packed,
@@ -130,8 +147,9 @@ class _Solve(torch.autograd.Function):
             if most <= cap:
                 break
             cap = 1 << int(np.ceil(np.log2(most + 1)))  # the buffer was too small: run the forward again with room
-            need = B * cap * (4 + 8 * y0.shape[1]) * 8
-            limit = int(cfg.get("ckpt_budget_bytes") or DEFAULT_CKPT_BUDGET)
+            if cap * row_bytes > limit and most * row_bytes <= limit:
+                cap = limit // row_bytes   # the power of two does not fit the budget, the steps themselves do
+            need = cap * row_bytes
             if need > limit:
                 raise capi.IonodeError(f"checkpoints of {most} accepted steps x {B} trajectories need {need / 2**30:.1f} GiB "
                                        f"(> ckpt_budget_bytes = {limit / 2**30:.1f} GiB): split the batch or raise the budget")
@@ -166,7 +184,7 @@ class _Solve(torch.autograd.Function):
         tiles = (B + 15) // 16
         recf = lib.ionode_grad_record_floats(L, N) if need_w else 0
         partf = lib.ionode_grad_partial_floats(L, N) if need_w else 0
-        budget = int(cfg.get("record_budget_bytes") or DEFAULT_RECORD_BUDGET)
+        budget = _bounded_budget(cfg.get("record_budget_bytes"), DEFAULT_RECORD_BUDGET, dev, 0.5)
         chunk = n_iter if not need_w else max(1, min(n_iter, budget // (tiles * 6 * recf * 4)))
         acc = torch.zeros(partf, dtype=torch.float64, device=dev) if need_w else None
         main = torch.cuda.current_stream(dev)
@@ -181,6 +199,9 @@ class _Solve(torch.autograd.Function):
         n_buf = 2 if (n_chunks > 1 and (need_w or two_phase)) else 1
         if need_w and n_buf == 2:
             chunk = max(1, min(n_iter, (budget // 2) // (tiles * 6 * recf * 4)))
+            if two_phase and chunk > MAX_RECOMPUTE_ITERS:   # small batch, small net, very long solve: stay inside HIP's grid.y limit
+                chunk = MAX_RECOMPUTE_ITERS
+                n_chunks = (n_iter + chunk - 1) // chunk
         elif two_phase and not need_w:
             # no record stream: the packets are what a chunk holds (two buffers); bounded chunks also keep phase A one chunk ahead
             per_it = tiles * int(lib.ionode_grad_packet_doubles()) * 8
@@ -320,7 +341,7 @@ def solve(model, weights_flat, params, prot_v, y0, t_eval, *, mlp_layers=0, mlp_
                atol=float(atol), v_oob=float(v_oob), max_steps=int(max_steps), max_total_steps=int(max_total_steps),
                max_step=float(max_step), ckpt_cap=ckpt_cap, record_budget_bytes=record_budget_bytes, weights_key=weights_key, t_eval_hint=t_eval_hint,
                tile_waves=int(tile_waves), ckpt_budget_bytes=ckpt_budget_bytes)
-    if two_phase is not None:   # None: the two-phase sweep unless IONODE_GRAD_ONE_PHASE=1; results are the same bits
+    if two_phase is not None:   # None: the two-phase sweep unless IONODE_GRAD_ONE_PHASE=1; results agree to fp32 rounding (1e-5), not bit for bit: the seed multiplies at the end of the product
         cfg["two_phase"] = bool(two_phase)
     return _Solve.apply(weights_flat, params, y0.contiguous(), cfg)
 

@@ -69,6 +69,8 @@ def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, even
 
     max_step = options.get("max_step", 0.0)
     if isinstance(max_step, str):  # "auto": the same cap the differentiable call would use (grad.stable_step_cap)
+        if max_step != "auto":
+            raise ValueError(f"odeint: options['max_step'] must be a number of milliseconds or 'auto', not {max_step!r}")
         max_step = grad.stable_step_cap(spec.model, torch.from_numpy(np.asarray(spec.params, dtype=np.float64)[None, :]),
                                         torch.from_numpy(np.asarray(spec.prot_v, dtype=np.float64)))
     t64 = t.detach().to(torch.float64)
@@ -128,6 +130,13 @@ def _odeint_with_grad(func, y0, t, spec, rtol, atol, options):
     return y[0].reshape((t.numel(),) + tuple(y0.shape)).to(y0.device)
 
 
+_warned_cap = False
+
+
+class StepCapNotice(UserWarning):
+    """Issued once: a differentiable odeint_adjoint call follows the capped step sequence (its forward values differ from odeint's)."""
+
+
 def odeint_adjoint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, event_fn=None,
                    adjoint_rtol=None, adjoint_atol=None, adjoint_method=None, adjoint_options=None, adjoint_params=None):
     """`from torchdiffeq import odeint_adjoint as odeint` (train-s1.py:29-32).  Under torch.no_grad() -- every call site of the
@@ -144,4 +153,12 @@ def odeint_adjoint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=No
     options = dict(options or {})
     if torch.is_grad_enabled() and _wants_grad(func, y0) and "max_step" not in options:
         options["max_step"] = (adjoint_options or {}).get("max_step", "auto")
+        global _warned_cap
+        if not _warned_cap and options["max_step"] == "auto":
+            # torchdiffeq's odeint_adjoint returns exactly odeint's forward values; here a differentiable call follows the CAPPED step
+            # sequence, so its forward values differ (at the solver's tolerance) from odeint's and from the same call under no_grad
+            _warned_cap = True
+            warnings.warn("odeint_adjoint with a gradient requested caps the step size (max_step='auto', the stabilised sweep): its "
+                          "forward values follow the capped step sequence and differ at the rtol level from odeint / the no_grad call. "
+                          "Pass adjoint_options={'max_step': 0} for the uncapped, reference-exact forward.", StepCapNotice, stacklevel=2)
     return odeint(func, y0, t, rtol=rtol, atol=atol, method=method, options=options, event_fn=event_fn)

@@ -43,7 +43,8 @@ def test_dispatch_geometry_and_errors(ion):
     assert g["grid"] == 256 and g["block"] == 256 and g["tile_waves"] == 4 and g["lds_bytes"] < 160 * 1024
     assert "ionode_dopri5_kernel<2, double, 4" in capi.kernel_name(d)
     d.model = capi.MODEL_HH2
-    assert capi.launch_geometry(d) == {"grid": 256, "block": 64, "lds_bytes": 64 * 14 * 8 + 64 * 64 + 768, "tile_waves": 1}  # 16 per wavefront; one interpolant row per lane
+    assert capi.launch_geometry(d) == {"grid": 256, "block": 64, "lds_bytes": 64 * 14 * 8 + 64 * 64 + 512 + 1024, "tile_waves": 1}  # 16 per wavefront; interpolant rows, objective sums, cursors, work list
+    assert capi.launch_geometry(d)["lds_bytes"] <= 12800  # gfx950 LDS granule 1280 B: 12 wavefronts per compute unit
     d.tile_waves = 64
     assert capi.launch_geometry(d)["grid"] == 64
     d.tile_waves = 0
