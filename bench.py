@@ -68,8 +68,11 @@ def main():
                          "of the N > 1 path with one rank on a 1-GPU box")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="rehearsal of the N > 1 code path on a 1-GPU box: every rank uses cuda:0 (use with gloo)")
+    ap.add_argument("--python-prefix-worker", nargs=3, type=int, metavar=("I", "N", "NT"), help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.python_prefix_worker:   # a child of the cpu_baseline_python leg: CPU only, never initialises the GPU
+        return _python_prefix_worker(*args.python_prefix_worker)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: this process becomes the launcher.  It has not touched the
         # GPU (no HIP call so far) and never will; it starts N fresh children, one per GPU, and relays rank 0's line.
@@ -168,8 +171,28 @@ def main():
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     if dist is not None:
         elapsed = allreduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed_own = t1 - t0
     elapsed = float(elapsed.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    # what a SCALE record needs to explain itself: every rank's own wall and kernel time (imbalance = device-to-device spread and step
+    # counts, not communication) and the cost of the path's one collective, measured by itself after the timed region
+    per_rank = None
+    if dist is not None:
+        mine = torch.tensor([elapsed_own / args.steps * 1e3, kern_ms], dtype=torch.float64, device=dev)
+        both = [torch.zeros_like(mine) for _ in range(world)]
+        if args.dist_backend == "nccl":
+            dist.all_gather(both, mine)
+        else:
+            both_c = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(both_c, mine.cpu())
+            both = both_c
+        barrier()
+        ta = time.perf_counter()
+        for _ in range(20):
+            allreduce(torch.zeros(2, dtype=torch.float64, device=dev))
+        torch.cuda.synchronize()
+        per_rank = {"per_rank_ms": [float(b[0]) for b in both], "per_rank_kernel_ms": [float(b[1]) for b in both],
+                    "allreduce_16B_us": (time.perf_counter() - ta) / 20 * 1e6}
 
     stats = r["stats"].cpu().numpy()
     status = r["status"].cpu().numpy()
@@ -210,6 +233,12 @@ def main():
     # which collective library and how many ranks it reports (a SCALE record can be checked from the line itself)
     res["config"]["dist_backend"] = dist.get_backend() if dist is not None else None
     res["config"]["dist_world_size"] = dist.get_world_size() if dist is not None else 1
+    if per_rank is not None:
+        res["config"].update(per_rank)
+        try:   # BASELINE configs[3] over the ranks: equal-count against cost-balanced candidate shards (never part of `value`)
+            res["config"]["objective_sharded"] = sharded_objective_leg(ion, dev, dist, args.dist_backend, rank, world)
+        except Exception as e:  # informational leg only
+            res["config"]["objective_sharded"] = {"error": repr(e)}
     lib_sha = capi.library_digest()
     res["config"]["libionode_sha256"] = lib_sha[:16]
     pmc = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
@@ -501,6 +530,53 @@ def objective_leg(ion, dev, weights):
     return out
 
 
+def sharded_objective_leg(ion, dev, dist, backend, rank, world):
+    """BASELINE.json configs[3] under `--gpus N` (every rank calls this): one CMA-ES generation of 1024 x N HH candidates from the
+    prior box (step counts differ several-fold between candidates) on the nine Pr5 sweeps, fused sum-of-squares objective,
+    candidates sharded over the ranks and the scores all-gathered (objective.population_sum_of_squares).  Twice: contiguous shards of
+    equal COUNT, and shards of equal predicted COST (distributed.shard_bounds_by_cost; cost = every candidate's step count on the
+    first sweep from a pilot solve, gathered over the ranks: what the previous generation gives an optimiser for free).
+    Reports every rank's solve time: max / mean is the imbalance, the gap to the wall time is gather + host overhead."""
+    P = ion.protocols
+    obj = importlib.import_module("neural-ode-ion-channels_amd.objective")
+    batched = importlib.import_module("neural-ode-ion-channels_amd.batched")
+    rng = np.random.default_rng(11)
+    C = 1024 * world
+    p0 = np.array([1.13e-4, 7.45e-2, 3.60e-5, 4.49e-2])
+    cand = p0 * 10.0 ** rng.uniform(-0.7, 0.7, (C, 4))
+    pv = np.stack([P.deactivation_pr5(v) for v in P.PR5_STEPS])
+    S, Np = pv.shape
+    te, data = np.arange(Np) * 0.1, np.zeros((S, Np))
+    kw = dict(base_params=P_HH, prot_t0=0.0, prot_dt=0.1, max_total_steps=20000, device=dev)
+
+    def gather(x):
+        parts = [torch.zeros_like(x) for _ in range(world)]
+        if backend == "nccl":
+            dist.all_gather(parts, x)
+            return torch.cat(parts)
+        parts = [torch.zeros_like(x.cpu()) for _ in range(world)]
+        dist.all_gather(parts, x.cpu())
+        return torch.cat(parts)
+
+    # pilot: this rank's equal-count share of the candidates on sweep 0, two output times -> RHS evaluations per candidate
+    lo, hi = rank * (C // world), (rank + 1) * (C // world)
+    params = np.tile(P_HH, (hi - lo, 1)); params[:, :4] = cand[lo:hi]
+    pilot = batched.solve(ion.capi.MODEL_HH2, params, pv[:1], torch.tensor([[0.0, 1.0]], dtype=torch.float32), np.array([0.0, te[-1]]),
+                          prot_t0=0.0, prot_dt=0.1, max_total_steps=20000, device=dev, t_eval_hint=None)
+    cost = gather(pilot.stats[:, 2].to(torch.float64)).cpu().numpy()
+    out = {"candidates": C, "sweeps": S, "samples_per_sweep": Np}
+    for name, c in (("equal_count", None), ("equal_cost", cost)):
+        obj.population_sum_of_squares(cand[: 16 * world], pv, data, te, **kw)      # warm-up
+        dist.barrier(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        sse = obj.population_sum_of_squares(cand, pv, data, te, cost=c, **kw)
+        torch.cuda.synchronize(); own = (time.perf_counter() - t0) * 1e3
+        dist.barrier(); wall = (time.perf_counter() - t0) * 1e3
+        ranks = gather(torch.tensor([own], dtype=torch.float64, device=dev)).cpu().numpy()
+        out[name] = {"per_rank_ms": [float(x) for x in ranks], "wall_ms": wall, "max_over_mean": float(ranks.max() / ranks.mean()),
+                     "finite": int(torch.isfinite(sse).sum())}
+    return out
+
+
 def launch_order_leg(ion, dev, weights):
     """The s00 kernel at four tiles per compute unit (the batch of BASELINE configs[2]) with the configs[1] protocols: the
     arbitrary trajectory order against schedule.lpt_order() of (a) a closed-form pilot solve and (b) the previous solve's own
@@ -619,21 +695,23 @@ def cpu_baseline(prot_v, weights, Nt, n_sample, gpu_out):
     dt = time.perf_counter() - t0
     g = gpu_out["y"][:n].cpu().numpy()
     err = float(np.linalg.norm(g - o["y"]) / np.linalg.norm(o["y"]))
+    # BASELINE.md section 2 asks for the port on ONE core as well (the reference process is serial, train-s1.py has no pool)
+    n1 = min(n, 12)
+    t0 = time.perf_counter()
+    oracle.solve(oracle.MODEL_NNF, np.tile(P_HH, (n1, 1)), pv[:n1], [0.0, 1.0], te, weights=weights,
+                 mlp_layers=MLP_L, mlp_width=MLP_N, prot_t0=0.0, prot_dt=0.1, nthreads=1)
+    dt1 = time.perf_counter() - t0
     return {"value": n / dt, "unit": "trajectories/s", "cores": cores, "kind": "port",
             "sample": f"first {n} trajectories of the same batch, oracle/liboracle.so (C, AVX2 fp32 fmaf chain), "
-                      f"{dt:.1f} s wall", "rel_l2_gpu_vs_oracle": err}
+                      f"{dt:.1f} s wall", "rel_l2_gpu_vs_oracle": err,
+            "one_core": {"value": n1 / dt1, "unit": "trajectories/s", "cores": 1,
+                         "sample": f"first {n1} trajectories, one thread, {dt1:.1f} s wall"}}
 
 
-def python_reference_structured_baseline(ion, prot_v, weights, Nt, gpu_out, budget_s=25.0):
-    """BASELINE.md 'Baseline A': the reference's cost structure -- a Python dopri5 (the package's opt-in generic
-    stepper) calling an nn.Module.forward shaped like train-s1.py:231-247 (SciPy interp1d on the host per RHS call +
-    fp32 nn.Sequential), one process, one thread.  torchdiffeq itself is not available here.  Bounded: integrates the
-    first trajectory of the batch over a prefix of the output grid that takes ~budget_s, and extrapolates linearly."""
+def _ref_style_nnf(weights):
+    """nn.Module shaped like the reference's ODEFunc (train-s1.py:186-247): fp32 nn.Sequential + SciPy interp1d on the host per RHS call."""
     import torch.nn as nn
     from scipy.interpolate import interp1d
-
-    generic = importlib.import_module("neural-ode-ion-channels_amd.generic")
-    torch.set_num_threads(1)
 
     class RefStyleNNf(nn.Module):
         def __init__(self):
@@ -666,7 +744,34 @@ def python_reference_structured_baseline(ion, prot_v, weights, Nt, gpu_out, budg
             dadt = self.net(torch.stack([(v / 100.0)[0], a[0]]).float()) / 1000.0
             return torch.stack([dadt[0], drdt[0]]).reshape(1, -1)
 
-    f = RefStyleNNf().eval()
+    return RefStyleNNf().eval()
+
+
+def _python_prefix_worker(index, n, Nt):
+    """One process of the all-cores Python leg (`bench.py --python-prefix-worker i n nt`, started as a plain child process before
+    anything touches the GPU): integrate the first n output samples of synthetic trajectory i with the Python stepper, print the time."""
+    torch.set_num_threads(1)
+    generic = importlib.import_module("neural-ode-ion-channels_amd.generic")
+    protocols = importlib.import_module("neural-ode-ion-channels_amd.protocols")
+    weights, _ = load_weights()
+    pv = protocols.sinewave(protocols.sinewave_scales(index, 1), n_samples=Nt, dt=0.1, xp=torch, device="cpu")[0].numpy()
+    f = _ref_style_nnf(weights)
+    tp = np.arange(Nt, dtype=np.float64) * 0.1
+    f.set_protocol(tp, pv)
+    t0 = time.perf_counter()
+    generic.generic_dopri5(f, torch.tensor([[0.0, 1.0]], dtype=torch.float64), torch.from_numpy(tp[:n]))
+    print(json.dumps({"seconds": time.perf_counter() - t0}))
+
+
+def python_reference_structured_baseline(ion, prot_v, weights, Nt, gpu_out, budget_s=12.0):
+    """BASELINE.md 'Baseline A': the reference's cost structure -- a Python dopri5 (the package's opt-in generic
+    stepper) calling an nn.Module.forward shaped like train-s1.py:231-247 (SciPy interp1d on the host per RHS call +
+    fp32 nn.Sequential).  torchdiffeq itself is not available here.  Bounded: integrates a prefix of the output grid that takes
+    ~budget_s and extrapolates linearly in samples.  Two legs: one process / one thread (the reference is serial), and one process
+    per host core over different trajectories (what PINTS' set_parallel(True) does, train-d0.py:538)."""
+    generic = importlib.import_module("neural-ode-ion-channels_amd.generic")
+    torch.set_num_threads(1)
+    f = _ref_style_nnf(weights)
     tp = np.arange(Nt, dtype=np.float64) * 0.1
     f.set_protocol(tp, prot_v[0].cpu().numpy())
     y0 = torch.tensor([[0.0, 1.0]], dtype=torch.float64)
@@ -680,10 +785,27 @@ def python_reference_structured_baseline(ion, prot_v, weights, Nt, gpu_out, budg
     dt = time.perf_counter() - t0
     g = gpu_out["y"][0, :n].cpu().numpy()
     err = float(np.linalg.norm(y[:, 0, :].numpy() - g) / np.linalg.norm(g))
-    return {"value": 1.0 / (dt * Nt / n), "unit": "trajectories/s", "cores": 1, "kind": "port",
-            "sample": f"trajectory 0, first {n} of {Nt} output samples in {dt:.1f} s, extrapolated linearly in samples; "
-                      "Python dopri5 + nn.Module.forward with host interp1d per RHS call (the reference's cost structure)",
-            "rel_l2_vs_gpu": err}
+    res = {"value": 1.0 / (dt * Nt / n), "unit": "trajectories/s", "cores": 1, "kind": "port",
+           "sample": f"trajectory 0, first {n} of {Nt} output samples in {dt:.1f} s, extrapolated linearly in samples; "
+                     "Python dopri5 + nn.Module.forward with host interp1d per RHS call (the reference's cost structure)",
+           "rel_l2_vs_gpu": err}
+    try:
+        import subprocess
+        cores = usable_cores()
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--python-prefix-worker", str(i), str(n), str(Nt)],
+                                  stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for i in range(cores)]
+        times = []
+        for pr in procs:   # (children of a GPU process are allowed; none of them initialises the GPU, and nothing is exec'ed in place)
+            out, _ = pr.communicate(timeout=20 * budget_s + 120)
+            times.append(json.loads(out.strip().splitlines()[-1])["seconds"])
+        wall = time.perf_counter() - t0
+        res["all_cores"] = {"value": cores / (max(times) * Nt / n), "unit": "trajectories/s", "cores": cores,
+                            "sample": f"{cores} processes (one per usable core), trajectory i in process i, first {n} of {Nt} output samples: slowest "
+                                      f"{max(times):.1f} s, fastest {min(times):.1f} s ({wall:.1f} s wall with interpreter start-up), extrapolated linearly"}
+    except Exception as e:  # informational leg only
+        res["all_cores"] = {"error": repr(e)}
+    return res
 
 
 if __name__ == "__main__":

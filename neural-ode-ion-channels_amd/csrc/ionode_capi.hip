@@ -10,6 +10,9 @@
 #ifndef IONODE_TILE32_FROM
 #define IONODE_TILE32_FROM 8192  // N = 200: two 16-trajectory tiles per compute unit
 #endif
+#ifndef IONODE_TINY64_MFMA
+#define IONODE_TINY64_MFMA 0   // 1: N = 10 keeps the MFMA form at 64 trajectories per wavefront (A/B)
+#endif
 #ifndef IONODE_TINY64_FROM
 #define IONODE_TINY64_FROM 73728  // 16 per wavefront: 32 768 trajectories per residency round of 12.8 ms; 64 per wavefront: 131 072 per round of 30 ms
 #endif
@@ -31,21 +34,21 @@ struct Plan {
 };
 
 // Closed-form kernels are registered with NT == 0 and RT = trajectories per wavefront (0 -> 64); rt < 0: any RT.
-const ionode::Variant *find_variant(int model, int f32, int G, int NT, int rt = -1, int tail = 0) {
+const ionode::Variant *find_variant(int model, int f32, int G, int NT, int rt = -1, int tail = 0, int pd = -1) {
   using namespace ionode;
   typedef const Variant *(*TabFn)(int *);
-  static const TabFn tabs[] = {variants_closed, variants_closed3, variants_nnf_f64, variants_nnf_f32, variants_nnd_f64, variants_nnd_f32};
+  static const TabFn tabs[] = {variants_closed, variants_nnf_f64, variants_nnf_f32, variants_nnd_f64, variants_nnd_f32};
   for (TabFn tf : tabs) {
     int n = 0;
     const Variant *t = tf(&n);
     for (int i = 0; i < n; ++i)
-      if (t[i].model == model && t[i].f32 == f32 && (G == 0 || t[i].G == G) && t[i].NT == NT && (rt < 0 || t[i].RT == rt) && t[i].tail == tail)
+      if (t[i].model == model && t[i].f32 == f32 && (G == 0 || t[i].G == G) && t[i].NT == NT && (rt < 0 || t[i].RT == rt) && t[i].tail == tail && (pd < 0 ? !(t[i].RT == 64 && t[i].PD > 1) : t[i].PD == pd))
         return &t[i];
   }
   return nullptr;
 }
 
-int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false) {
+int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false, bool explicit_grid = false) {
   if (!d) { set_err("null descriptor"); return IONODE_ERR_ARG; }
   const bool mlp = d->model == IONODE_MODEL_NNF || d->model == IONODE_MODEL_NND;
   const int D = d->model == IONODE_MODEL_MARKOV6 ? 6 : 2;
@@ -64,16 +67,18 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false) {
     const int tpw = (d->tile_waves == 64 || d->tile_waves == 16) ? d->tile_waves : (d->n_traj >= tpw64_from ? 64 : 16);
     // deferred aligned emission (2-state models): the output grid must be VERIFIED uniform and no current trace requested
     // ... or, with a current trace / fused objective and the protocol-at-outputs table given, the table variant (hint path)
-    const int defer = (want_current && d->v_at_outputs && d->t_eval_dt_hint > 0.0 && d->n_out > 1) ? 2
-                      : ((D == 2 && d->t_eval_exact && d->t_eval_dt_hint > 0.0 && d->n_out > 1 && !want_current) ? 1 : 0);
-    // 2-state model: the 2-wavefronts-per-SIMD build (NT slot 2: 238 VGPRs, no spill) whenever the launch fits ONE residency
-    // round at 2 per SIMD (2048 wavefronts), else the 3-per-SIMD build (tools/ab_hh.sh, ab_hh2.sh: 131 072 trajectories at 64
-    // per wavefront 19.3 against 24.3 ms; beyond one round the 2-per-SIMD build loses, e.g. 163 839: 32.8 against 24.6 ms)
-    const long long waves = ((long long)d->n_traj + tpw - 1) / tpw;
-    int wslot = (d->model == IONODE_MODEL_HH2 && waves <= 2048) ? 2 : 0;
-    // 6-state model: one wavefront per SIMD (the whole register file) at every batch.  (Round 3 had a two-per-SIMD build for
-    // launches beyond two residency rounds; since the packed dense output the two are within 3 % of each other -- 196 608: 69.5
-    // against 72.8 ms, 262 144: 96.1 against 93.7 ms -- and that build was the library's only user of scratch: removed.)
+    // The specialised variants are compiled under a CONTRACT (ionode_device.hpp, top of the kernel): uniform protocol grid, no step log,
+    // no checkpoints -- anything else takes the general variant (TAIL slot 0).
+    const bool lean_ok = !explicit_grid && !d->step_log && !d->ckpt;
+    //   1: states only on a VERIFIED uniform output grid (2-state models: deferred aligned emission)
+    //   2: current trace / fused objective with the protocol-at-outputs table given (hint path)
+    const int defer = !lean_ok ? 0
+                      : (want_current && d->v_at_outputs && d->t_eval_dt_hint > 0.0 && d->n_out > 1) ? 2
+                      : ((d->t_eval_exact && d->t_eval_dt_hint > 0.0 && d->n_out > 1 && !want_current) ? 1 : 0);
+    // (Rounds 2-3 kept two builds of the 2-state kernels -- 2 and 3 wavefronts per SIMD -- and switched at 2048 wavefronts; since round 4
+    // one build runs at three per SIMD without a spill: ionode_device.hpp IONODE_CF_WAVES.)
+    // 6-state model: one wavefront per SIMD (the whole register file) at every batch.
+    const int wslot = 0;
     pl->v = find_variant(d->model, f32, 1, wslot, tpw == 64 ? 0 : 16, defer);
     pl->grid = (unsigned)((d->n_traj + tpw - 1) / tpw);
     pl->block = 64;
@@ -95,13 +100,15 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false) {
     const bool img64 = d->traj_per_image <= 0 || d->traj_per_image % 64 == 0;
     const bool t64 = NT == 1 && (d->tile_waves == 64 || (d->tile_waves == 0 && d->n_traj >= IONODE_TINY64_FROM && img64));
     // (deferred aligned emission as for the 2-state closed-form kernels: verified uniform output grid, no current / objective)
-    const int t64defer = (t64 && d->t_eval_exact && d->t_eval_dt_hint > 0.0 && d->n_out > 1 && !want_current) ? 1 : 0;
+    const int t64defer = (t64 && d->t_eval_exact && d->t_eval_dt_hint > 0.0 && d->n_out > 1 && !want_current && !explicit_grid && !d->step_log && !d->ckpt) ? 1 : 0;
     // N = 200: from two 16-trajectory tiles per compute unit on (8192 trajectories), 32-trajectory tiles -- two column sets per weight
     // fragment, the scalar integrator work replicated twice instead of four times (tile_waves = 8 forces it, 4 forces the 16-tile).
     // Needs a hidden layer (asm stream) and weight images that cover whole 32-trajectory tiles.
     const bool t32 = !t64 && NT == 13 && d->mlp_layers >= 1 && (d->traj_per_image <= 0 || d->traj_per_image % 32 == 0) &&
                      (d->tile_waves == 8 || (d->tile_waves == 0 && d->n_traj >= IONODE_TILE32_FROM));
-    pl->v = t64 ? find_variant(d->model, f32, 1, NT, 64, t64defer)
+    // N = 10 (architectures s03-s05) at one trajectory per lane: the per-lane vector-ALU net (MlpLane), unless IONODE_TINY64_MFMA
+    const bool vnet = t64 && d->mlp_width == 10 && !IONODE_TINY64_MFMA;
+    pl->v = t64 ? find_variant(d->model, f32, 1, NT, 64, t64defer, vnet ? 10 : 1)
                 : find_variant(d->model, f32, (d->tile_waves == 8 ? 4 : d->tile_waves), NT, NT == 1 ? 1 : -1, t32 ? 4 : 0);
     if (!pl->v) {
       set_err("MLP width outside the compiled kernel variants: N must pad to 16, 112, 208 or 512 "
@@ -114,7 +121,7 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false) {
     pl->lds = ((size_t)2 * (NT + Gv - 1) * 64 + (size_t)2 * Rv * Gv * 64 + NP) * 16 + ((size_t)d->mlp_layers * NP + NP + 4) * 4;
     // the asm tile (N = 200): + scratch slot (+ the input exchange of the two-column-set tile), MlpTile::lds_total
     if (Gv == 4 && NT == 13) pl->lds = t32 ? ionode::MlpTile<4, 4, 13, 13, 4>::lds_total(d->mlp_layers) : ionode::MlpTile<4, 4, 13, 13, 0>::lds_total(d->mlp_layers);
-    if (t64) pl->lds = ((pl->lds + 15) & ~(size_t)15) + (size_t)ionode::LwLds::bytes(2, t64defer == 1, f32 ? 4 : 8);  // + the lane-wise kernels' region
+    if (t64) pl->lds = (vnet ? (size_t)0 : ((pl->lds + 15) & ~(size_t)15)) + (size_t)ionode::LwLds::bytes(2, t64defer == 1, f32 ? 4 : 8);  // + the lane-wise kernels' region
   }
   if (!pl->v) { set_err("no kernel variant compiled for this descriptor"); return IONODE_ERR_UNSUPPORTED; }
   return IONODE_OK;
@@ -161,7 +168,9 @@ size_t ionode_mlp_packed_floats(int32_t L, int32_t N) {
   int G, RT;
   if (L < 0 || N < 1 || !tile_shape(N, &G, &RT)) return 0;
   const size_t NP = (size_t)np_of(N), NT = NP / 16;
-  return 4 * NP + (size_t)L * ((size_t)G * frags_per_wave((int)NT, G) * 256 + NP) + NP + 4;
+  // N <= 16: + the scalar section of the per-lane net (rows of RS floats: weights in the canonical k order, bias, pad)
+  const size_t scalar = (NT == 1) ? (size_t)L * (size_t)N * (size_t)((N + 1 + 3) & ~3) : 0;
+  return 4 * NP + (size_t)L * ((size_t)G * frags_per_wave((int)NT, G) * 256 + NP) + NP + 4 + scalar;
 }
 
 int ionode_mlp_pack(const float *w, int32_t L, int32_t N, float *out) {
@@ -217,6 +226,25 @@ int ionode_mlp_pack(const float *w, int32_t L, int32_t N, float *out) {
   }
   for (int k = 0; k < N; ++k) dst[k] = src[k];
   dst[NP] = src[N];
+  if (NT == 1) {
+    // scalar section (ionode_device.hpp MlpLane): hidden layer l, row j: W[j][k] for k = 4 q + r < N in the order r-major / q-minor
+    // (the order in which the 16 x 16 x 4 MFMA tile accumulates them), then the bias as bias + 0.0f (a -0 bias becomes +0: see MlpLane)
+    const int RS = (N + 1 + 3) & ~3;
+    float *sc = dst + NP + 4;
+    const float *lsrc = b0 + N;
+    for (int l = 0; l < L; ++l) {
+      const float *W = lsrc, *b = lsrc + (size_t)N * N;
+      for (int j = 0; j < N; ++j) {
+        float *row = sc + ((size_t)l * N + j) * RS;
+        int pos = 0;
+        for (int r = 0; r < 4; ++r)
+          for (int q = 0; q < 4; ++q)
+            if (4 * q + r < N) row[pos++] = W[(size_t)j * N + 4 * q + r];
+        row[N] = (N < 16) ? b[j] + 0.0f : b[j];
+      }
+      lsrc += (size_t)N * N + N;
+    }
+  }
   return IONODE_OK;
 }
 
@@ -244,7 +272,7 @@ int ionode_dopri5(const ionode_desc *d, const float *mlp_packed, const double *p
                   const double *prot_t, const int32_t *prot_of_traj, const void *y0, const double *t_eval,
                   void *y_out, double *i_out, int32_t *status, int64_t *stats, void *stream) {
   Plan pl;
-  const int rc = make_plan(d, &pl, i_out != nullptr || d->sse_out != nullptr);
+  const int rc = make_plan(d, &pl, i_out != nullptr || d->sse_out != nullptr, prot_t != nullptr);
   if (rc != IONODE_OK) return rc;
   const bool mlp = d->model == IONODE_MODEL_NNF || d->model == IONODE_MODEL_NND;
   if (!params || !prot_v || !y0 || !t_eval || (!y_out && !d->sse_out) || !status || (mlp && !mlp_packed)) {

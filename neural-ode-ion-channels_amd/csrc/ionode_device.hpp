@@ -357,17 +357,23 @@ __device__ __forceinline__ int mbcnt(unsigned long long m, int acc = 0) {
 //   clist  [512] u16   the attempt's dense-output WORK LIST: one entry per 8-sample chunk {lane, 8 * chunk number}
 // gfx950 allocates LDS in 1280-byte granules and the 2-state kernels want 12 wavefronts per compute unit: <= 12 800 bytes.
 struct LwLds {
-  // ss = sizeof(state scalar).  Deferred emission (2 states): coefficients kept in the state dtype + 16 bytes of cursors
-  static __host__ __device__ constexpr int rowx(int D, bool defer, int ss) { return defer ? ((32 + 5 * D * ss + 15) & ~15) : (4 + 5 * D) * 8; }
-  static __host__ __device__ constexpr int rowb(int D, bool defer, int ss) { return rowx(D, defer, ss) + (defer ? 16 : 0); }
+  // ss = sizeof(state scalar).  Deferred emission (2 states): coefficients kept in the state dtype; the four emission cursors of a
+  // trajectory live in their own array (row strides of 112 / 80 bytes spread consecutive rows over the LDS banks; 128-byte rows put
+  // every row on the same banks: measured 30 % of the LDS cycles in bank conflicts)
+  static __host__ __device__ constexpr int rowb(int D, bool defer, int ss) { return defer ? ((32 + 5 * D * ss + 15) & ~15) : (4 + 5 * D) * 8; }
+  static __host__ __device__ constexpr int cur_off(int D, bool defer, int ss) { return 64 * rowb(D, defer, ss); }
+  static __host__ __device__ constexpr int aux_off(int D, bool defer, int ss) { return cur_off(D, defer, ss) + (defer ? 64 * 16 : 0); }
   static __host__ __device__ constexpr int aux_bytes(bool defer, int ss) { return (defer && ss == 8) ? 64 * 48 : 64 * 64; }
-  static __host__ __device__ constexpr int aux_off(int D, bool defer, int ss) { return 64 * rowb(D, defer, ss); }
   static __host__ __device__ constexpr int owp_off(int D, bool defer, int ss) { return aux_off(D, defer, ss) + aux_bytes(defer, ss); }
   static __host__ __device__ constexpr int trl_off(int D, bool defer, int ss) { return owp_off(D, defer, ss) + 256; }
   static __host__ __device__ constexpr int clist_off(int D, bool defer, int ss) { return trl_off(D, defer, ss) + (defer ? 0 : 256); }
   static __host__ __device__ constexpr int bytes(int D, bool defer, int ss) { return clist_off(D, defer, ss) + 1024; }
 };
 static_assert(LwLds::bytes(2, true, 8) <= 12800 && LwLds::bytes(2, true, 4) <= 12800 && LwLds::bytes(2, false, 8) <= 12800, "2-state kernels: 12 wavefronts per compute unit");
+
+#ifndef IONODE_PK_SAMPLES
+#define IONODE_PK_SAMPLES 1
+#endif
 
 // Uniform protocol grid, in two halves so that a caller can issue the two sample loads of several lookups back to back:
 // the sample index (false: t outside the protocol), and the interpolation from the two samples.
@@ -418,7 +424,16 @@ __device__ __forceinline__ bool protocol_v(const KArgs &a, const double *__restr
 }
 
 // nn.LeakyReLU(0.01): x > 0 ? x : 0.01*x  ==  max(x, 0.01*x) for every input (incl. +-0, NaN): 2 VALU ops
-__device__ __forceinline__ float lrelu(float x) { return fmaxf(x, x * 0.01f); }
+// fmaxf() makes hipcc canonicalise its operands first (v_max_f32 x, x, x: one dead vector instruction per MFMA result register -- 1280
+// in the N <= 16 kernel at 64 per wavefront); the v_max_f32 instruction itself returns the same bits for every non-NaN input and quiets
+// NaNs on its own (IEEE mode), so it is issued directly.  The multiply stays hipcc's: it is the first reader of the MFMA result and
+// gets the required wait states; the asm reads its output, so it can only follow it.
+__device__ __forceinline__ float lrelu(float x) {
+  const float t = x * 0.01f;
+  float h;
+  asm("v_max_f32 %0, %1, %2" : "=v"(h) : "v"(x), "v"(t));
+  return h;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Stage MLP of one 16-trajectory tile on the fp32 MFMA.  All G wavefronts of the workgroup call
@@ -943,6 +958,90 @@ struct MlpTile {
   }
 };
 
+// ---------------------------------------------------------------------------------------------
+// N = 10 nets (architectures s03-s05) at one trajectory per lane: the net evaluated PER LANE on the vector ALU, weights as
+// SCALAR operands.  The MFMA form of this path (MlpTile::eval_tiny64) spends 80 MFMAs = 2560 cycles per evaluation on 16 x 16
+// tiles of a 10 x 10 layer, gathers its inputs across lanes and keeps four accumulator tiles; per lane the net is 530 fmaf + 2 x 60
+// LeakyReLU operations = 2.6 k cycles with no cross-lane traffic, and ~25 registers instead of ~110.  Every weight is used by all 64
+// lanes at once, so it is read through the scalar cache (constant address space: s_load_dwordx8/x16) and enters v_fmac_f32 as its
+// one SGPR operand.  Same canonical order as the oracle / the MFMA tile with NT = 1:
+//   hidden row j:  acc = bias; for r = 0..3: for q = 0..3: k = 4 q + r < N: acc = fmaf(W[j][k], h[k], acc)
+//   Linear(N, 1):  part_q = 0; for r: k = 4 q + r < N: part_q = fmaf(wl[k], h[k], part_q); out = ((p0 + p1) + (p2 + p3)) + bl
+// The padded terms the tile executes (k >= N: fmaf(0, 0, acc)) are skipped: they return acc for every acc except -0, and an
+// accumulator can only be -0 if its bias is -0 (x + (-x) rounds to +0; +0 + -0 = +0), which ionode_mlp_pack rules out by writing
+// bias + 0.0f into this section (N < 16; the tile's own trailing padded term does the same to its result).
+// Image section (ionode_mlp_pack, behind wl / bl): L x N rows of RS = 12 floats {W[j][k] in the canonical k order, bias, pad}.
+// ---------------------------------------------------------------------------------------------
+#ifndef IONODE_VNET_GROUP
+#define IONODE_VNET_GROUP 5
+#endif
+template <int N> struct MlpLane {
+  static_assert(N == 10, "the per-lane net is instantiated for N = 10 (architectures s03-s05)");
+  static constexpr int GW = 1;
+  static constexpr int NP = 16;
+  static constexpr int RS = (N + 1 + 3) & ~3;   // floats per row of the scalar section
+  typedef const float __attribute__((address_space(4))) cfloat;   // constant address space: uniform loads are scalar loads
+  const cfloat *img;   // the tile's packed image
+  int L;
+#ifdef IONODE_STAMPS
+  Stamps *sp;
+#endif
+  static __host__ __device__ constexpr size_t lds_bytes(int) { return 0; }
+  static __host__ __device__ constexpr size_t scalar_floats(int L) { return (size_t)L * N * RS; }
+  __device__ __forceinline__ void init(const KArgs &a, unsigned char *, int, int, int first_traj = 0) {
+    L = a.L;
+    const float *g = a.mlp + (a.traj_per_img > 0 ? (size_t)(first_traj / a.traj_per_img) * (size_t)a.mlp_stride : (size_t)0);
+    img = (const cfloat *)(uintptr_t)g;
+  }
+  // canonical position of k in a row's chain: r-major, q-minor over k = 4 q + r < N
+  static __host__ __device__ constexpr int k_at(int pos) {
+    int n = 0;
+    for (int r = 0; r < 4; ++r)
+      for (int q = 0; q < 4; ++q)
+        if (4 * q + r < N) { if (n == pos) return 4 * q + r; ++n; }
+    return -1;
+  }
+  __device__ __forceinline__ float eval_tiny64(float x0, float x1) {
+    float h[N];
+    const cfloat *w0 = img;                       // [NP][4] {b0, w00, w01, 0}
+#pragma unroll
+    for (int j = 0; j < N; ++j) h[j] = lrelu(fmaf(w0[4 * j + 2], x1, fmaf(w0[4 * j + 1], x0, w0[4 * j + 0])));
+    constexpr size_t lstride = (size_t)256 + NP;  // MlpTile<1, 1, 1, 1>::layer_floats(): one fragment + bias[NP]
+    const cfloat *wl = img + 4 * NP + (size_t)L * lstride;   // wl[NP], bl, 3 pad
+    const cfloat *ws = wl + NP + 4;               // the scalar section
+    for (int l = 0; l < L; ++l) {
+      float g[N];
+      // rows in groups of GR: a group's weights (GR x 11 scalars) are in flight together, then consumed; with all ten rows at once the
+      // 110 weights take every SGPR and whatever else is live is spilled into VGPR lanes around each evaluation (v_writelane /
+      // v_readlane bursts: vector instructions again)
+#pragma unroll
+      for (int j0 = 0; j0 < N; j0 += IONODE_VNET_GROUP) {
+#pragma unroll
+        for (int j = j0; j < j0 + IONODE_VNET_GROUP && j < N; ++j) {
+          const cfloat *row = ws + ((size_t)l * N + j) * RS;
+          float acc = row[N];
+#pragma unroll
+          for (int pos = 0; pos < N; ++pos) acc = fmaf(row[pos], h[k_at(pos)], acc);
+          g[j] = lrelu(acc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int j = 0; j < N; ++j) h[j] = g[j];
+    }
+    float part[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      part[q] = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (4 * q + r < N) part[q] = fmaf(wl[4 * q + r], h[4 * q + r], part[q]);
+    }
+    return ((part[0] + part[1]) + (part[2] + part[3])) + wl[NP];
+  }
+  __device__ __forceinline__ float eval(float x0, float x1) { return eval_tiny64(x0, x1); }
+};
+
 // Closed-form models carry an empty stand-in so the integrator code is shared.
 struct NoMlp {
   static constexpr int GW = 1;
@@ -1127,24 +1226,25 @@ template <typename S, int D> __device__ __forceinline__ S rms_norm(const S *x) {
 }
 template <typename S> __device__ __forceinline__ S abs_(S x) { return x < 0 ? -x : x; }
 
-// Closed-form kernels are fp64-issue bound at 64 trajectories per wavefront.  2-state: 3 wavefronts per SIMD (168 VGPRs, 4-12
-// spilled dwords) for launches beyond one residency round, 2 per SIMD (238 VGPRs, no spill) for launches of at most 2048
-// wavefronts (+20 % at 131 072 trajectories; -25 % at 196 608); 4 per SIMD spills 43 dwords and loses.  6-state: ONE wavefront per
-// SIMD (the whole 512-register file): at 2 per SIMD it spilled 48 dwords into scratch inside the stage loop and ran 1.6x
-// (65 536 trajectories) to 2x (16 384) slower; from 131 072 trajectories the two are equal.  MLP tiles: 1 per SIMD.
+// Wavefronts per SIMD asked of hipcc (__launch_bounds__).  2-state closed-form kernels: TWO -- a 256-register budget, of which hipcc
+// uses 147-157 (round 4: constants as scalar operands, lane- and parameter-derived invariants kept out of the attempt loop), so the
+// hardware runs THREE per SIMD (<= 168 registers) without a spill; asked for three, hipcc's scheduler fills the 168 and spills 2-6
+// registers to scratch.  6-state: ONE wavefront per SIMD (the whole register file): at 2 per SIMD it spilled 48 dwords into scratch
+// inside the stage loop and ran 1.6x (65 536 trajectories) to 2x (16 384) slower.  MLP tiles: 1 per SIMD.
 #ifndef IONODE_M6_WAVES
 #define IONODE_M6_WAVES 1
 #endif
 #ifndef IONODE_CF_WAVES
-#define IONODE_CF_WAVES(MODEL, G) ((G) > 1 ? 1 : ((MODEL) == IONODE_MODEL_HH2 ? 3 : IONODE_M6_WAVES))
+#ifndef IONODE_HH2_WAVES
+#define IONODE_HH2_WAVES 2
 #endif
-// Closed-form kernels do not use the NT slot of the template: a non-zero value there is an explicit wavefronts-per-SIMD
-// budget (the 2-state kernel is also instantiated at 2: 238 VGPRs, no spill -- the faster build below ~160 k trajectories)
+#define IONODE_CF_WAVES(MODEL, G) ((G) > 1 ? 1 : ((MODEL) == IONODE_MODEL_HH2 ? IONODE_HH2_WAVES : IONODE_M6_WAVES))
+#endif
 #ifndef IONODE_T64_WAVES
 #define IONODE_T64_WAVES 1
 #endif
 #define IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT) \
-  ((((MODEL) == IONODE_MODEL_HH2 || (MODEL) == IONODE_MODEL_MARKOV6) && (NT) > 0) ? (NT) : (((MODEL) >= IONODE_MODEL_NNF && (RT) == 64) ? IONODE_T64_WAVES : IONODE_CF_WAVES(MODEL, G)))
+  (((MODEL) >= IONODE_MODEL_NNF && (RT) == 64) ? IONODE_T64_WAVES : IONODE_CF_WAVES(MODEL, G))
 
 template <typename S, int D> __device__ __forceinline__ void store_state(S *dst, const S *v) {
   if constexpr (D == 2 && sizeof(S) == 8) {
@@ -1164,8 +1264,25 @@ template <typename S, int D> __device__ __forceinline__ void store_state(S *dst,
 // The integrator.  One workgroup = one tile of TPW trajectories (G wavefronts for MLP models).
 // ---------------------------------------------------------------------------------------------
 template <int MODEL, typename S, int G, int RT, int NT, int PD, int TAIL>
-__global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT)) ionode_dopri5_kernel(const KArgs a) {
+__global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT)) ionode_dopri5_kernel(const KArgs a_in) {
   using MT = ModelTraits<MODEL>;
+  // Per-variant CONTRACTS (ionode_capi.hip make_plan selects a variant only when they hold).  What a variant is never asked to do is
+  // cleared in its private copy of the arguments: the branches fold away at compile time, and with them their code, their registers
+  // and the scalars (pointers, caps) that would otherwise stay live through the attempt loop -- in SGPRs that spill into VGPR lanes.
+  //   TAIL == 1 of a lane-wise kernel (LEAN): uniform protocol grid, VERIFIED uniform output grid, states only (no current trace, no
+  //                fused objective), no step log, no checkpoints
+  //   TAIL == 2 of a closed-form kernel (table variant): uniform protocol grid, no step log, no checkpoints
+#ifndef IONODE_LEAN
+#define IONODE_LEAN 1   // 0: A/B build without the contract folding
+#endif
+  constexpr bool LEAN = IONODE_LEAN && (!MT::MLP || RT == 64) && TAIL == 1;
+  constexpr bool LEANT = IONODE_LEAN && !MT::MLP && TAIL == 2;
+  KArgs a = a_in;
+  if constexpr (LEAN || LEANT) { a.prot_t = nullptr; a.step_log = nullptr; a.step_log_cap = 0; a.ckpt = nullptr; a.ckpt_cap = 0; }
+  if constexpr (LEAN) { a.i_out = nullptr; a.sse_out = nullptr; a.sse_ref = nullptr; a.v_tab = nullptr; a.te_exact = 1; }
+#ifdef IONODE_STAMPS
+  a.step_log = a_in.step_log; a.step_log_cap = a_in.step_log_cap;   // (the diagnostic build reports its stamps through the step log)
+#endif
   using R = Real<S>;
   constexpr int D = MT::D, NPAR = MT::NPAR;
   // trajectories per wavefront: 16 for MLP tiles (MFMA column count); closed-form kernels: 64 (one per lane), or RT
@@ -1198,7 +1315,10 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
   const int traj = a.order ? a.order[slot_c] : slot_c;
   const int traj_raw = valid ? traj : a.B;   // (== 0 only for the lane that owns trajectory 0: the step log)
 
-  using MlpT = MlpTile<G, (T64 ? 1 : (RT > 0 ? RT : 1)), (NT > 0 ? NT : 1), (PD > 0 ? PD : 1), (NSETS > 1 ? 4 : 0)>;
+  // PD slot of a 64-per-wavefront MLP kernel: 1 = the MFMA form (any N <= 16), 10 = the per-lane vector-ALU net for N = 10 (MlpLane)
+  constexpr bool VNET = T64 && PD > 1;
+  using MlpTileT = MlpTile<G, (T64 ? 1 : (RT > 0 ? RT : 1)), (NT > 0 ? NT : 1), ((PD > 0 && !VNET) ? PD : 1), (NSETS > 1 ? 4 : 0)>;
+  using MlpT = typename std::conditional<VNET, MlpLane<(VNET ? PD : 10)>, MlpTileT>::type;
   typename std::conditional<MT::MLP, MlpT, NoMlp>::type mlp;
   if constexpr (MT::MLP) mlp.init(a, smem, wave, lane, (int)blockIdx.x * TPW);
   // lane-wise kernels: interpolant rows + tail buffers; behind the MlpTile region when there is one
@@ -1210,7 +1330,7 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
   if constexpr (MT::MLP) mlp.sp = &stamps_;
 #endif
 
-  double p[NPAR];
+  double p[NPAR];   // (not const: made opaque once per attempt in the lane-wise kernels, below)
 #pragma unroll
   for (int i = 0; i < NPAR; ++i) p[i] = a.params[(size_t)traj * a.n_params + i];
   const int pidx = a.prot_of_traj ? a.prot_of_traj[traj] : (traj % a.P);
@@ -1289,7 +1409,7 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
   constexpr bool defer = CF2 && TAIL == 1;
   constexpr int SS = (int)sizeof(S);
   constexpr int ROWB = LwLds::rowb(D, defer, SS);
-  constexpr int ROWX = LwLds::rowx(D, defer, SS);   // byte offset of the deferred emission's {w, o, end, E} inside a row
+  int4 *const curs = reinterpret_cast<int4 *>(lsm + LwLds::cur_off(D, defer, SS));   // deferred emission: {w, o, end, E} of every lane's trajectory
   // TAIL == 2 of a closed-form kernel: the current / objective epilogue reads V(t_k) from the pre-pass table a.v_tab (selected
   // by the dispatcher when ionode_desc.v_at_outputs is given); a compile-time variant so that neither variant carries the
   // other's code and registers
@@ -1361,12 +1481,12 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
 #define IONODE_BATCH_LOOKUPS_T64 0
 #endif
 #ifndef IONODE_BATCH_LOOKUPS_CF
-#define IONODE_BATCH_LOOKUPS_CF 1   // closed-form kernels of NT slot 0 (6-state at one wavefront per SIMD: -4 .. -10 %; 2-state at three per
-                                    // SIMD since its no-LICM build has the registers: -2 .. -3.4 %; the 2-per-SIMD 2-state builds: not)
+#define IONODE_BATCH_LOOKUPS_CF 1   // closed-form kernels (6-state at one wavefront per SIMD: -4 .. -10 %; 2-state: -2 .. -3.4 %; not the
+                                    // 2-state table variant TAIL == 2: 173 instead of 151 registers = two wavefronts per SIMD instead of three)
 #endif
     // (not for the N <= 16 kernel at 64 per wavefront: 251 -> 272 VGPRs = one wavefront per SIMD, 58 -> 87 ms; the 2-state kernel lost
     // 4 % with it while its build still hoisted constants and spilled)
-    if (((MT::MLP && G > 1) || (IONODE_BATCH_LOOKUPS_CF && !MT::MLP && NT == 0) || (IONODE_BATCH_LOOKUPS_T64 && T64) || IONODE_BATCH_LOOKUPS_ALL) && a.prot_t == nullptr) {
+    if (((MT::MLP && G > 1) || (IONODE_BATCH_LOOKUPS_CF && !MT::MLP && (D > 2 || TAIL != 2)) || (IONODE_BATCH_LOOKUPS_T64 && T64) || IONODE_BATCH_LOOKUPS_ALL) && a.prot_t == nullptr) {
       // uniform protocol grid: five indices, five 16-byte loads back to back, then the interpolations -- ONE memory round
       // trip per attempt (protocol_v() per stage time waited for each pair of samples in turn: 5 dependent round trips,
       // ~7 k cycles of the s00 attempt)
@@ -1399,6 +1519,14 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
   if constexpr (CARRY_V) lookup_stages(t, dt);
 
   for (;;) {
+    if constexpr (LW) {
+      // Lane-wise kernels run at a fixed register budget (2-state: 168 for three wavefronts per SIMD).  Everything DERIVED from the
+      // per-lane parameters that is invariant over the attempts -- fp32 copies and out-of-range rate constants for the fp32-state
+      // rule, negated exponents, protocol row addresses -- would be hoisted out of this loop and stay live through it: ~20 VGPRs for
+      // values the hot path never reads.  An empty asm makes the parameters opaque once per attempt: no instruction, no hoisting.
+#pragma unroll
+      for (int i = 0; i < NPAR; ++i) asm volatile("" : "+v"(p[i]));
+    }
     // ---- per-trajectory assertions of _adaptive_step / _advance ----
     bool failed_now = false;
     if (active) {
@@ -1585,7 +1713,7 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
       }
     }
     STAMP(stamps_, 8);  // slot 8: interpolant fit
-    if (a.te_dt > 0.0) {
+    if (LEAN || a.te_dt > 0.0) {
       // ---- output cursor, lane-parallel: how many requested times fall in (t0, t1] for MY trajectory? ----
       // Guess the last index from the (nearly) uniform output grid, then VERIFY against t_eval itself and walk to the
       // exact answer: correct for any increasing t_eval, one L2 round trip for the whole tile when the guess is right
@@ -1615,15 +1743,29 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
         // wave-uniform per trajectory (interpolant, cursors, trajectory index) from the owner's LDS row.  Steps of more than 8 chunks
         // are emitted by the whole wavefront, 64 consecutive samples per pass.  Same samples, same arithmetic, same sector-aligned
         // stores (a chunk = 8 consecutive samples from an 8-sample-aligned position = 1-2 whole sectors).
-        constexpr int PK = 8, NCH_MAX = 8;
-        static_assert(PK % LS == 0 && 64 % PK == 0, "a chunk is made of whole sectors");
+        // Round 4b: with one sample per lane and pass, every lane re-read its trajectory's 96-128-byte row per sample and the LDS pipe
+        // (128 B / clk / CU, 12 wavefronts) became the bound.  A chunk is now served by PKL = 4 lanes x NSL = 2 samples each (lane kk:
+        // samples kk and kk + 4 of the chunk, so every store instruction still writes whole runs of 4 consecutive samples): half the
+        // LDS bytes and half the per-entry overhead per sample, 16 chunks per pass.  The two samples of a lane are evaluated as a
+        // 2-vector: v_pk_mul_f32 / v_pk_add_f32 for fp32 state (separate multiply and add, as the canonical arithmetic demands).
+#ifndef IONODE_DEFER_PKL
+#define IONODE_DEFER_PKL 4   // lanes per 8-sample chunk (8: one sample per lane)
+#endif
+        constexpr int PK = 8, NCH_MAX = 8, PKL = IONODE_DEFER_PKL, NSL = PK / PKL;
+        static_assert(PK % LS == 0 && 64 % PKL == 0, "a chunk is made of whole sectors");
         using S2 = typename std::conditional<SS == 8, double2, float2>::type;
-        const bool em_lane = n_out > 0 && lane < LPS;
+        typedef S SV __attribute__((ext_vector_type(NSL)));
+        // an opaque per-attempt copy of the lane id: everything derived from it below (row / tail / list addresses, list entries, group and
+        // sample numbers) is then computed here, per attempt, instead of being hoisted out of the attempt loop into a dozen VGPRs that stay
+        // live through the stage loop (the three-per-SIMD builds have 168)
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const bool em_lane = n_out > 0 && lane_e < LPS;
         const unsigned long long emd = __ballot(em_lane);
         if (emd) {
           int nch = 0, E_own = 0;
           if (em_lane) {
-            const int w = owp[lane], endx = oi + n_out;
+            const int w = owp[lane_e], endx = oi + n_out;
             const long long G0 = (long long)traj * Nt;  // global sample index of the row's first sample
             int E = Nt;                                  // samples [w, E) go to HBM now, [E, end) wait in the tail buffer
             if (endx < Nt) {
@@ -1633,8 +1775,8 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
             const int b0 = (int)(((G0 + w) & ~(long long)(PK - 1)) - G0);   // first chunk: the aligned block that holds sample w
             nch = (endx - b0 + PK - 1) / PK;
             E_own = E;
-            *reinterpret_cast<int2 *>(lsm + lane * ROWB + 24) = make_int2(b0, traj);       // the row's spare slot
-            *reinterpret_cast<int4 *>(lsm + lane * ROWB + ROWX) = make_int4(w, oi, endx, E);
+            *reinterpret_cast<int2 *>(lsm + lane_e * ROWB + 24) = make_int2(b0, traj);       // the row's spare slot
+            curs[lane_e] = make_int4(w, oi, endx, E);
           }
           // work list of the short steps: exclusive prefix sum of the chunk counts (1 .. 8) over the lanes, from ballots of the
           // three bit planes of nch - 1 -- no cross-lane data movement
@@ -1646,7 +1788,7 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
           const int C = __builtin_popcountll(ms) + __builtin_popcountll(m0) + 2 * __builtin_popcountll(m1) + 4 * __builtin_popcountll(m2);
 #pragma unroll
           for (int i = 0; i < NCH_MAX; ++i)
-            if (shortl && i < nch) clist[q + i] = (unsigned short)(lane | (i * PK) << 6);
+            if (shortl && i < nch) clist[q + i] = (unsigned short)(lane_e | (i * PK) << 6);
           struct Row { double t0, den, rden; int b0, tr, w, o, end, E; S cb[5][2]; };
           auto load_row = [&](int jj) {
             Row r;
@@ -1659,51 +1801,86 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
             const S2 *cr = reinterpret_cast<const S2 *>(rp + 32);
 #pragma unroll
             for (int c = 0; c < 5; ++c) { const S2 cc = cr[c]; r.cb[c][0] = cc.x; r.cb[c][1] = cc.y; }
-            const int4 cu = *reinterpret_cast<const int4 *>(rp + ROWX);
+            const int4 cu = curs[jj];
             r.w = cu.x; r.o = cu.y; r.end = cu.z; r.E = cu.w;
             return r;
           };
-          auto sample = [&](bool has, int idx, const Row &r, int jj) {
-            if (has && idx >= r.w && idx < r.end) {
-              unsigned char *const tj = tails + jj * TAILB;
-              S out[D];
-              if (idx < r.o) {  // computed by an earlier step: parked in the tail buffer
-                const S *ts = reinterpret_cast<const S *>(tj) + (size_t)(idx - r.w) * D;
-                out[0] = ts[0]; out[1] = ts[1];
-              } else {
-                const S x_ = (S)div_pos(te_at(idx) - r.t0, r.den, r.rden);  // _interp_evaluate: x in fp64, cast; running powers
-                S xp = x_;
+          // NSL samples of one lane: idx0, idx0 + stride, ...
+          auto samples = [&](bool has, int idx0, int stride, const Row &r, int jj) {
+            unsigned char *const tj = tails + jj * TAILB;
+            // Samples computed by an earlier step wait in the tail buffer; samples behind the last sector boundary go INTO it.  Every
+            // tail read of a pass comes before any tail write of the pass (as with one sample per lane): the lane's second sample may be
+            // an old one while another lane's first sample -- of a later chunk of the same trajectory, same pass -- already parks a new one
+            S told[NSL][D];
+            bool isold[NSL];
 #pragma unroll
-                for (int d = 0; d < D; ++d) out[d] = r.cb[0][d] + x_ * r.cb[1][d];
+            for (int u = 0; u < NSL; ++u) {
+              const int idx = idx0 + u * stride;
+              isold[u] = has && idx >= r.w && idx < r.o;
+              told[u][0] = told[u][1] = (S)0;
+              if (isold[u]) {
+                const S *ts = reinterpret_cast<const S *>(tj) + (size_t)(idx - r.w) * D;
+                told[u][0] = ts[0]; told[u][1] = ts[1];
+              }
+            }
+            auto put = [&](int u, int idx, S o0, S o1) {
+              if (has && idx >= r.w && idx < r.end) {
+                S out[D] = {isold[u] ? told[u][0] : o0, isold[u] ? told[u][1] : o1};
+                if (idx < r.E) store_state<S, D>(reinterpret_cast<S *>(a.y_out) + ((size_t)r.tr * Nt + idx) * D, out);
+                else store_state<S, D>(reinterpret_cast<S *>(tj) + (size_t)(idx - r.E) * D, out);
+              }
+            };
+            if constexpr (SS == 4 && IONODE_PK_SAMPLES) {
+              // fp32 state: the lane's NSL samples as one vector -- v_pk_mul_f32 / v_pk_add_f32 (separate multiply and add)
+              SV xv;
+#pragma unroll
+              for (int u = 0; u < NSL; ++u) xv[u] = (S)div_pos(te_at(idx0 + u * stride) - r.t0, r.den, r.rden);  // _interp_evaluate: x in fp64, cast
+              SV ov[D], xp = xv;   // running powers
+#pragma unroll
+              for (int d = 0; d < D; ++d) ov[d] = r.cb[0][d] + xv * r.cb[1][d];
+#pragma unroll
+              for (int c = 2; c < 5; ++c) {
+                xp = xp * xv;
+#pragma unroll
+                for (int d = 0; d < D; ++d) ov[d] = ov[d] + xp * r.cb[c][d];
+              }
+#pragma unroll
+              for (int u = 0; u < NSL; ++u) put(u, idx0 + u * stride, ov[0][u], ov[1][u]);
+            } else {
+              // fp64 state: one sample after the other (no packed fp64 arithmetic; interleaving them only costs registers)
+#pragma unroll
+              for (int u = 0; u < NSL; ++u) {
+                const int idx = idx0 + u * stride;
+                const S x_ = (S)div_pos(te_at(idx) - r.t0, r.den, r.rden);
+                S xp = x_, o0 = r.cb[0][0] + x_ * r.cb[1][0], o1 = r.cb[0][1] + x_ * r.cb[1][1];
 #pragma unroll
                 for (int c = 2; c < 5; ++c) {
                   xp = xp * x_;
-#pragma unroll
-                  for (int d = 0; d < D; ++d) out[d] = out[d] + xp * r.cb[c][d];
+                  o0 = o0 + xp * r.cb[c][0];
+                  o1 = o1 + xp * r.cb[c][1];
                 }
+                put(u, idx, o0, o1);
               }
-              if (idx < r.E) store_state<S, D>(reinterpret_cast<S *>(a.y_out) + ((size_t)r.tr * Nt + idx) * D, out);
-              else store_state<S, D>(reinterpret_cast<S *>(tj) + (size_t)(idx - r.E) * D, out);
             }
           };
-          const int slot = lane / PK, kk = lane % PK;
-          for (int c0 = 0; c0 < C; c0 += 64 / PK) {
+          const int slot = lane_e / PKL, kk = lane_e % PKL;
+          for (int c0 = 0; c0 < C; c0 += 64 / PKL) {
             const bool has = c0 + slot < C;
             const unsigned e = clist[has ? c0 + slot : c0];   // (idle lane groups shadow the pass's first chunk, stores masked)
             const int jj = (int)(e & 63u);
             const Row r = load_row(jj);
-            sample(has, r.b0 + (int)(e >> 6) + kk, r, jj);
+            samples(has, r.b0 + (int)(e >> 6) + kk, PKL, r, jj);
           }
-          // long steps (more than 64 samples): the whole wavefront, 64 consecutive samples per pass, rows at uniform addresses
+          // long steps (more than 64 samples): the whole wavefront, 128 consecutive samples per pass, rows at uniform addresses
           unsigned long long lm = __ballot(em_lane && !shortl);
           while (lm) {
             const int jj = __builtin_ctzll(lm);
             lm &= lm - 1;
             const Row r = load_row(jj);
             const int b0u = __builtin_amdgcn_readfirstlane(r.b0), endu = __builtin_amdgcn_readfirstlane(r.end);
-            for (int b = b0u; b < endu; b += 64) sample(true, b + lane, r, jj);
+            for (int b = b0u; b < endu; b += 64 * NSL) samples(true, b + lane_e, 64, r, jj);
           }
-          if (em_lane) owp[lane] = E_own;
+          if (em_lane) owp[lane_e] = E_own;
         }
         oi += n_out;
       } else if constexpr (!LW && G > 1) {
@@ -1802,54 +1979,68 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
       // one-trajectory-per-pass loop below); V(t_k) and the reference current of the NEXT pass are loaded before this pass's stores.
       bool packed_lane = false;   // my trajectory's samples are emitted by the work-list passes (the others: the loop below)
       if constexpr (LW && (VTAB || D > 2)) {
-        constexpr int PK = 8;
+        // a chunk of PK = 8 samples is served by PKL lanes x NSL samples each (lane kk: samples kk, kk + PKL, ...): one row read per
+        // NSL samples -- with one sample per lane the LDS pipe, not the vector ALU, bounded these passes (the 6-state row is 272 bytes)
+        constexpr int PK = 8, PKL = (D == 2) ? 4 : 2, NSL = PK / PKL;
+        typedef S SV __attribute__((ext_vector_type(NSL)));
         const bool want_i = (a.i_out != nullptr) || (a.sse_out != nullptr);
         // one instance per compiled variant: the table variant (TAIL == 2) serves the current / objective epilogue, the plain one
         // states only (its epilogue without the table -- a protocol lookup per sample -- stays on the loop below)
         // (2-state kernels that also store the states keep the loop below: at ~34 samples per step its 64 consecutive samples per
         // store instruction touch half the cache lines of 8 x 8, and that path is store-bound: 41.5 against 44.7 ms packed)
         if (a.te_exact && (VTAB ? (want_i && (D > 2 || a.y_out == nullptr)) : (!want_i && a.y_out != nullptr))) {
-          packed_lane = n_out > 0 && lane < LPS && n_out <= 64;
+          int lane_e = lane;   // opaque per-attempt copy (see the deferred variant): keeps lane-derived addresses out of the attempt loop's live set
+          asm volatile("" : "+v"(lane_e));
+          packed_lane = n_out > 0 && lane_e < LPS && n_out <= 64;
           const unsigned long long emd = __ballot(packed_lane);
           auto emit_packed = [&](auto wi_tag) {
             constexpr bool WI = decltype(wi_tag)::value;
             const int nch = (n_out + PK - 1) / PK;   // 1 .. 8 for the listed lanes
-            if (packed_lane) *reinterpret_cast<int2 *>(lsm + lane * ROWB + 24) = make_int2(oi, oi + n_out);   // the row's spare slot
+            if (packed_lane) *reinterpret_cast<int2 *>(lsm + lane_e * ROWB + 24) = make_int2(oi, oi + n_out);   // the row's spare slot
             const int x = nch - 1;
             const unsigned long long m0 = __ballot(packed_lane && (x & 1)), m1 = __ballot(packed_lane && (x & 2)), m2 = __ballot(packed_lane && (x & 4));
             const int q = mbcnt(m0, mbcnt(emd)) + 2 * mbcnt(m1) + 4 * mbcnt(m2);
             const int C = __builtin_popcountll(emd) + __builtin_popcountll(m0) + 2 * __builtin_popcountll(m1) + 4 * __builtin_popcountll(m2);
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-              if (packed_lane && i < nch) clist[q + i] = (unsigned short)(lane | (i * PK) << 6);
-            const int slot = lane / PK, kk = lane % PK;
+              if (packed_lane && i < nch) clist[q + i] = (unsigned short)(lane_e | (i * PK) << 6);
+            const int slot = lane_e / PKL, kk = lane_e % PKL;
             // decode of a list entry: trajectory lane, first sample of the lane, and (table variant) the loads of V(t_k) / reference
-            struct Ent { int jj, idx, end, part; bool on; double vk, rf; };
+            struct Ent { int jj, idx0, end, part; bool has; double vk[NSL], rf[NSL]; };
             auto decode = [&](int c0) {
               Ent t;
-              const bool has = c0 + slot < C;
-              const unsigned e = clist[has ? c0 + slot : (c0 < C ? c0 : 0)];
+              t.has = c0 + slot < C;
+              const unsigned e = clist[t.has ? c0 + slot : (c0 < C ? c0 : 0)];
               t.jj = (int)(e & 63u);
               t.part = (int)(e >> 9);   // chunk number: the objective's partial-sum slot
               const int2 on2 = *reinterpret_cast<const int2 *>(lsm + t.jj * ROWB + 24);
-              t.idx = on2.x + (int)(e >> 6) + kk;
+              t.idx0 = on2.x + (int)(e >> 6) + kk;
               t.end = on2.y;
-              t.on = has && t.idx < t.end;
-              t.vk = 0.0; t.rf = 0.0;
+#pragma unroll
+              for (int u = 0; u < NSL; ++u) { t.vk[u] = 0.0; t.rf[u] = 0.0; }
               if constexpr (VTAB && WI) {
-                if (t.on) {
-                  const int pj = owp[t.jj];
-                  t.vk = a.v_tab[(size_t)pj * Nt + t.idx];
-                  if (a.sse_out) t.rf = a.sse_ref[(size_t)pj * Nt + t.idx];
+                const int pj = owp[t.jj];
+#pragma unroll
+                for (int u = 0; u < NSL; ++u) {
+                  const int idx = t.idx0 + u * PKL;
+                  if (t.has && idx < t.end) {
+                    t.vk[u] = a.v_tab[(size_t)pj * Nt + idx];
+                    if (a.sse_out) t.rf[u] = a.sse_ref[(size_t)pj * Nt + idx];
+                  }
                 }
               }
               return t;
             };
-            Ent nx = decode(0);
-            for (int c0 = 0; c0 < C; c0 += 64 / PK) {
-              const Ent cur = nx;
-              if (c0 + 64 / PK < C) nx = decode(c0 + 64 / PK);
-              const int jj = cur.jj, idx = cur.idx;
+            // 6-state kernels (one wavefront per SIMD, registers to spare): the next pass's entry and table loads are issued before this
+            // pass is evaluated.  2-state kernels (three per SIMD, 168 registers): no cross-pass prefetch -- two live entries cost
+            // 14-28 spilled registers, and the fused objective stores nothing its loads could queue behind
+            constexpr bool PREF = (D > 2);
+            Ent nx{};
+            if constexpr (PREF) nx = decode(0);
+            for (int c0 = 0; c0 < C; c0 += 64 / PKL) {
+              const Ent cur = PREF ? nx : decode(c0);
+              if constexpr (PREF) { if (c0 + 64 / PKL < C) nx = decode(c0 + 64 / PKL); }
+              const int jj = cur.jj;
               const double2 *rj = reinterpret_cast<const double2 *>(lsm + jj * ROWB);
               const double2 h0 = rj[0];
               const double t0b = h0.x, denb = h0.y, rdenb = rj[1].x;
@@ -1862,36 +2053,59 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
                   cb[c][d] = (S)cc.x; cb[c][d + 1] = (S)cc.y;
                 }
               const int tr = trl[jj];
-              double rr2 = 0.0;
-              if (cur.on) {
-                const double tk = te_at(idx);
-                const S x_ = (S)div_pos(tk - t0b, denb, rdenb);  // _interp_evaluate: x in fp64, cast; running powers
-                S out[D];
-                S xp = x_;
+              double tk[NSL];
+              SV xv;
 #pragma unroll
-                for (int d = 0; d < D; ++d) out[d] = cb[0][d] + x_ * cb[1][d];
+              for (int u = 0; u < NSL; ++u) {
+                tk[u] = te_at(cur.idx0 + u * PKL);
+                xv[u] = (S)div_pos(tk[u] - t0b, denb, rdenb);  // _interp_evaluate: x in fp64, cast; running powers
+              }
+              SV ov[D], xp = xv;
 #pragma unroll
-                for (int c = 2; c < 5; ++c) {
-                  xp = xp * x_;
+              for (int d = 0; d < D; ++d) ov[d] = cb[0][d] + xv * cb[1][d];
 #pragma unroll
-                  for (int d = 0; d < D; ++d) out[d] = out[d] + xp * cb[c][d];
-                }
-                if (!WI || a.y_out) store_state<S, D>(reinterpret_cast<S *>(a.y_out) + ((size_t)tr * Nt + idx) * D, out);
-                if constexpr (WI) {
-                  double vk;
-                  if constexpr (VTAB) vk = cur.vk;  // == protocol_v(a, pvb, t_eval[idx]), evaluated once per protocol by the pre-pass
-                  else protocol_v(a, a.prot_v + (size_t)owp[jj] * a.Np, tk, vk);
-                  S gate;
-                  if (a.obs_open) gate = out[D - 1]; else gate = out[0] * out[1];
-                  if (a.obs_g != 1.0) gate = (S)a.obs_g * gate;
-                  const double ik = (double)gate * (vk - a.obs_e);
-                  if (a.i_out) a.i_out[(size_t)tr * Nt + idx] = ik;
-                  if (a.sse_out) { const double rr = ik - (VTAB ? cur.rf : a.sse_ref[(size_t)owp[jj] * Nt + idx]); rr2 = rr * rr; }
+              for (int c = 2; c < 5; ++c) {
+                xp = xp * xv;
+#pragma unroll
+                for (int d = 0; d < D; ++d) ov[d] = ov[d] + xp * cb[c][d];
+              }
+              double rr2[NSL];
+#pragma unroll
+              for (int u = 0; u < NSL; ++u) {
+                const int idx = cur.idx0 + u * PKL;
+                rr2[u] = 0.0;
+                if (cur.has && idx < cur.end) {
+                  S out[D];
+#pragma unroll
+                  for (int d = 0; d < D; ++d) out[d] = ov[d][u];
+                  if (!WI || a.y_out) store_state<S, D>(reinterpret_cast<S *>(a.y_out) + ((size_t)tr * Nt + idx) * D, out);
+                  if constexpr (WI) {
+                    double vk;
+                    if constexpr (VTAB) vk = cur.vk[u];  // == protocol_v(a, pvb, t_eval[idx]), evaluated once per protocol by the pre-pass
+                    else protocol_v(a, a.prot_v + (size_t)owp[jj] * a.Np, tk[u], vk);
+                    S gate;
+                    if (a.obs_open) gate = out[D - 1]; else gate = out[0] * out[1];
+                    if (a.obs_g != 1.0) gate = (S)a.obs_g * gate;
+                    const double ik = (double)gate * (vk - a.obs_e);
+                    if (a.i_out) a.i_out[(size_t)tr * Nt + idx] = ik;
+                    if (a.sse_out) { const double rr = ik - (VTAB ? cur.rf[u] : a.sse_ref[(size_t)owp[jj] * Nt + idx]); rr2[u] = rr * rr; }
+                  }
                 }
               }
               if (WI && a.sse_out) {
-                const double g8 = group8_sum_f64(rr2);
-                if (kk == 0 && c0 + slot < C) ssep[jj * 8 + cur.part] += g8;
+                // the chunk's sum in the canonical tree ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)) over its 8 consecutive samples
+                double g8;
+                if constexpr (PKL == 4) {
+                  double ql = rr2[0] + dpp_f64<0xB1, 0xf>(rr2[0]), qh = rr2[1] + dpp_f64<0xB1, 0xf>(rr2[1]);   // quad_perm [1,0,3,2]
+                  ql = ql + dpp_f64<0x4E, 0xf>(ql); qh = qh + dpp_f64<0x4E, 0xf>(qh);                           // quad_perm [2,3,0,1]
+                  g8 = ql + qh;
+                } else {
+                  double sj[NSL];
+#pragma unroll
+                  for (int u = 0; u < NSL; ++u) sj[u] = rr2[u] + dpp_f64<0xB1, 0xf>(rr2[u]);
+                  g8 = (sj[0] + sj[1]) + (sj[2] + sj[3]);
+                }
+                if (kk == 0 && cur.has) ssep[jj * 8 + cur.part] += g8;
               }
             }
           };

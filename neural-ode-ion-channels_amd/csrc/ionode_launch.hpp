@@ -36,13 +36,14 @@ hipError_t launch(const KArgs &a, unsigned grid, size_t lds, hipStream_t s) {
   IONODE_VARIANT(MODEL, S, F32, 1, 1, 1, 1, 0), IONODE_VARIANT(MODEL, S, F32, 4, 4, 7, 7, 0),        \
       /* N <= 16 at 64 trajectories per wavefront (RT slot 64), plain and with the deferred aligned emission (TAIL 1) */ \
       IONODE_VARIANT(MODEL, S, F32, 1, 64, 1, 1, 0), IONODE_VARIANT(MODEL, S, F32, 1, 64, 1, 1, 1),      \
+      /* ... and N = 10 with the net evaluated per lane on the vector ALU (PD slot 10: MlpLane) */      \
+      IONODE_VARIANT(MODEL, S, F32, 1, 64, 1, 10, 0), IONODE_VARIANT(MODEL, S, F32, 1, 64, 1, 10, 1),    \
       IONODE_VARIANT(MODEL, S, F32, 4, 4, 13, 13, 0), IONODE_VARIANT(MODEL, S, F32, 4, 8, 32, 4, 0),     \
       /* N = 200 with two column sets per tile (TAIL slot 4: 32 trajectories per workgroup), launches of >= 512 such tiles' worth */ \
       IONODE_VARIANT(MODEL, S, F32, 4, 4, 13, 13, 4)
 
 // one table per translation unit (they compile in parallel)
 const Variant *variants_closed(int *n);
-const Variant *variants_closed3(int *n);
 const Variant *variants_nnf_f64(int *n);
 const Variant *variants_nnf_f32(int *n);
 const Variant *variants_nnd_f64(int *n);

@@ -296,7 +296,7 @@ def test_tiny_net_kernel_chosen_for_large_batches(ion, gpu, oracle):
     te = np.arange(0, 2001, 5) * 1.0
     sol = ion.solve(K.MODEL_NNF, params, pv, torch.tensor([K.NN_Y0], dtype=torch.float64), te, weights=w, mlp_layers=L, mlp_width=N,
                     prot_t0=0.0, prot_dt=1.0, prot_of_traj=pot)
-    assert ", 1, 64, 1, 1, 1>" in sol.kernel and bool((sol.status == 0).all())
+    assert ", 1, 64, 1, 10, 1>" in sol.kernel and bool((sol.status == 0).all())   # N = 10: the per-lane net, lean variant
     pick = rng.choice(B // 2, 24, replace=False)
     o = oracle.solve(K.MODEL_NNF, params[pick], pv, K.NN_Y0, te, weights=w, mlp_layers=L, mlp_width=N, prot_t0=0.0, prot_dt=1.0,
                      prot_of_traj=pot[pick], nthreads=8)

@@ -200,6 +200,14 @@ def test_bench_gpus_2_self_launches_two_ranks(ion, gpu):
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 128 and res["config"]["trajectories_ok"] == 64
     assert res["scaling"] == "weak" and res["value"] > 0
+    # round 4: a multi-rank line explains itself -- every rank's wall / kernel time, the collective's own cost, and the configs[3]
+    # objective over the ranks with equal-count and cost-balanced candidate shards
+    cfg = res["config"]
+    assert len(cfg["per_rank_ms"]) == 2 and len(cfg["per_rank_kernel_ms"]) == 2 and cfg["allreduce_16B_us"] > 0
+    so = cfg["objective_sharded"]
+    assert "error" not in so, so
+    for k in ("equal_count", "equal_cost"):
+        assert len(so[k]["per_rank_ms"]) == 2 and so[k]["finite"] > 0 and so[k]["max_over_mean"] >= 1.0
 
 
 def test_max_step_extension_matches_the_oracle_and_is_off_by_default(ion, gpu, oracle):
@@ -365,7 +373,8 @@ def test_protocol_at_outputs_table(ion, gpu, oracle, explicit_grid):
 @pytest.mark.parametrize("L,N,f32", [(5, 10, False), (1, 10, True), (10, 10, False), (3, 16, True)])
 def test_tiny_nets_at_64_trajectories_per_wavefront(ion, gpu, oracle, model, L, N, f32):
     """N <= 16 (architectures s03-s05): the kernel variant with one trajectory per lane (tile_waves = 64; chosen by itself
-    for large batches) -- four MFMA column tiles per evaluation, inputs gathered with ds_bpermute -- returns the bits of
+    for large batches) -- N = 10: the net per lane on the vector ALU with scalar-operand weights; otherwise four MFMA column tiles per
+    evaluation, inputs gathered with ds_bpermute -- returns the bits of
     the 16-per-wavefront kernel and of the oracle: ragged batch, per-trajectory protocols, one failing trajectory, fused current."""
     rng = np.random.default_rng(7 * L + N)
     B = 150
@@ -396,9 +405,11 @@ def test_tiny_nets_at_64_trajectories_per_wavefront(ion, gpu, oracle, model, L, 
     assert np.allclose(sse[64][ok], want[ok], rtol=1e-12, atol=0) and np.allclose(sse[1][ok], want[ok], rtol=1e-12, atol=0)
     d = ion.capi.make_desc(model=model, state_f32=int(f32), n_state=2, n_out=te.size, n_traj=B, n_prot=3, prot_n=pv.shape[1],
                            mlp_layers=L, mlp_width=N, n_params=8, prot_dt=1.0, rtol=1e-7, atol=1e-9, tile_waves=64)
-    assert ion.capi.launch_geometry(d)["grid"] == 3 and ", 1, 64, 1, 1, " in ion.capi.kernel_name(d)
+    # N = 10: the per-lane vector-ALU net (PD slot 10, round 4); other N <= 16: four MFMA column tiles per evaluation (PD slot 1)
+    form = ", 1, 64, 1, %d, " % (10 if N == 10 else 1)
+    assert ion.capi.launch_geometry(d)["grid"] == 3 and form in ion.capi.kernel_name(d)
     d.tile_waves, d.n_traj = 0, 160000
-    assert ion.capi.launch_geometry(d)["grid"] == 2500 and ", 1, 64, 1, 1, " in ion.capi.kernel_name(d)     # chosen by itself
+    assert ion.capi.launch_geometry(d)["grid"] == 2500 and form in ion.capi.kernel_name(d)     # chosen by itself
     d.n_traj = 30000
     assert ion.capi.launch_geometry(d)["grid"] == 1875 and ", 1, 1, 1, 1, 0>" in ion.capi.kernel_name(d)
 

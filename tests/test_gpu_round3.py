@@ -351,6 +351,9 @@ def test_rccl_path_runs_under_the_drivers_launcher_with_one_rank(ion, gpu):
     res = json.loads(lines[0])
     assert res["config"]["dist_backend"] == "nccl" and res["config"]["dist_world_size"] == 1
     assert res["n_gpus"] == 1 and res["config"]["trajectories_ok"] == 64 and res["value"] > 0
+    # the self-explaining multi-rank fields ride on this line too (all-gather + 16-byte all-reduce through RCCL, sharded objective leg)
+    assert len(res["config"]["per_rank_ms"]) == 1 and res["config"]["allreduce_16B_us"] > 0
+    assert "error" not in res["config"]["objective_sharded"], res["config"]["objective_sharded"]
 
 
 @pytest.mark.parametrize("model_name", ["s1", "d2"])

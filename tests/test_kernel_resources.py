@@ -26,3 +26,43 @@ def test_no_kernel_uses_scratch():
     for r in rows:
         if "ionode_dopri5_kernel<" in r["kernel"] and ", 4, 4, 13, 13, " in r["kernel"]:
             assert r["vgpr"] <= 512 and 92 <= r["agpr"] <= 256 and r["scratch_bytes"] == 0, r   # vgpr = unified VGPR + AGPR count
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf") or shutil.which("c++filt") is None, reason="llvm tools")
+def test_two_state_kernels_fit_three_wavefronts_per_simd():
+    """The 2-state closed-form kernels are vector-issue bound and need three resident wavefronts per SIMD: 512 / 3 -> 168 registers
+    (allocation granule 8).  They are compiled with a two-per-SIMD launch bound (hipcc then needs ~150); this guards the budget."""
+    ion = importlib.import_module("neural-ode-ion-channels_amd")
+    from kernel_resources import kernel_resources
+    rows = [r for r in kernel_resources(ion.capi.LIB_PATH) if "ionode_dopri5_kernel<0, " in r["kernel"]]
+    assert len(rows) == 12, [r["kernel"] for r in rows]   # {fp64, fp32} x {64, 16 per wavefront} x {plain, deferred, table}
+    for r in rows:
+        assert r["vgpr"] <= 168 and r["vgpr_spill"] == 0 and r["scratch_bytes"] == 0, r
+
+
+# Static instruction budgets of the attempt loops (tools/asm_stats.py: the unit compiled to assembly with the Makefile's flags).
+# SGPR-spill lane traffic (v_readlane / v_writelane) and constant materialisation (v_mov of a literal) are VALU instructions on the pipe
+# that bounds these kernels; round 3's review found 132 + 44 lane operations and 498 constant moves in the 2-state attempt loop, 626
+# v_readlane in the s00 kernel's.  The budgets are the round-4 figures plus ~10 %: a change that lets the traffic creep back fails here.
+_BUDGETS = {
+    # unit, kernel substring: (max v_readlane + v_writelane, max literal v_mov_b32 + v_mov_b64, max canonicalising v_max x, x, x)
+    ("inst_closed", "<0, double, 1, 0, 0, 0, 1>"): (190, 230, 0),
+    ("inst_closed", "<1, double, 1, 0, 0, 0, 0>"): (310, 170, 0),
+}
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("c++filt") is None, reason="hipcc")
+@pytest.mark.parametrize("unit", sorted({u for u, _ in _BUDGETS}))
+def test_attempt_loop_instruction_budgets(unit):
+    from asm_stats import compile_asm, kernel_stats
+    st = kernel_stats(compile_asm(unit))
+    for (u, key), (lane_ops, const_movs, max_self) in _BUDGETS.items():
+        if u != unit:
+            continue
+        k = [v for n, v in st.items() if key in n]
+        assert len(k) == 1, (key, list(st))
+        a = k[0]["attempt_loop"]
+        assert a["valu"] > 1000, a   # the attempt loop was found
+        assert a["readlane"] + a["writelane"] <= lane_ops, (key, a)
+        assert a["mov_const32"] + a["mov_const64"] <= const_movs, (key, a)
+        assert a["max_self"] <= max_self, (key, a)

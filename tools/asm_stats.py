@@ -98,12 +98,15 @@ def kernel_stats(asm):
         i1 = next((i for i in range(i0, len(lines)) if lines[i].startswith(".Lfunc_end")), len(lines))
         body = lines[i0 + 1:i1]
         # instruction list with positions; labels; loop headers
-        instrs, labels, headers = [], {}, {}
+        instrs, labels, headers, block_notes = [], {}, {}, []
         for k, l in enumerate(body):
             s = l.strip()
             m = re.match(r"^(\.LBB\d+_\d+):", s)
             if m:
                 labels[m.group(1)] = len(instrs)
+                hm = re.search(r"(?:Header=|Parent Loop )(BB\d+_\d+)", s)
+                if hm:
+                    block_notes.append((hm.group(1), len(instrs)))
                 dm = re.search(r"Depth=(\d+)", s)
                 if "Loop Header" in s and dm:
                     headers[m.group(1)] = int(dm.group(1))
@@ -112,6 +115,9 @@ def kernel_stats(asm):
                 continue
             if not s or s.startswith((";", ".", "//")):
                 # a header comment can sit on a continuation line:  "; =>  This Inner Loop Header: Depth=2"
+                hm = re.search(r"Parent Loop (BB\d+_\d+)", s)
+                if hm:
+                    block_notes.append((hm.group(1), len(instrs)))
                 dm = re.search(r"This (?:Inner )?Loop Header: Depth=(\d+)", s)
                 if dm and labels:
                     last = max(labels, key=lambda q: labels[q])
@@ -119,12 +125,22 @@ def kernel_stats(asm):
                         headers[last] = int(dm.group(1))
                 continue
             instrs.append(s.split(";")[0].strip())
-        # loop extent: header position .. last branch back to the header
+        # loop extent: header position .. end of the last block hipcc annotates with "in Loop: Header=<label>" (a back edge can be a
+        # long-branch trampoline, so the branch target alone is not reliable); nested loops' blocks name their own header and their
+        # parent chain, so the outermost loop also claims every "Parent Loop <label>" block
         loops = []
         for lab, depth in headers.items():
             a = labels[lab]
-            b = max((k for k, ins in enumerate(instrs) if k >= a and re.search(r"(?<![\w.])%s(?!\d)" % re.escape(lab), ins) and ins.startswith(("s_cbranch", "s_branch"))), default=a)
-            loops.append((lab, depth, a, b))
+            bare = lab.lstrip(".L")
+            last = a
+            for lab2, pos in block_notes:
+                if pos >= a and bare == lab2:
+                    last = max(last, pos)
+            # extend to the end of that block: the next label position after `last`
+            nxt = sorted(v for v in labels.values() if v > last)
+            b = (nxt[0] - 1) if nxt else len(instrs) - 1
+            bb = max((k for k, ins in enumerate(instrs) if k >= a and re.search(r"(?<![\w.])%s(?!\d)" % re.escape(lab), ins) and ins.startswith(("s_cbranch", "s_branch"))), default=a)
+            loops.append((lab, depth, a, max(b, bb)))
         tot = {k: 0 for k in KEYS}
         for ins in instrs:
             classify(ins, tot)
