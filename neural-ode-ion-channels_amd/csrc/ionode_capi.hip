@@ -10,6 +10,9 @@
 #ifndef IONODE_TILE32_FROM
 #define IONODE_TILE32_FROM 8192  // N = 200: two 16-trajectory tiles per compute unit
 #endif
+#ifndef IONODE_TILE4_UPTO
+#define IONODE_TILE4_UPTO 1536  // N = 200: up to this many trajectories, 4 per tile (one tile per compute unit up to 1024; 16-tiles would use <= 96 of 256 CUs)
+#endif
 #ifndef IONODE_TINY64_MFMA
 #define IONODE_TINY64_MFMA 0   // 1: N = 10 keeps the MFMA form at 64 trajectories per wavefront (A/B)
 #endif
@@ -31,7 +34,36 @@ struct Plan {
   unsigned grid = 0;
   unsigned block = 0;
   size_t lds = 0;
+  size_t lw_bytes = 0;   // lane-wise kernels: LDS bytes of one wavefront's region (the workgroup reserves four)
 };
+
+
+// Lane-wise kernels: four one-wavefront tiles per workgroup (ionode_device.hpp IONODE_LW_TILES_PER_WG), tile t on XCD t % 8.  The
+// workgroup count is a multiple of 8 so that (workgroup, wavefront) -> tile is onto; empty tiles leave at once.
+// EVEN PLACEMENT: the hardware places whole workgroups, and a four-wavefront workgroup occupies one slot on each SIMD of its compute
+// unit -- so the workgroups that fit a CU are the wavefronts per SIMD.  A launch of fewer tiles than the kernel's natural residency
+// reserves more LDS per workgroup (a multiple of the 1280-byte granule), capping the workgroups per CU at ceil(workgroups / CUs):
+// without the cap the dispatcher stacks a small launch three deep on some SIMDs and leaves others idle.
+void plan_lane_wise(Plan *pl, size_t tiles, size_t per_wave_bytes) {
+  const size_t cap = 160 * 1024, gran = 1280, T = IONODE_LW_TILES_PER_WG;
+  pl->lw_bytes = (per_wave_bytes + 15) & ~(size_t)15;
+  pl->grid = (unsigned)(8 * ((tiles + 8 * T - 1) / (8 * T)));
+  pl->block = (unsigned)(64 * T);
+  size_t lds = T * pl->lw_bytes;
+#ifndef IONODE_EVEN_PLACEMENT
+#define IONODE_EVEN_PLACEMENT 1
+#endif
+  if (IONODE_EVEN_PLACEMENT) {
+    const size_t ncu = 256;   // MI355X
+    const size_t per_cu = (pl->grid + ncu - 1) / ncu;
+    const size_t natural = cap / (((lds + gran - 1) / gran) * gran);
+    if (per_cu >= 1 && per_cu < natural) {
+      const size_t pad = (cap / per_cu) / gran * gran;
+      if (pad > lds) lds = pad;
+    }
+  }
+  pl->lds = lds;
+}
 
 // Closed-form kernels are registered with NT == 0 and RT = trajectories per wavefront (0 -> 64); rt < 0: any RT.
 const ionode::Variant *find_variant(int model, int f32, int G, int NT, int rt = -1, int tail = 0, int pd = -1) {
@@ -80,16 +112,13 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false, bool ex
     // 6-state model: one wavefront per SIMD (the whole register file) at every batch.
     const int wslot = 0;
     pl->v = find_variant(d->model, f32, 1, wslot, tpw == 64 ? 0 : 16, defer);
-    pl->grid = (unsigned)((d->n_traj + tpw - 1) / tpw);
-    pl->block = 64;
-    // interpolant rows + tail buffers / objective partial sums + cursors + the dense-output work list (ionode_device.hpp LwLds)
-    pl->lds = (size_t)ionode::LwLds::bytes(D, defer == 1, f32 ? 4 : 8);
+    plan_lane_wise(pl, (size_t)((d->n_traj + tpw - 1) / tpw), (size_t)ionode::LwLds::bytes(D, defer == 1 && D == 2, f32 ? 4 : 8));   // (the deferred-emission LAYOUT is the 2-state kernels')
   } else {
     if (d->mlp_width < 1 || d->mlp_layers < 0) { set_err("bad MLP shape"); return IONODE_ERR_ARG; }
     if (d->mlp_width <= 16 && d->mlp_layers > 10) { set_err("N <= 16 kernels keep at most 10 hidden layers resident"); return IONODE_ERR_UNSUPPORTED; }
     const int NP = np_of(d->mlp_width), NT = NP / 16;
-    if (d->tile_waves != 0 && d->tile_waves != 1 && d->tile_waves != 4 && !(d->tile_waves == 64 && NT == 1) && !(d->tile_waves == 8 && NT == 13)) {
-      set_err("tile_waves must be 0, 1 or 4 for MLP models (64: the N <= 16 kernel at 64 trajectories per wavefront; 8: the N = 200 kernel with 32 trajectories per tile)");
+    if (d->tile_waves != 0 && d->tile_waves != 1 && d->tile_waves != 4 && !(d->tile_waves == 64 && NT == 1) && !((d->tile_waves == 8 || d->tile_waves == 2) && NT == 13)) {
+      set_err("tile_waves must be 0, 1 or 4 for MLP models (64: the N <= 16 kernel at 64 trajectories per wavefront; 8 / 2: the N = 200 kernel with 32 / 4 trajectories per tile)");
       return IONODE_ERR_UNSUPPORTED;
     }
     // N <= 16 (architectures s03-s05): from IONODE_TINY64_FROM trajectories on, one trajectory per lane (64 per wavefront, four
@@ -108,20 +137,26 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false, bool ex
                      (d->tile_waves == 8 || (d->tile_waves == 0 && d->n_traj >= IONODE_TILE32_FROM));
     // N = 10 (architectures s03-s05) at one trajectory per lane: the per-lane vector-ALU net (MlpLane), unless IONODE_TINY64_MFMA
     const bool vnet = t64 && d->mlp_width == 10 && !IONODE_TINY64_MFMA;
+    // N = 200, small batches and single calls: 4 trajectories per tile (MlpTile4; tile_waves = 2 forces it, 4 / 8 exclude it)
+    const bool t4 = !t64 && !t32 && NT == 13 && d->mlp_layers >= 1 && (d->traj_per_image <= 0 || d->traj_per_image % 4 == 0) &&
+                    (d->tile_waves == 2 || (d->tile_waves == 0 && d->n_traj <= IONODE_TILE4_UPTO));
+    // N = 200 tiles: the lean variant when its contract holds (ionode_device.hpp LEANM)
+    const bool leanm = !t64 && NT == 13 && d->mlp_layers >= 1 && !explicit_grid && !d->step_log && !d->ckpt && d->t_eval_exact && d->t_eval_dt_hint > 0.0 && d->n_out > 1;
     pl->v = t64 ? find_variant(d->model, f32, 1, NT, 64, t64defer, vnet ? 10 : 1)
-                : find_variant(d->model, f32, (d->tile_waves == 8 ? 4 : d->tile_waves), NT, NT == 1 ? 1 : -1, t32 ? 4 : 0);
+                : find_variant(d->model, f32, ((d->tile_waves == 8 || d->tile_waves == 2) ? 4 : d->tile_waves), NT, NT == 1 ? 1 : -1, (t32 ? 4 : 0) | (leanm ? 8 : 0) | (t4 ? 16 : 0));
     if (!pl->v) {
       set_err("MLP width outside the compiled kernel variants: N must pad to 16, 112, 208 or 512 "
               "(architectures s00-s11: N = 10, 100, 200, 500)");
       return IONODE_ERR_UNSUPPORTED;
     }
-    pl->grid = t64 ? (unsigned)((d->n_traj + 63) / 64) : (t32 ? (unsigned)((d->n_traj + 31) / 32) : (unsigned)((d->n_traj + 15) / 16));
+    pl->grid = t64 ? (unsigned)((d->n_traj + 63) / 64) : (t32 ? (unsigned)((d->n_traj + 31) / 32) : (t4 ? (unsigned)((d->n_traj + 3) / 4) : (unsigned)((d->n_traj + 15) / 16)));
     pl->block = 64u * pl->v->G;
     const int Gv = pl->v->G, Rv = NT - Gv * (NT / Gv);  // remainder row tiles: K-split partial sums in LDS
     pl->lds = ((size_t)2 * (NT + Gv - 1) * 64 + (size_t)2 * Rv * Gv * 64 + NP) * 16 + ((size_t)d->mlp_layers * NP + NP + 4) * 4;
     // the asm tile (N = 200): + scratch slot (+ the input exchange of the two-column-set tile), MlpTile::lds_total
-    if (Gv == 4 && NT == 13) pl->lds = t32 ? ionode::MlpTile<4, 4, 13, 13, 4>::lds_total(d->mlp_layers) : ionode::MlpTile<4, 4, 13, 13, 0>::lds_total(d->mlp_layers);
-    if (t64) pl->lds = (vnet ? (size_t)0 : ((pl->lds + 15) & ~(size_t)15)) + (size_t)ionode::LwLds::bytes(2, t64defer == 1, f32 ? 4 : 8);  // + the lane-wise kernels' region
+    if (t4) pl->lds = ionode::MlpTile4::lds_bytes(d->mlp_layers);
+    else if (Gv == 4 && NT == 13) pl->lds = t32 ? ionode::MlpTile<4, 4, 13, 13, 4>::lds_total(d->mlp_layers) : ionode::MlpTile<4, 4, 13, 13, 0>::lds_total(d->mlp_layers);
+    if (t64) plan_lane_wise(pl, (size_t)((d->n_traj + 63) / 64), (vnet ? (size_t)0 : ((pl->lds + 15) & ~(size_t)15)) + (size_t)ionode::LwLds::bytes(2, t64defer == 1, f32 ? 4 : 8));  // MlpTile region + the lane-wise region
   }
   if (!pl->v) { set_err("no kernel variant compiled for this descriptor"); return IONODE_ERR_UNSUPPORTED; }
   return IONODE_OK;
@@ -170,7 +205,9 @@ size_t ionode_mlp_packed_floats(int32_t L, int32_t N) {
   const size_t NP = (size_t)np_of(N), NT = NP / 16;
   // N <= 16: + the scalar section of the per-lane net (rows of RS floats: weights in the canonical k order, bias, pad)
   const size_t scalar = (NT == 1) ? (size_t)L * (size_t)N * (size_t)((N + 1 + 3) & ~3) : 0;
-  return 4 * NP + (size_t)L * ((size_t)G * frags_per_wave((int)NT, G) * 256 + NP) + NP + 4 + scalar;
+  // N = 200: + the section of the 4-trajectory tile (MlpTile4): its own fragment order and bias float4s
+  const size_t tile4 = (NT == 13) ? (size_t)L * ionode::MlpTile4::layer_floats() : 0;
+  return 4 * NP + (size_t)L * ((size_t)G * frags_per_wave((int)NT, G) * 256 + NP) + NP + 4 + scalar + tile4;
 }
 
 int ionode_mlp_pack(const float *w, int32_t L, int32_t N, float *out) {
@@ -226,6 +263,47 @@ int ionode_mlp_pack(const float *w, int32_t L, int32_t N, float *out) {
   }
   for (int k = 0; k < N; ++k) dst[k] = src[k];
   dst[NP] = src[N];
+  if (NT == 13) {
+    // section of the 4-trajectory tile (ionode_device.hpp MlpTile4): layer | wavefront w | step s (k-tile (s + w) mod 13) | q | lane 4 b + i ->
+    // float4 over r of W[row][16 kt + 4 q + r]; block b = 4 g + u: g < 3 row 16 (w + 4 g) + 4 u + i, g == 3 remainder row 192 + 4 u + i on
+    // the steps that carry chain w (s % 4 == 0, s + w < 13) and -0.0f elsewhere; then per (w, lane) the accumulator start {bias of rows i}
+    float *t4 = dst + NP + 4;
+    const float *lsrc = b0 + N;
+    for (int l = 0; l < L; ++l) {
+      const float *W = lsrc, *b = lsrc + (size_t)N * N;
+      float *lay = t4 + (size_t)l * ionode::MlpTile4::layer_floats();
+      for (int wv = 0; wv < 4; ++wv) {
+        for (int st = 0; st < 13; ++st) {
+          const int kt = (st + wv) % 13;
+          const bool chain = (st % 4 == 0) && (st + wv < 13);
+          for (int q = 0; q < 4; ++q)
+            for (int lane = 0; lane < 64; ++lane) {
+              const int i = lane & 3, bb = lane >> 2, g = bb >> 2, u = bb & 3;
+              float *f = lay + ((((size_t)wv * 13 + st) * 4 + q) * 64 + lane) * 4;
+              for (int r = 0; r < 4; ++r) {
+                const int k = 16 * kt + 4 * q + r;
+                if (g < 3) {
+                  const int row = 16 * (wv + 4 * g) + 4 * u + i;
+                  f[r] = (row < N && k < N) ? W[(size_t)row * N + k] : 0.0f;
+                } else {
+                  const int row = 192 + 4 * u + i;
+                  f[r] = chain ? ((row < N && k < N) ? W[(size_t)row * N + k] : 0.0f) : -0.0f;
+                }
+              }
+            }
+        }
+        float *bias = lay + (size_t)4 * 13 * 4 * 256 + (size_t)wv * 256;
+        for (int lane = 0; lane < 64; ++lane) {
+          const int bb = lane >> 2, g = bb >> 2, u = bb & 3;
+          for (int i = 0; i < 4; ++i) {
+            const int row = (g < 3) ? 16 * (wv + 4 * g) + 4 * u + i : 192 + 4 * u + i;
+            bias[lane * 4 + i] = (row < N && (g < 3 || wv == 0)) ? b[row] : 0.0f;
+          }
+        }
+      }
+      lsrc += (size_t)N * N + N;
+    }
+  }
   if (NT == 1) {
     // scalar section (ionode_device.hpp MlpLane): hidden layer l, row j: W[j][k] for k = 4 q + r < N in the order r-major / q-minor
     // (the order in which the 16 x 16 x 4 MFMA tile accumulates them), then the bias as bias + 0.0f (a -0 bias becomes +0: see MlpLane)
@@ -301,7 +379,7 @@ int ionode_dopri5(const ionode_desc *d, const float *mlp_packed, const double *p
   a.step_log = d->step_log; a.step_log_cap = d->step_log ? d->step_log_cap : 0;
   a.sse_ref = d->sse_ref; a.sse_out = d->sse_out; a.v_tab = d->v_at_outputs;
   if (mlp && d->traj_per_image > 0) {
-    const int tile = (pl.block == 64 && pl.v->RT == 64) ? 64 : (pl.v->tail == 4 && pl.v->G == 4 ? 32 : 16);
+    const int tile = (pl.block == 64 && pl.v->RT == 64) ? 64 : ((pl.v->tail & 4) && pl.v->G == 4 ? 32 : ((pl.v->tail & 16) ? 4 : 16));
     if (d->traj_per_image % tile != 0 || d->mlp_image_stride < (int64_t)ionode_mlp_packed_floats(d->mlp_layers, d->mlp_width)) {
       set_err("traj_per_image must be a multiple of the tile size (16; 64 with tile_waves = 64) and mlp_image_stride at least one packed image");
       return IONODE_ERR_ARG;
@@ -312,6 +390,7 @@ int ionode_dopri5(const ionode_desc *d, const float *mlp_packed, const double *p
     if (a.traj_per_img > 0) { set_err("launch_order cannot be combined with traj_per_image (tiles of an image must stay together)"); return IONODE_ERR_ARG; }
     a.order = d->launch_order;
   }
+  a.lw_bytes = (int32_t)pl.lw_bytes;
   a.te_t0 = d->t_eval_t0_hint; a.te_dt = (d->t_eval_dt_hint > 0.0 && d->n_out > 1) ? d->t_eval_dt_hint : 0.0;
   a.te_rdt = a.te_dt > 0.0 ? 1.0 / a.te_dt : 0.0;
   a.te_exact = (a.te_dt > 0.0 && d->t_eval_exact) ? 1 : 0;

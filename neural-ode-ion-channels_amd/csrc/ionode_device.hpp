@@ -69,6 +69,7 @@ struct KArgs {
                         // kernels' current / objective epilogue then loads V(t_k) instead of re-deriving it per trajectory
   int64_t mlp_stride;   // several weight images (an ensemble / a population of nets): floats between consecutive images ...
   int32_t traj_per_img; // ... and how many consecutive trajectories share one (a multiple of the tile size); 0: one image for all
+  int32_t lw_bytes;     // lane-wise kernels: LDS bytes of ONE wavefront's region (a workgroup carries four of them, see the kernel)
   const int32_t *order; // optional launch order (a permutation of 0..B-1): launch slot s integrates trajectory order[s]; every
                         // input and output stays at the trajectory's own index -- only the tiling / lane assignment changes
 };
@@ -959,6 +960,167 @@ struct MlpTile {
 };
 
 // ---------------------------------------------------------------------------------------------
+// N = 200 at FOUR trajectories per tile: the small-batch / single-call form (round 4).  The reference's own scripts call
+// odeint with ONE trajectory (train-s1.py:319-330, 32 sequential solves at :566-580), and BASELINE configs[4]'s per-GPU share is 1024
+// trajectories: at 16 per tile those occupy 64 of 256 compute units and every RHS evaluation still costs a full 16-column MFMA
+// pass (36.6 k cycles).  Here a tile is 4 trajectories (256 tiles for 1024 trajectories: the whole chip) and a hidden layer is
+// 13 x 16 v_mfma_f32_4x4x1_16B_f32 per wavefront: 16 blocks of (4 rows) x (4 trajectories) x (1 k) -- each block an exact fmaf
+// per element, so a block's accumulator runs the SAME chain as a row of the 16-column tile when it is fed the same k sequence.
+//   lane = 4 b + i supplies A = W[row(b, i)][k];  lane = 4 b + j supplies B = h[k][trajectory j];  D[i][j] = VGPR i of lane 4 b + j
+//   wavefront w, block b = 4 g + u:  g < 3: full row tile w + 4 g, rows 16 (w + 4 g) + 4 u + i -- all three tiles have rt % 4 == w, so
+//                                    the whole wavefront walks the k-tiles in ONE rotated order kt = (s + w) mod 13, s = 0 .. 12;
+//                                    g == 3: remainder tile 12, rows 192 + 4 u + i, partial chain w (k-tiles kt % 4 == w, ascending):
+//                                    exactly the steps s % 4 == 0 with s + w < 13 of that same walk; on the other steps its A operand
+//                                    is -0.0f (x + (-0 * h) == x for every x as long as h is finite and the chain is not at -0)
+//   within a k-tile:  for r: for q: k = 16 kt + 4 q + r      (the canonical order; one MFMA per (r, q))
+// so results are bit-identical to MlpTile<4, 4, 13, 13> and to the oracle.  Activations live in LDS as [k / 4][trajectory] float4
+// (a lane reads the 4 x float4 of a k-tile for ITS trajectory; an output block IS one such float4); the remainder tile's four partial
+// sums meet in LDS and every lane folds them itself ((p0 + p1) + (p2 + p3), LeakyReLU) when the walk reaches k-tile 12.
+// Weights stream from L2 as in the 16-column tile (SRSRC buffer loads into a register ring one layer ahead: 13 steps x 4 float4),
+// in their own image section (ionode_mlp_pack): layer | wavefront | step | q | lane -> float4 over r, then the layer's bias float4s.
+// ---------------------------------------------------------------------------------------------
+struct MlpTile4 {
+  static constexpr int GW = 4, NT = 13, NP = 208, KQ = NP / 4;
+  static constexpr int ACT = KQ * 4;                 // float4 per activation buffer: [kq][trajectory]
+  static constexpr size_t layer_floats() { return (size_t)4 * NT * 4 * 256 + (size_t)4 * 256; }   // fragments + bias float4 per (wave, lane)
+  static __host__ __device__ constexpr size_t lds_bytes(int L) {
+    return ((size_t)2 * ACT + (size_t)2 * 4 * 16 + NP) * 16 + ((size_t)NP + 4) * 4;   // activations x2, partial sums x2, W0 rows, wl + bl
+  }
+  f32x4 ring[NT][4];
+  f32x4 *Hs, *Ps;
+  const f32x4 *W0s;
+  const float *wlS;
+  __amdgpu_buffer_rsrc_t rsrc;
+  unsigned voff, sec0, lbytes;
+  int L, wave, lane;
+#ifdef IONODE_STAMPS
+  Stamps *sp;
+#endif
+  // offset (floats) of the T4 section inside the packed image of (L, N = 200): behind the 16-column image
+  static __host__ __device__ constexpr size_t section_off(int L) {
+    return 4 * (size_t)NP + (size_t)L * ((size_t)4 * 43 * 256 + NP) + NP + 4;   // MlpTile<4, 4, 13, 13>: FRAGS = 13 * 3 + 4 = 43 per wavefront
+  }
+  __device__ __forceinline__ f32x4 frag(unsigned lbase, int n) const {
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, lbase + (unsigned)n * 1024u, 0);
+    return __builtin_bit_cast(f32x4, v);
+  }
+  // accumulator start of this lane's block: {bias of row 0..3} (0 for the remainder chains w > 0), behind the layer's fragments
+  __device__ __forceinline__ f32x4 bias4(unsigned lbase) const {
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)(lane * 16), lbase + (unsigned)(4 * NT * 4 * 1024 + wave * 1024), 0);
+    return __builtin_bit_cast(f32x4, v);
+  }
+  __device__ __forceinline__ void init(const KArgs &a, unsigned char *smem, int wave_, int lane_, int first_traj = 0) {
+    L = a.L; wave = wave_; lane = lane_;
+    const float *__restrict__ img = a.mlp + (a.traj_per_img > 0 ? (size_t)(first_traj / a.traj_per_img) * (size_t)a.mlp_stride : (size_t)0);
+    Hs = reinterpret_cast<f32x4 *>(smem);
+    Ps = Hs + 2 * ACT;
+    f32x4 *w0 = Ps + 2 * 4 * 16;
+    float *ws = reinterpret_cast<float *>(w0 + NP);
+    const int tid = wave * 64 + lane;
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(img);
+    for (int i = tid; i < NP; i += 256) w0[i] = src[i];
+    const float *wl = img + 4 * (size_t)NP + (size_t)L * ((size_t)4 * 43 * 256 + NP);
+    for (int i = tid; i < NP + 4; i += 256) ws[i] = wl[i];
+    W0s = w0; wlS = ws;
+    const size_t sec = section_off(L);
+    const size_t img_bytes = (sec + (size_t)L * layer_floats()) * 4;
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(img), 0, (int)img_bytes, 0x00020000);
+    sec0 = (unsigned)(sec * 4);
+    lbytes = (unsigned)(layer_floats() * 4);
+    voff = (unsigned)(wave * NT * 4 * 1024 + lane * 16);
+#pragma unroll
+    for (int s = 0; s < NT; ++s)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ring[s][q] = (L > 0) ? frag(sec0, s * 4 + q) : f32x4{0, 0, 0, 0};
+    __syncthreads();
+  }
+  // activations of the remainder k-tile (rows 192 .. 207) for this lane's trajectory, k = 192 + 4 q + r: fold of the four partial chains
+  __device__ __forceinline__ f32x4 remainder_h(const f32x4 *__restrict__ Pin, int q, int j) const {
+    const f32x4 p0 = Pin[(0 * 4 + q) * 4 + j], p1 = Pin[(1 * 4 + q) * 4 + j], p2 = Pin[(2 * 4 + q) * 4 + j], p3 = Pin[(3 * 4 + q) * 4 + j];
+    f32x4 h;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h[r] = lrelu((p0[r] + p1[r]) + (p2[r] + p3[r]));
+    return h;
+  }
+  __device__ __forceinline__ float eval(float x0, float x1) {
+    const int j = lane & 3, b = lane >> 2, g = b >> 2, u = b & 3;
+    // layer 0: Linear(2, N) + LeakyReLU; the lane fills output block kq = 16 wave + b of its trajectory
+    {
+      const int kq = 16 * wave + b;
+      if (kq < KQ) {
+        f32x4 h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const f32x4 w = W0s[4 * kq + r];
+          h[r] = lrelu(fmaf(w[2], x1, fmaf(w[1], x0, w[0])));
+        }
+        Hs[kq * 4 + j] = h;
+      }
+    }
+    __syncthreads();
+    for (int l = 0; l < L; ++l) {
+      const f32x4 *__restrict__ Hin = Hs + (l & 1) * ACT;
+      f32x4 *__restrict__ Hout = Hs + ((l + 1) & 1) * ACT;
+      const f32x4 *__restrict__ Pin = Ps + (l & 1) * 64;
+      f32x4 *__restrict__ Pout = Ps + ((l + 1) & 1) * 64;
+      const int ln = (l + 1 < L) ? l + 1 : 0;   // the ring runs cyclically over the hidden stack (see MlpTile)
+      const unsigned lcur = sec0 + (unsigned)l * lbytes, lnext = sec0 + (unsigned)ln * lbytes;
+      // accumulators: D[i][j] = VGPR i: bias of row i of my block (the remainder chain w > 0 starts at 0: the image says so)
+      f32x4 acc = bias4(lcur);
+#pragma unroll
+      for (int s = 0; s < NT; ++s) {
+        const int kt = (s + wave < NT) ? s + wave : s + wave - NT;
+        f32x4 hq[4];
+        if (kt == NT - 1 && l > 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) hq[q] = remainder_h(Pin, q, j);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) hq[q] = Hin[(4 * kt + q) * 4 + j];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(ring[s][q][r], hq[q][r], acc, 0, 0, 0);
+          if (r == 3) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ring[s][q] = frag(lnext, s * 4 + q);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (g < 3) {
+        f32x4 h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = lrelu(acc[r]);
+        Hout[(4 * (wave + 4 * g) + u) * 4 + j] = h;
+      } else {
+        Pout[(wave * 4 + u) * 4 + j] = acc;   // partial chain `wave` of the remainder tile, pre-activation
+      }
+      __syncthreads();
+    }
+    // Linear(N, 1): chain q = b & 3 per lane (k = 16 kt + 4 q + r, kt ascending, r ascending), folded ((p0 + p1) + (p2 + p3)) + bl
+    const f32x4 *__restrict__ Hin = Hs + (L & 1) * ACT;
+    const f32x4 *__restrict__ Pin = Ps + (L & 1) * 64;
+    const int q = b & 3;
+    float part = 0.0f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      const f32x4 w = *reinterpret_cast<const f32x4 *>(wlS + 16 * kt + 4 * q);
+      const f32x4 h = (kt == NT - 1 && L > 0) ? remainder_h(Pin, q, j) : Hin[(4 * kt + q) * 4 + j];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part = fmaf(w[r], h[r], part);
+    }
+    const float pair = part + __shfl_xor(part, 4);    // (p0 + p1) or (p2 + p3): lanes 4 apart hold neighbouring chains
+    const float out = (pair + __shfl_xor(pair, 8)) + wlS[NP];
+    __syncthreads();   // the next evaluation's layer 0 rewrites buffer 0; its partial sums reuse Ps
+    return out;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
 // N = 10 nets (architectures s03-s05) at one trajectory per lane: the net evaluated PER LANE on the vector ALU, weights as
 // SCALAR operands.  The MFMA form of this path (MlpTile::eval_tiny64) spends 80 MFMAs = 2560 cycles per evaluation on 16 x 16
 // tiles of a 10 x 10 layer, gathers its inputs across lanes and keeps four accumulator tiles; per lane the net is 530 fmaf + 2 x 60
@@ -1127,7 +1289,9 @@ __device__ __forceinline__ void rhs(const KArgs &a, const double *p, double v, b
     const S one_m_r = (S)1 - rv;
     // (not for the 64-per-wavefront N <= 16 kernel: two interleaved branch-free exps cost ~30 registers -- it went from 252 to 284
     // VGPRs, i.e. from two wavefronts per SIMD to one, 58 -> 87 ms)
-    auto dexp = [](double x) { if constexpr (MT::MLP && !WIDE) return det_exp_s(x); else return det_exp(x); };
+    // (the 4-trajectory tile keeps a 208-register weight ring: the branchy form with one exp in flight, same bits)
+    constexpr bool TIGHT = std::is_same<MLP, MlpTile4>::value;
+    auto dexp = [](double x) { if constexpr (TIGHT) return det_exp_ldexp(x); else if constexpr (MT::MLP && !WIDE) return det_exp_s(x); else return det_exp(x); };
     const double k3 = p[4] * dexp(p[5] * v);
     const double k4 = p[6] * dexp(-p[7] * v);
     const double drdt = -k3 * (double)rv + k4 * (double)one_m_r;
@@ -1263,8 +1427,15 @@ template <typename S, int D> __device__ __forceinline__ void store_state(S *dst,
 // ---------------------------------------------------------------------------------------------
 // The integrator.  One workgroup = one tile of TPW trajectories (G wavefronts for MLP models).
 // ---------------------------------------------------------------------------------------------
+// Lane-wise kernels (closed-form models, N <= 16 nets at 64 per wavefront): a tile is ONE wavefront, but a workgroup carries FOUR independent
+// tiles (IONODE_LW_TILES_PER_WG), one per SIMD of a compute unit, each with its own LDS region and no barrier between them.  The
+// hardware hands out whole workgroups, so the plan can cap the wavefronts per SIMD of a small launch through the workgroup's LDS
+// reservation (ionode_capi.hip even_placement): single-wavefront workgroups of a launch that does not fill the chip get stacked three
+// deep on some SIMDs while others idle (6-state, 65 536 trajectories: 24.2 ms stacked, 20.0 ms at one per SIMD).
+#define IONODE_LW_TILES_PER_WG 4
+#define IONODE_IS_LW(MODEL, RT) ((MODEL) == IONODE_MODEL_HH2 || (MODEL) == IONODE_MODEL_MARKOV6 || (RT) == 64)
 template <int MODEL, typename S, int G, int RT, int NT, int PD, int TAIL>
-__global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT)) ionode_dopri5_kernel(const KArgs a_in) {
+__global__ void __launch_bounds__(64 * (IONODE_IS_LW(MODEL, RT) ? IONODE_LW_TILES_PER_WG : G), IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT)) ionode_dopri5_kernel(const KArgs a_in) {
   using MT = ModelTraits<MODEL>;
   // Per-variant CONTRACTS (ionode_capi.hip make_plan selects a variant only when they hold).  What a variant is never asked to do is
   // cleared in its private copy of the arguments: the branches fold away at compile time, and with them their code, their registers
@@ -1277,8 +1448,16 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
 #endif
   constexpr bool LEAN = IONODE_LEAN && (!MT::MLP || RT == 64) && TAIL == 1;
   constexpr bool LEANT = IONODE_LEAN && !MT::MLP && TAIL == 2;
+  //   TAIL & 8 of an MLP tile kernel: uniform protocol grid, VERIFIED uniform output grid, no step log, no checkpoints (states,
+  //                current trace and fused objective stay run-time choices)
+  constexpr bool LEANM = IONODE_LEAN && MT::MLP && G > 1 && (TAIL & 8);
+#ifndef IONODE_M6_LEAN_PAD
+#define IONODE_M6_LEAN_PAD 0   // A/B: 1 = the lean 6-state kernels claim AGPRs up to a47, so that only ONE wavefront fits a SIMD
+#endif
+  if constexpr (IONODE_M6_LEAN_PAD && MODEL == IONODE_MODEL_MARKOV6 && LEAN) asm volatile("" ::: "a47");
   KArgs a = a_in;
-  if constexpr (LEAN || LEANT) { a.prot_t = nullptr; a.step_log = nullptr; a.step_log_cap = 0; a.ckpt = nullptr; a.ckpt_cap = 0; }
+  if constexpr (LEANM) a.te_exact = 1;
+  if constexpr (LEAN || LEANT || LEANM) { a.prot_t = nullptr; a.step_log = nullptr; a.step_log_cap = 0; a.ckpt = nullptr; a.ckpt_cap = 0; }
   if constexpr (LEAN) { a.i_out = nullptr; a.sse_out = nullptr; a.sse_ref = nullptr; a.v_tab = nullptr; a.te_exact = 1; }
 #ifdef IONODE_STAMPS
   a.step_log = a_in.step_log; a.step_log_cap = a_in.step_log_cap;   // (the diagnostic build reports its stamps through the step log)
@@ -1296,20 +1475,28 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
   constexpr bool LW = !MT::MLP || T64;
   // MLP tile kernels with TAIL == 4: two 16-trajectory column sets per workgroup (MlpTile::NSETS); wavefronts [0, WPS) integrate
   // set 0, [WPS, 2 WPS) set 1.  LPS = lanes of a wavefront that hold distinct trajectories.
-  constexpr int NSETS = (MT::MLP && G > 1 && TAIL == 4) ? 2 : 1;
+  constexpr int NSETS = (MT::MLP && G > 1 && (TAIL & 4)) ? 2 : 1;   // (TAIL & 8: the tile kernels' lean variant, top of the kernel)
   constexpr int WPS = G / NSETS;
-  constexpr int TPW = MT::MLP ? (T64 ? 64 : 16 * NSETS) : (RT > 0 ? RT : 64);
-  constexpr int LPS = (MT::MLP && !T64) ? 16 : TPW;
+  // TAIL & 16 of an N = 200 tile kernel: FOUR trajectories per tile (MlpTile4: small batches and single calls); lane = 4 b + j holds trajectory j
+  constexpr bool T4 = MT::MLP && G == 4 && NT == 13 && (TAIL & 16);
+  static_assert(!T4 || NSETS == 1, "the 4-trajectory tile has one column set");
+  constexpr int TPW = MT::MLP ? (T64 ? 64 : (T4 ? 4 : 16 * NSETS)) : (RT > 0 ? RT : 64);
+  constexpr int LPS = (MT::MLP && !T64) ? (T4 ? 4 : 16) : TPW;
   static_assert(MT::MLP || G == 1, "closed-form models use one wavefront per tile");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps per-wave tile guards scalar
+  const int wgw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wavefront inside the workgroup (wave-uniform: keeps tile guards scalar)
+  const int wave = LW ? 0 : wgw;                                       // wavefront inside the TILE (lane-wise kernels: a tile is one wavefront)
+  // lane-wise kernels: four tiles per workgroup.  Workgroups go round-robin over the 8 XCDs; tile t keeps landing on XCD t % 8 (the
+  // protocol-major launch order deals the protocols out per XCD on that assumption): workgroup b, wavefront w -> tile (b % 8) + 8 (4 (b / 8) + w)
+  const int tile = LW ? (int)((blockIdx.x & 7u) + 8u * ((blockIdx.x >> 3) * (unsigned)IONODE_LW_TILES_PER_WG + (unsigned)wgw)) : (int)blockIdx.x;
+  unsigned char *const smem_t = LW ? smem + (size_t)wgw * (size_t)a.lw_bytes : smem;
   const int j = lane % LPS;
   const int cset = (NSETS > 1) ? wave / WPS : 0, wis = wave % WPS;  // column set of this wavefront, wavefront index inside the set
   const bool primary = (lane < LPS) && (wis == 0);  // the replica that writes per-trajectory scalars
-  const int slot_raw = blockIdx.x * TPW + cset * LPS + j;   // launch slot; the trajectory it integrates: a.order[slot] (or slot)
+  const int slot_raw = tile * TPW + cset * LPS + j;   // launch slot; the trajectory it integrates: a.order[slot] (or slot)
   const bool valid = slot_raw < a.B;
   const int slot_c = valid ? slot_raw : a.B - 1;
   const int traj = a.order ? a.order[slot_c] : slot_c;
@@ -1318,13 +1505,13 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
   // PD slot of a 64-per-wavefront MLP kernel: 1 = the MFMA form (any N <= 16), 10 = the per-lane vector-ALU net for N = 10 (MlpLane)
   constexpr bool VNET = T64 && PD > 1;
   using MlpTileT = MlpTile<G, (T64 ? 1 : (RT > 0 ? RT : 1)), (NT > 0 ? NT : 1), ((PD > 0 && !VNET) ? PD : 1), (NSETS > 1 ? 4 : 0)>;
-  using MlpT = typename std::conditional<VNET, MlpLane<(VNET ? PD : 10)>, MlpTileT>::type;
+  using MlpT = typename std::conditional<VNET, MlpLane<(VNET ? PD : 10)>, typename std::conditional<T4, MlpTile4, MlpTileT>::type>::type;
   typename std::conditional<MT::MLP, MlpT, NoMlp>::type mlp;
-  if constexpr (MT::MLP) mlp.init(a, smem, wave, lane, (int)blockIdx.x * TPW);
+  if constexpr (MT::MLP) mlp.init(a, smem_t, wave, lane, tile * TPW);
   // lane-wise kernels: interpolant rows + tail buffers; behind the MlpTile region when there is one
   size_t lw_off = 0;
   if constexpr (T64) lw_off = (MlpT::lds_bytes(a.L) + 15) & ~(size_t)15;
-  unsigned char *const lsm = smem + lw_off;
+  unsigned char *const lsm = smem_t + lw_off;
   STAMP_DECL
 #ifdef IONODE_STAMPS
   if constexpr (MT::MLP) mlp.sp = &stamps_;
@@ -1515,7 +1702,10 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
 #ifndef IONODE_CARRY_V_MLP
 #define IONODE_CARRY_V_MLP 0  // tried for the MLP kernels too: +1 % time (372.6 -> 376.2 ms same box), kept off
 #endif
-  constexpr bool CARRY_V = (LW && D == 2) || (MT::MLP && (IONODE_CARRY_V_MLP || (IONODE_CARRY_V_TINY16 && G == 1)));  // (6-state: +50 % at 2 wavefronts per SIMD, no change at 1 per SIMD -- 38.0 vs 37.9 ms)
+#ifndef IONODE_CARRY_V_M6
+#define IONODE_CARRY_V_M6 1   // lean 6-state variant (224 registers, headroom for five more voltages): next attempt's lookups ahead of the emission's stores
+#endif
+  constexpr bool CARRY_V = (LW && D == 2) || (IONODE_CARRY_V_M6 && LW && D > 2 && LEAN) || (MT::MLP && (IONODE_CARRY_V_MLP || (IONODE_CARRY_V_TINY16 && G == 1)));  // (6-state: +50 % at 2 wavefronts per SIMD, no change at 1 per SIMD -- 38.0 vs 37.9 ms)
   if constexpr (CARRY_V) lookup_stages(t, dt);
 
   for (;;) {
@@ -1713,7 +1903,7 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
       }
     }
     STAMP(stamps_, 8);  // slot 8: interpolant fit
-    if (LEAN || a.te_dt > 0.0) {
+    if (LEAN || LEANM || a.te_dt > 0.0) {
       // ---- output cursor, lane-parallel: how many requested times fall in (t0, t1] for MY trajectory? ----
       // Guess the last index from the (nearly) uniform output grid, then VERIFY against t_eval itself and walk to the
       // exact answer: correct for any increasing t_eval, one L2 round trip for the whole tile when the guess is right
@@ -1981,7 +2171,10 @@ __global__ void __launch_bounds__(64 * G, IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT
       if constexpr (LW && (VTAB || D > 2)) {
         // a chunk of PK = 8 samples is served by PKL lanes x NSL samples each (lane kk: samples kk, kk + PKL, ...): one row read per
         // NSL samples -- with one sample per lane the LDS pipe, not the vector ALU, bounded these passes (the 6-state row is 272 bytes)
-        constexpr int PK = 8, PKL = (D == 2) ? 4 : 2, NSL = PK / PKL;
+#ifndef IONODE_PACK_PKL_D6
+#define IONODE_PACK_PKL_D6 2
+#endif
+        constexpr int PK = 8, PKL = (D == 2) ? 4 : IONODE_PACK_PKL_D6, NSL = PK / PKL;
         typedef S SV __attribute__((ext_vector_type(NSL)));
         const bool want_i = (a.i_out != nullptr) || (a.sse_out != nullptr);
         // one instance per compiled variant: the table variant (TAIL == 2) serves the current / objective epilogue, the plain one

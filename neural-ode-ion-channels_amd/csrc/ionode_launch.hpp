@@ -16,12 +16,20 @@ struct Variant {
 template <int MODEL, typename S, int G, int RT, int NT, int PD, int TAIL>
 hipError_t launch(const KArgs &a, unsigned grid, size_t lds, hipStream_t s) {
   auto kern = ionode_dopri5_kernel<MODEL, S, G, RT, NT, PD, TAIL>;
+  // the lane-wise kernels' LDS region is laid out from the SAME template constants the kernel uses: a plan that reserved less
+  // (a host / device layout mismatch) is refused here instead of becoming an out-of-bounds LDS access on the device
+  constexpr bool mlp = (MODEL == IONODE_MODEL_NNF || MODEL == IONODE_MODEL_NND);
+  if constexpr (!mlp || RT == 64) {
+    constexpr int D = (MODEL == IONODE_MODEL_MARKOV6) ? 6 : 2;
+    const size_t need = (size_t)LwLds::bytes(D, D == 2 && TAIL == 1, (int)sizeof(S));
+    if ((size_t)a.lw_bytes < need || (a.lw_bytes & 15) || lds < (size_t)IONODE_LW_TILES_PER_WG * (size_t)a.lw_bytes) return hipErrorInvalidValue;
+  }
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * G), lds, s, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (IONODE_IS_LW(MODEL, RT) ? IONODE_LW_TILES_PER_WG : G)), lds, s, a);
   return hipGetLastError();
 }
 
@@ -40,7 +48,11 @@ hipError_t launch(const KArgs &a, unsigned grid, size_t lds, hipStream_t s) {
       IONODE_VARIANT(MODEL, S, F32, 1, 64, 1, 10, 0), IONODE_VARIANT(MODEL, S, F32, 1, 64, 1, 10, 1),    \
       IONODE_VARIANT(MODEL, S, F32, 4, 4, 13, 13, 0), IONODE_VARIANT(MODEL, S, F32, 4, 8, 32, 4, 0),     \
       /* N = 200 with two column sets per tile (TAIL slot 4: 32 trajectories per workgroup), launches of >= 512 such tiles' worth */ \
-      IONODE_VARIANT(MODEL, S, F32, 4, 4, 13, 13, 4)
+      IONODE_VARIANT(MODEL, S, F32, 4, 4, 13, 13, 4),                                                     \
+      /* ... and both N = 200 tiles as LEAN variants (TAIL & 8: uniform protocol grid, verified output grid, no step log / checkpoints) */ \
+      IONODE_VARIANT(MODEL, S, F32, 4, 4, 13, 13, 8), IONODE_VARIANT(MODEL, S, F32, 4, 4, 13, 13, 12),    \
+      /* N = 200 at FOUR trajectories per tile (TAIL & 16: MlpTile4, small batches / single calls), general and lean */ \
+      IONODE_VARIANT(MODEL, S, F32, 4, 4, 13, 13, 16), IONODE_VARIANT(MODEL, S, F32, 4, 4, 13, 13, 24)
 
 // one table per translation unit (they compile in parallel)
 const Variant *variants_closed(int *n);

@@ -407,9 +407,9 @@ def test_tiny_nets_at_64_trajectories_per_wavefront(ion, gpu, oracle, model, L, 
                            mlp_layers=L, mlp_width=N, n_params=8, prot_dt=1.0, rtol=1e-7, atol=1e-9, tile_waves=64)
     # N = 10: the per-lane vector-ALU net (PD slot 10, round 4); other N <= 16: four MFMA column tiles per evaluation (PD slot 1)
     form = ", 1, 64, 1, %d, " % (10 if N == 10 else 1)
-    assert ion.capi.launch_geometry(d)["grid"] == 3 and form in ion.capi.kernel_name(d)
+    assert ion.capi.launch_geometry(d)["grid"] == 8 and form in ion.capi.kernel_name(d)        # 3 tiles -> one round of 8 workgroups x 4 tiles
     d.tile_waves, d.n_traj = 0, 160000
-    assert ion.capi.launch_geometry(d)["grid"] == 2500 and form in ion.capi.kernel_name(d)     # chosen by itself
+    assert ion.capi.launch_geometry(d)["grid"] == 632 and form in ion.capi.kernel_name(d)      # 2500 tiles, four per workgroup, chosen by itself
     d.n_traj = 30000
     assert ion.capi.launch_geometry(d)["grid"] == 1875 and ", 1, 1, 1, 1, 0>" in ion.capi.kernel_name(d)
 

@@ -43,10 +43,18 @@ def test_dispatch_geometry_and_errors(ion):
     assert g["grid"] == 256 and g["block"] == 256 and g["tile_waves"] == 4 and g["lds_bytes"] < 160 * 1024
     assert "ionode_dopri5_kernel<2, double, 4" in capi.kernel_name(d)
     d.model = capi.MODEL_HH2
-    assert capi.launch_geometry(d) == {"grid": 256, "block": 64, "lds_bytes": 64 * 14 * 8 + 64 * 64 + 512 + 1024, "tile_waves": 1}  # 16 per wavefront; interpolant rows, objective sums, cursors, work list
-    assert capi.launch_geometry(d)["lds_bytes"] <= 12800  # gfx950 LDS granule 1280 B: 12 wavefronts per compute unit
-    d.tile_waves = 64
-    assert capi.launch_geometry(d)["grid"] == 64
+    layout = 64 * 14 * 8 + 64 * 64 + 512 + 1024   # 16 per wavefront; interpolant rows, objective sums, cursors, work list
+    assert layout <= 12800                          # gfx950 LDS granule 1280 B: 12 wavefronts per compute unit
+    # lane-wise kernels: a tile is one wavefront (16 trajectories here), a workgroup carries FOUR tiles and the workgroup count is a
+    # multiple of 8 (tile t on XCD t % 8): 4096 trajectories = 256 tiles = 64 workgroups of 256 threads.  Even placement: 64 workgroups
+    # on 256 compute units = at most one per CU, so the plan reserves the whole 160 KB of LDS per workgroup
+    assert capi.launch_geometry(d) == {"grid": 64, "block": 256, "lds_bytes": 160 * 1024, "tile_waves": 1}
+    d.n_traj = 16 * 4 * 256 * 2    # two workgroups per compute unit
+    assert capi.launch_geometry(d) == {"grid": 512, "block": 256, "lds_bytes": 160 * 1024 // 2 // 1280 * 1280, "tile_waves": 1}
+    d.n_traj, d.tile_waves = 16 * 4 * 256 * 40, 16   # far beyond the residency (3 per CU at 4 x 12 800 bytes): the layout itself
+    assert capi.launch_geometry(d) == {"grid": 256 * 40, "block": 256, "lds_bytes": 4 * layout, "tile_waves": 1}
+    d.n_traj, d.tile_waves = 4096, 64
+    assert capi.launch_geometry(d)["grid"] == 16     # 64 tiles of 64 trajectories -> 16 workgroups
     d.tile_waves = 0
     d.n_state = 6  # inconsistent with HH2
     with pytest.raises(capi.IonodeError):
@@ -64,6 +72,33 @@ def test_weight_pack_is_a_permutation_with_zero_padding(ion, L, N):
     n = 2 * N + N + L * (N * N + N) + N + 1
     w = rng.permutation(n).astype(np.float32) + 1.0  # distinct, non-zero, exactly representable
     img = ion.capi.mlp_pack(w, L, N)
+    if N <= 16:
+        # N <= 16: the image ends with the SCALAR section of the per-lane net (MlpLane): L x N rows of RS floats, a second copy of the
+        # hidden layers' weights in the canonical k order (r-major, q-minor over k = 4 q + r) followed by the bias
+        RS = (N + 1 + 3) & ~3
+        sc = img[-L * N * RS:].reshape(L, N, RS)
+        img = img[:-L * N * RS]
+        korder = [4 * q + r for r in range(4) for q in range(4) if 4 * q + r < N]
+        off = 2 * N + N
+        for l in range(L):
+            W = w[off:off + N * N].reshape(N, N); b = w[off + N * N:off + N * N + N]; off += N * N + N
+            assert np.array_equal(sc[l, :, :N], W[:, korder]) and np.array_equal(sc[l, :, N], b) and not sc[l, :, N + 1:].any()
+    if N == 200:
+        # N = 200: the image ends with the section of the 4-trajectory tile (MlpTile4): per layer 4 waves x 13 steps x 4 q x 64 lanes x 4
+        # fragments (every hidden weight once more; -0.0 where the remainder block idles) + 4 x 64 bias float4s
+        lay = 4 * 13 * 4 * 256 + 4 * 256
+        t4 = img[-L * lay:].reshape(L, lay)
+        img = img[:-L * lay]
+        off = 2 * N + N
+        for l in range(L):
+            fr = t4[l, :4 * 13 * 4 * 256]
+            Wl = w[off:off + N * N]; bl = w[off + N * N:off + N * N + N]; off += N * N + N
+            nzf = fr[fr != 0]
+            assert nzf.size == N * N and np.array_equal(np.sort(nzf), np.sort(Wl))
+            bias = t4[l, 4 * 13 * 4 * 256:]
+            assert np.array_equal(np.sort(bias[bias != 0]), np.sort(np.repeat(bl, 4)))   # every lane of a block (4 trajectories) carries its rows' biases
+            idle = sum(1 for wv in range(4) for st in range(13) if not (st % 4 == 0 and st + wv < 13))
+            assert int((np.signbit(fr) & (fr == 0)).sum()) == idle * 4 * 16 * 4   # idle steps x q x the 16 lanes of block group 3 x r
     nz = img[img != 0]
     assert nz.size == n and np.array_equal(np.sort(nz), np.sort(w))
     with pytest.raises(ion.capi.IonodeError):

@@ -45,9 +45,10 @@ def test_two_state_kernels_fit_three_wavefronts_per_simd():
 # that bounds these kernels; round 3's review found 132 + 44 lane operations and 498 constant moves in the 2-state attempt loop, 626
 # v_readlane in the s00 kernel's.  The budgets are the round-4 figures plus ~10 %: a change that lets the traffic creep back fails here.
 _BUDGETS = {
-    # unit, kernel substring: (max v_readlane + v_writelane, max literal v_mov_b32 + v_mov_b64, max canonicalising v_max x, x, x)
-    ("inst_closed", "<0, double, 1, 0, 0, 0, 1>"): (190, 230, 0),
-    ("inst_closed", "<1, double, 1, 0, 0, 0, 0>"): (310, 170, 0),
+    # unit, kernel substring: (max v_readlane + v_writelane, max literal v_mov_b32 + v_mov_b64, max canonicalising v_max x, x, x, max AGPR copies)
+    ("inst_closed", "<0, double, 1, 0, 0, 0, 1>"): (20, 175, 0, 0),      # 2-state, lean variant (round 3: 176 lane operations, 498 constant moves)
+    ("inst_closed", "<0, float, 1, 0, 0, 0, 2>"): (150, 225, 0, 0),      # 2-state, table variant (fused objective)
+    ("inst_closed", "<1, double, 1, 0, 0, 0, 1>"): (20, 220, 0, 0),      # 6-state, lean variant (round 3: 592 lane operations, 353 AGPR copies)
 }
 
 
@@ -56,7 +57,7 @@ _BUDGETS = {
 def test_attempt_loop_instruction_budgets(unit):
     from asm_stats import compile_asm, kernel_stats
     st = kernel_stats(compile_asm(unit))
-    for (u, key), (lane_ops, const_movs, max_self) in _BUDGETS.items():
+    for (u, key), (lane_ops, const_movs, max_self, agpr) in _BUDGETS.items():
         if u != unit:
             continue
         k = [v for n, v in st.items() if key in n]
@@ -66,3 +67,4 @@ def test_attempt_loop_instruction_budgets(unit):
         assert a["readlane"] + a["writelane"] <= lane_ops, (key, a)
         assert a["mov_const32"] + a["mov_const64"] <= const_movs, (key, a)
         assert a["max_self"] <= max_self, (key, a)
+        assert a["accvgpr"] <= agpr, (key, a)
