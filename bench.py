@@ -241,7 +241,7 @@ def main():
             res["config"]["objective_sharded"] = {"error": repr(e)}
     lib_sha = capi.library_digest()
     res["config"]["libionode_sha256"] = lib_sha[:16]
-    pmc = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
+    pmc = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")
     if os.path.exists(pmc) and B == 4096 and Nt == 100001:
         # HBM bytes per launch from the rocprofv3 --pmc passes of this same command (profiles/README.md): FETCH_SIZE is
         # doubled (gfx950 counts 128-B requests as 64 B), WRITE_SIZE is exact; both are reported in KiB.  The counters belong
@@ -255,7 +255,7 @@ def main():
             for key in ("roofline", "roofline_hbm"):
                 res[key]["traffic"] = None if stale else traffic
                 res[key]["traffic_stale"] = stale
-                res[key]["traffic_source"] = ("HBM bytes per launch, profiles/r03_pmc_summary.json (separate rocprofv3 --pmc "
+                res[key]["traffic_source"] = ("HBM bytes per launch, profiles/r04_pmc_summary.json (separate rocprofv3 --pmc "
                                               "passes of this command; FETCH_SIZE x2 per the gfx950 note, WRITE_SIZE exact)"
                                               + ("; NOT reported: the counters were collected with another build of libionode.so "
                                                  f"({str(pj.get('libionode_sha256'))[:16]})" if stale else ""))
@@ -276,7 +276,7 @@ def main():
         for key, fn in (("roofline_closed_form", closed_form_legs), ("gradient_config5", gradient_leg),
                         ("regression_step", regression_leg), ("launch_order_16384", launch_order_leg),
                         ("objective_config4_share", objective_leg), ("config3_nnd_staircase_16384", config3_leg),
-                        ("other_architectures_4096", architectures_leg)):
+                        ("other_architectures_4096", architectures_leg), ("config1_latency", config1_latency_leg)):
             try:
                 res[key] = fn(ion, dev, weights)
             except Exception as e:  # informational legs only
@@ -326,7 +326,7 @@ def closed_form_legs(ion, dev, weights):
                                         ("hh2_two_full_rounds", capi.MODEL_HH2, P_HH, [0.0, 1.0], 393216, None, False),
                                         ("markov6", capi.MODEL_MARKOV6, p_m6, [0.0, 1.0, 0, 0, 0, 0], 65536, None, False),
                                         ("nnf_s03_5x10", capi.MODEL_NNF, P_HH, [0.0, 1.0], 65536, (w10, L10, N10), False),
-                                        # from 73 728 trajectories the N <= 16 nets run one trajectory per lane (64 per wavefront)
+                                        # from 49 152 trajectories the N <= 16 nets run one trajectory per lane (64 per wavefront; N = 10: the per-lane vector-ALU net)
                                         ("nnf_s03_5x10_262144", capi.MODEL_NNF, P_HH, [0.0, 1.0], 262144, (w10, L10, N10), False),
                                         # the reference's own state dtype (fp32, SURVEY.md finding 4): half the bytes per sample, the
                                         # same instruction stream -- the byte-based fraction halves, the trajectories per second do not
@@ -377,7 +377,7 @@ def closed_form_legs(ion, dev, weights):
                                        "note": "ms includes the protocol-at-outputs pre-pass (64 x 20001 lookups)"}
     del params, y0t, hold
     torch.cuda.empty_cache()
-    legs["note"] = ("fp64-VALU-issue bound, not HBM bound (DESIGN.md 5.1; counters: profiles/r03_pmc_summary.json cf1-cf6: "
+    legs["note"] = ("fp64-VALU-issue bound, not HBM bound (DESIGN.md 5.1; counters: profiles/r04_pmc_summary.json cf1-cf6: "
                     "SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles = 74 % for the 2-state kernel)")
     return legs
 
@@ -436,9 +436,20 @@ def gradient_leg(ion, dev, weights):
         gnorm = float(w.grad.double().norm())
         del y
     fwd, bwd = times[-1]
+    # algorithmic FLOPs: forward = RHS evaluations x F_MLP; backward = accepted steps x 6 stages x (forward recompute + input-gradient
+    # products + weight-gradient contraction = 3 F_MLP); fp32 MFMA peak as for the headline
+    st = capi.dopri5(capi.MODEL_NNF, torch.from_numpy(np.tile(P_HH, (B, 1))).to(dev), pv, torch.tensor([[0.0, 1.0]], dtype=torch.float32, device=dev).repeat(B, 1).contiguous(),
+                     te, mlp_packed=torch.from_numpy(capi.mlp_pack(weights, MLP_L, MLP_N)).to(dev), mlp_layers=MLP_L, mlp_width=MLP_N,
+                     prot_t0=0.0, prot_dt=0.1, t_eval_hint=(0.0, 0.1), t_eval_exact=True)
+    stats = st["stats"].cpu().numpy()
+    f_fwd = float(stats[:, 2].sum()) * F_MLP
+    f_bwd = float(stats[:, 0].sum()) * 6 * 3 * F_MLP
     return {"workload": "configs[4]: dL/dW through odeint, NN-f s00, 1024 trajectories (1/8 of the 8192-trajectory batch), "
                         "fp32 state, sine-wave protocols, N_t = N_p = 100001", "forward_with_checkpoints_s": fwd, "backward_s": bwd,
-            "trajectories_per_s_fwd_bwd": B / (fwd + bwd), "grad_w_norm": gnorm, "ok": int((status == 0).sum().item())}
+            "forward_kernel": st["kernel"], "trajectories_per_s_fwd_bwd": B / (fwd + bwd), "grad_w_norm": gnorm, "ok": int((status == 0).sum().item()),
+            "flop_forward": f_fwd, "flop_backward": f_bwd, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+            "frac_forward": f_fwd / fwd / 1e12 / PEAK_FP32_TFLOPS, "frac_backward": f_bwd / bwd / 1e12 / PEAK_FP32_TFLOPS,
+            "frac": (f_fwd + f_bwd) / (fwd + bwd) / 1e12 / PEAK_FP32_TFLOPS}
 
 
 def config3_leg(ion, dev, weights):
@@ -575,6 +586,32 @@ def sharded_objective_leg(ion, dev, dist, backend, rank, world):
         out[name] = {"per_rank_ms": [float(x) for x in ranks], "wall_ms": wall, "max_over_mean": float(ranks.max() / ranks.mean()),
                      "finite": int(torch.isfinite(sse).sum())}
     return out
+
+
+def config1_latency_leg(ion, dev, weights):
+    """BASELINE.json configs[0] / the reference's own call shape: ONE trajectory, `odeint(func, y0, t)` through the torchdiffeq shim
+    (train-s1.py:319-330), NN-f s00 on the 10 s synthetic sine wave, fp32 state as in the scripts.  Steady-state call (module, weights
+    and protocol already device-resident): the serial chain of ~21 k RHS evaluations on the 4-trajectory tile."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ref_style_modules as M
+    from torchdiffeq import odeint
+    P = ion.protocols
+    func = M.NNf(P_HH)
+    M.load_flat_weights(func.net, weights)
+    func.eval()
+    Nt = 100001
+    pv = P.sinewave(P.sinewave_scales(0, 1), n_samples=Nt)[0]
+    func.set_fixed_form_voltage_protocol(np.arange(Nt) * 0.1, pv)
+    t = torch.linspace(0.0, 10000.0, 2001)
+    y0 = torch.tensor([[0.0, 1.0]])
+    ms = []
+    with torch.no_grad():
+        for rep in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            y = odeint(func, y0, t)
+            torch.cuda.synchronize(); ms.append((time.perf_counter() - t0) * 1e3)
+    return {"workload": "one odeint(func, y0, t) call, NN-f s00, 10 s sine wave, 2001 outputs, fp32 state", "ms_per_call": min(ms[1:]),
+            "first_call_ms": ms[0], "kernel": ion.capi.lib().ionode_last_kernel_name().decode(), "finite": bool(torch.isfinite(y).all())}
 
 
 def launch_order_leg(ion, dev, weights):

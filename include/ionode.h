@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define IONODE_ABI_VERSION 6
+#define IONODE_ABI_VERSION 7
 
 /* RHS families (func.forward variants of the reference) */
 #define IONODE_MODEL_HH2 0     /* 2-state Hodgkin-Huxley: Lambda, train-s1.py:134-177; candidate ODEFunc train-d0.py:321-374 */
@@ -120,7 +120,7 @@ typedef struct ionode_desc {
                           results are those of index order, bit for bit -- only which trajectories share a tile / a wavefront, and
                           in which sequence the tiles start, changes.  What the reference's callers would sort by: predicted cost
                           (tiles become homogeneous, the launch a longest-first list schedule) or protocol (the lanes of a
-                          wavefront interpolate one protocol).  Not with traj_per_image.  ABI 6. */
+                          wavefront interpolate one protocol).  Not with traj_per_image.  Since ABI 6. */
 } ionode_desc;
 
 #define IONODE_DEFAULT_MAX_TOTAL_STEPS 1000000
@@ -229,18 +229,16 @@ int ionode_dopri5_backward(const ionode_desc *d, int32_t it_begin, int32_t it_en
  *   ionode_grad_reduce_unit()           contracts such records, scaling the D tiles by the seeds while staging them.
  * Same gradients as ionode_dopri5_backward() up to fp32 rounding (the seed multiplies at the end of the product instead of at its
  * start).  Call order per chunk: recompute, sweep, reduce_unit; recompute of chunk k + 1 may run beside the sweep of chunk k.
- * `signs` is unused (kept for ABI 6 callers; may be NULL).
  */
-size_t ionode_grad_sign_words(void);
 size_t ionode_grad_packet_doubles(void);
 int ionode_dopri5_backward_recompute(const ionode_desc *d, int32_t it_begin, int32_t it_end, int32_t n_iter, const float *grad_image,
                                      const double *params, const double *prot_v, const double *prot_t, const int32_t *prot_of_traj,
                                      const double *t_eval, const int32_t *n_accepted, const void *grad_y, float *records,
-                                     uint64_t *signs, double *packets, void *stream);
+                                     double *packets, void *stream);
 int ionode_dopri5_backward_sweep(const ionode_desc *d, int32_t it_begin, int32_t it_end, int32_t n_iter, const float *grad_image,
                                  const double *params, const double *prot_v, const double *prot_t, const int32_t *prot_of_traj,
                                  const double *t_eval, const int32_t *n_accepted, const void *grad_y, double *state,
-                                 float *records, const uint64_t *signs, const double *packets, double *grad_params, double *grad_y0,
+                                 float *records, const double *packets, double *grad_params, double *grad_y0,
                                  void *stream);
 int ionode_grad_reduce_unit(int32_t mlp_layers, int32_t mlp_width, const float *records, int64_t n_records, int32_t n_slabs,
                             float *partials, void *stream);

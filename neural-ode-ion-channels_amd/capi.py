@@ -21,13 +21,13 @@ STATUS_TEXT = {
     2: "non-finite values in state `y`",
     3: "max_num_steps exceeded",
 }
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 EXPORTS = (
     "ionode_abi_version", "ionode_last_error", "ionode_mlp_packed_floats", "ionode_mlp_pack",
     "ionode_launch_geometry", "ionode_kernel_name", "ionode_last_kernel_name", "ionode_dopri5", "ionode_protocol_at_outputs",
     "ionode_grad_image_floats", "ionode_grad_pack", "ionode_grad_record_floats", "ionode_dopri5_backward",
-    "ionode_grad_sign_words", "ionode_grad_packet_doubles", "ionode_dopri5_backward_recompute", "ionode_dopri5_backward_sweep",
+    "ionode_grad_packet_doubles", "ionode_dopri5_backward_recompute", "ionode_dopri5_backward_sweep",
     "ionode_grad_partial_floats", "ionode_grad_reduce", "ionode_grad_reduce_unit", "ionode_grad_last_error",
     "ionode_regress_step", "ionode_adam_step", "ionode_image_refresh",
 )
@@ -92,14 +92,12 @@ def lib():
         L.ionode_grad_pack.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         L.ionode_dopri5_backward.restype = C.c_int
         L.ionode_dopri5_backward.argtypes = [C.POINTER(IonodeDesc), C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 13
-        L.ionode_grad_sign_words.restype = C.c_size_t
-        L.ionode_grad_sign_words.argtypes = []
         L.ionode_dopri5_backward_recompute.restype = C.c_int
         L.ionode_grad_packet_doubles.restype = C.c_size_t
         L.ionode_grad_packet_doubles.argtypes = []
-        L.ionode_dopri5_backward_recompute.argtypes = [C.POINTER(IonodeDesc), C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 12
+        L.ionode_dopri5_backward_recompute.argtypes = [C.POINTER(IonodeDesc), C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 11
         L.ionode_dopri5_backward_sweep.restype = C.c_int
-        L.ionode_dopri5_backward_sweep.argtypes = [C.POINTER(IonodeDesc), C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 15
+        L.ionode_dopri5_backward_sweep.argtypes = [C.POINTER(IonodeDesc), C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 14
         L.ionode_grad_reduce.restype = C.c_int
         L.ionode_grad_reduce.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
         L.ionode_grad_reduce_unit.restype = C.c_int
@@ -266,7 +264,7 @@ def dopri5(model, params, prot_v, y0, t_eval, *, mlp_packed=None, mlp_layers=0, 
             raise IonodeError("launch_order: None, 'auto' or an int32 device tensor [B]")
         launch_order = None
         lane_wise = model in (MODEL_HH2, MODEL_MARKOV6) or (mlp_width and mlp_width <= 16)
-        if lane_wise and prot_of_traj is not None and P > 1 and B >= 81920 and not traj_per_image:
+        if lane_wise and prot_of_traj is not None and P > 1 and B >= 49152 and not traj_per_image:
             launch_order = _protocol_major(prot_of_traj)
     if launch_order is not None:
         _dev_ptr(launch_order, torch.int32, "launch_order", (B,))

@@ -11,13 +11,13 @@
 #define IONODE_TILE32_FROM 8192  // N = 200: two 16-trajectory tiles per compute unit
 #endif
 #ifndef IONODE_TILE4_UPTO
-#define IONODE_TILE4_UPTO 1536  // N = 200: up to this many trajectories, 4 per tile (one tile per compute unit up to 1024; 16-tiles would use <= 96 of 256 CUs)
+#define IONODE_TILE4_UPTO 1024  // N = 200: up to this many trajectories, 4 per tile = at most one tile per compute unit (16-tiles would use <= 64 of the 256 CUs)
 #endif
 #ifndef IONODE_TINY64_MFMA
 #define IONODE_TINY64_MFMA 0   // 1: N = 10 keeps the MFMA form at 64 trajectories per wavefront (A/B)
 #endif
 #ifndef IONODE_TINY64_FROM
-#define IONODE_TINY64_FROM 73728  // 16 per wavefront: 32 768 trajectories per residency round of 12.8 ms; 64 per wavefront: 131 072 per round of 30 ms
+#define IONODE_TINY64_FROM 49152  // round 4 (per-lane net, even placement; 20 001 samples): 16 per wavefront 12.1 ms up to 32 768, 19.7 at 49 152, 23.3 at 65 536; 64 per wavefront 19.2-19.4 ms from 16 384 to 65 536
 #endif
 
 namespace {
@@ -91,11 +91,10 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false, bool ex
   if (!(d->rtol > 0) || !(d->atol >= 0) || !(d->prot_dt > 0)) { set_err("rtol/atol/prot_dt must be positive"); return IONODE_ERR_ARG; }
   const int f32 = d->state_f32 ? 1 : 0;
   if (!mlp) {
-    // small batches: 16 trajectories per wavefront (lanes replicated 4x, 4x the wavefronts) until the chip's resident
-    // wavefront slots (3 per SIMD for the 2-state, 1 for the 6-state kernel) are well over-subscribed; measured crossovers
-    // (tools/ab_tpw.sh, 20 001 samples): 2-state between 65 536 and 98 304 trajectories, 6-state between 32 768 and 65 536
-    // (65 536: 58.9 ms at 64 per wavefront against 93.4 ms at 16).  tile_waves = 64 / 16 forces a choice (tests).
-    const int tpw64_from = (D == 6) ? 40960 : 81920;
+    // small batches: 16 trajectories per wavefront (lanes replicated 4x, 4x the wavefronts) while the launch has fewer wavefronts than
+    // the chip has SIMDs to spread them over; measured crossovers (round 4, tools/gpu/r4_t4b.sh, 20 001 samples): 2-state 32 768: 6.3 ms at
+    // 16 per wavefront / 9.7 at 64, 65 536: 11.6 / 10.1; 6-state 16 384: 9.1 / 13.8, 32 768: 17.5 / 15.0.  tile_waves = 64 / 16 forces a choice.
+    const int tpw64_from = (D == 6) ? 24576 : 49152;
     const int tpw = (d->tile_waves == 64 || d->tile_waves == 16) ? d->tile_waves : (d->n_traj >= tpw64_from ? 64 : 16);
     // deferred aligned emission (2-state models): the output grid must be VERIFIED uniform and no current trace requested
     // ... or, with a current trace / fused objective and the protocol-at-outputs table given, the table variant (hint path)
@@ -141,7 +140,7 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false, bool ex
     const bool t4 = !t64 && !t32 && NT == 13 && d->mlp_layers >= 1 && (d->traj_per_image <= 0 || d->traj_per_image % 4 == 0) &&
                     (d->tile_waves == 2 || (d->tile_waves == 0 && d->n_traj <= IONODE_TILE4_UPTO));
     // N = 200 tiles: the lean variant when its contract holds (ionode_device.hpp LEANM)
-    const bool leanm = !t64 && NT == 13 && d->mlp_layers >= 1 && !explicit_grid && !d->step_log && !d->ckpt && d->t_eval_exact && d->t_eval_dt_hint > 0.0 && d->n_out > 1;
+    const bool leanm = !t64 && (NT == 13 || NT == 7 || NT == 32) && d->mlp_layers >= 1 && !explicit_grid && !d->step_log && !d->ckpt && d->t_eval_exact && d->t_eval_dt_hint > 0.0 && d->n_out > 1;
     pl->v = t64 ? find_variant(d->model, f32, 1, NT, 64, t64defer, vnet ? 10 : 1)
                 : find_variant(d->model, f32, ((d->tile_waves == 8 || d->tile_waves == 2) ? 4 : d->tile_waves), NT, NT == 1 ? 1 : -1, (t32 ? 4 : 0) | (leanm ? 8 : 0) | (t4 ? 16 : 0));
     if (!pl->v) {

@@ -980,8 +980,10 @@ struct MlpTile {
 // in their own image section (ionode_mlp_pack): layer | wavefront | step | q | lane -> float4 over r, then the layer's bias float4s.
 // ---------------------------------------------------------------------------------------------
 struct MlpTile4 {
-  static constexpr int GW = 4, NT = 13, NP = 208, KQ = NP / 4;
-  static constexpr int ACT = KQ * 4;                 // float4 per activation buffer: [kq][trajectory]
+  static constexpr int GW = 4, NT = 13, NP = 208;
+  static constexpr int SLOTS = NT + 3;               // k-tile slots per activation buffer: tiles 0..2 are stored twice (slot kt and kt + 13), so
+                                                     // that wavefront w reads its rotated walk kt = (s + w) mod 13 at the LINEAR slot s + w
+  static constexpr int ACT = SLOTS * 16;             // float4 per activation buffer: [slot][q][trajectory]
   static constexpr size_t layer_floats() { return (size_t)4 * NT * 4 * 256 + (size_t)4 * 256; }   // fragments + bias float4 per (wave, lane)
   static __host__ __device__ constexpr size_t lds_bytes(int L) {
     return ((size_t)2 * ACT + (size_t)2 * 4 * 16 + NP) * 16 + ((size_t)NP + 4) * 4;   // activations x2, partial sums x2, W0 rows, wl + bl
@@ -1036,32 +1038,42 @@ struct MlpTile4 {
       for (int q = 0; q < 4; ++q) ring[s][q] = (L > 0) ? frag(sec0, s * 4 + q) : f32x4{0, 0, 0, 0};
     __syncthreads();
   }
-  // activations of the remainder k-tile (rows 192 .. 207) for this lane's trajectory, k = 192 + 4 q + r: fold of the four partial chains
-  __device__ __forceinline__ f32x4 remainder_h(const f32x4 *__restrict__ Pin, int q, int j) const {
-    const f32x4 p0 = Pin[(0 * 4 + q) * 4 + j], p1 = Pin[(1 * 4 + q) * 4 + j], p2 = Pin[(2 * 4 + q) * 4 + j], p3 = Pin[(3 * 4 + q) * 4 + j];
-    f32x4 h;
+  // store an output block (4 rows of k-tile kt, lane group q, trajectory j); tiles 0..2 also at their second slot
+  __device__ __forceinline__ void put_h(f32x4 *__restrict__ H, int kt, int q, int j, f32x4 h) const {
+    H[(kt * 4 + q) * 4 + j] = h;
+    if (kt < 3) H[((kt + NT) * 4 + q) * 4 + j] = h;
+  }
+  // The remainder k-tile (rows 192 .. 207) arrives as four partial chains; 16 lanes of EVERY wavefront fold them ((p0 + p1) + (p2 + p3),
+  // LeakyReLU) into slot 12 of the input buffer -- identical bits from all four wavefronts, and each wavefront reads slot 12 (late in its
+  // walk) after its own write, so no barrier is needed and the k loop has no special case
+  __device__ __forceinline__ void fold_remainder(f32x4 *__restrict__ Hin, const f32x4 *__restrict__ Pin) const {
+    if (lane < 16) {
+      const int q = lane >> 2, j = lane & 3;
+      const f32x4 p0 = Pin[(0 * 4 + q) * 4 + j], p1 = Pin[(1 * 4 + q) * 4 + j], p2 = Pin[(2 * 4 + q) * 4 + j], p3 = Pin[(3 * 4 + q) * 4 + j];
+      f32x4 h;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) h[r] = lrelu((p0[r] + p1[r]) + (p2[r] + p3[r]));
-    return h;
+      for (int r = 0; r < 4; ++r) h[r] = lrelu((p0[r] + p1[r]) + (p2[r] + p3[r]));
+      Hin[((NT - 1) * 4 + q) * 4 + j] = h;
+    }
   }
   __device__ __forceinline__ float eval(float x0, float x1) {
     const int j = lane & 3, b = lane >> 2, g = b >> 2, u = b & 3;
-    // layer 0: Linear(2, N) + LeakyReLU; the lane fills output block kq = 16 wave + b of its trajectory
+    // layer 0: Linear(2, N) + LeakyReLU; the lane fills output block (kt, q) = (4 wave + b / 4, b % 4) of its trajectory
     {
       const int kq = 16 * wave + b;
-      if (kq < KQ) {
+      if (kq < NP / 4) {
         f32x4 h;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const f32x4 w = W0s[4 * kq + r];
           h[r] = lrelu(fmaf(w[2], x1, fmaf(w[1], x0, w[0])));
         }
-        Hs[kq * 4 + j] = h;
+        put_h(Hs, kq >> 2, kq & 3, j, h);
       }
     }
     __syncthreads();
     for (int l = 0; l < L; ++l) {
-      const f32x4 *__restrict__ Hin = Hs + (l & 1) * ACT;
+      f32x4 *__restrict__ Hin = Hs + (l & 1) * ACT;
       f32x4 *__restrict__ Hout = Hs + ((l + 1) & 1) * ACT;
       const f32x4 *__restrict__ Pin = Ps + (l & 1) * 64;
       f32x4 *__restrict__ Pout = Ps + ((l + 1) & 1) * 64;
@@ -1069,16 +1081,20 @@ struct MlpTile4 {
       const unsigned lcur = sec0 + (unsigned)l * lbytes, lnext = sec0 + (unsigned)ln * lbytes;
       // accumulators: D[i][j] = VGPR i: bias of row i of my block (the remainder chain w > 0 starts at 0: the image says so)
       f32x4 acc = bias4(lcur);
+      if (l > 0) fold_remainder(Hin, Pin);
+      // this wavefront's walk: k-tile (s + wave) mod 13 = slot s + wave; B operands one step ahead of their use
+      const f32x4 *__restrict__ Bw = Hin + (wave * 4) * 4 + j;
+      f32x4 hn[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) hn[q] = Bw[q * 4];
 #pragma unroll
       for (int s = 0; s < NT; ++s) {
-        const int kt = (s + wave < NT) ? s + wave : s + wave - NT;
         f32x4 hq[4];
-        if (kt == NT - 1 && l > 0) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) hq[q] = remainder_h(Pin, q, j);
-        } else {
+        for (int q = 0; q < 4; ++q) hq[q] = hn[q];
+        if (s + 1 < NT) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) hq[q] = Hin[(4 * kt + q) * 4 + j];
+          for (int q = 0; q < 4; ++q) hn[q] = Bw[((s + 1) * 4 + q) * 4];
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1095,21 +1111,21 @@ struct MlpTile4 {
         f32x4 h;
 #pragma unroll
         for (int r = 0; r < 4; ++r) h[r] = lrelu(acc[r]);
-        Hout[(4 * (wave + 4 * g) + u) * 4 + j] = h;
+        put_h(Hout, wave + 4 * g, u, j, h);
       } else {
         Pout[(wave * 4 + u) * 4 + j] = acc;   // partial chain `wave` of the remainder tile, pre-activation
       }
       __syncthreads();
     }
     // Linear(N, 1): chain q = b & 3 per lane (k = 16 kt + 4 q + r, kt ascending, r ascending), folded ((p0 + p1) + (p2 + p3)) + bl
-    const f32x4 *__restrict__ Hin = Hs + (L & 1) * ACT;
-    const f32x4 *__restrict__ Pin = Ps + (L & 1) * 64;
+    f32x4 *__restrict__ Hin = Hs + (L & 1) * ACT;
+    if (L > 0) fold_remainder(Hin, Ps + (L & 1) * 64);
     const int q = b & 3;
     float part = 0.0f;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
       const f32x4 w = *reinterpret_cast<const f32x4 *>(wlS + 16 * kt + 4 * q);
-      const f32x4 h = (kt == NT - 1 && L > 0) ? remainder_h(Pin, q, j) : Hin[(4 * kt + q) * 4 + j];
+      const f32x4 h = Hin[(kt * 4 + q) * 4 + j];
 #pragma unroll
       for (int r = 0; r < 4; ++r) part = fmaf(w[r], h[r], part);
     }
@@ -1134,8 +1150,8 @@ struct MlpTile4 {
 // bias + 0.0f into this section (N < 16; the tile's own trailing padded term does the same to its result).
 // Image section (ionode_mlp_pack, behind wl / bl): L x N rows of RS = 12 floats {W[j][k] in the canonical k order, bias, pad}.
 // ---------------------------------------------------------------------------------------------
-#ifndef IONODE_VNET_GROUP
-#define IONODE_VNET_GROUP 5
+#ifndef IONODE_VNET_AHEAD
+#define IONODE_VNET_AHEAD 0   // 0 (default): every row waits for its own scalar loads.  1 or 4: a ring of AHEAD + 1 row buffers with the loads issued AHEAD rows early -- measured SLOWER (262 144 x 20 001: 46.3 ms at 0, 53.6 at 1, 55.3 at 4: the ring costs SGPRs, i.e. v_readlane traffic around each evaluation, and pins the schedule); kept for A/B
 #endif
 template <int N> struct MlpLane {
   static_assert(N == 10, "the per-lane net is instantiated for N = 10 (architectures s03-s05)");
@@ -1171,25 +1187,57 @@ template <int N> struct MlpLane {
     constexpr size_t lstride = (size_t)256 + NP;  // MlpTile<1, 1, 1, 1>::layer_floats(): one fragment + bias[NP]
     const cfloat *wl = img + 4 * NP + (size_t)L * lstride;   // wl[NP], bl, 3 pad
     const cfloat *ws = wl + NP + 4;               // the scalar section
-    for (int l = 0; l < L; ++l) {
-      float g[N];
-      // rows in groups of GR: a group's weights (GR x 11 scalars) are in flight together, then consumed; with all ten rows at once the
-      // 110 weights take every SGPR and whatever else is live is spilled into VGPR lanes around each evaluation (v_writelane /
-      // v_readlane bursts: vector instructions again)
+    // Hidden layers.  A row's 11 scalars (10 weights in the canonical k order + bias) are loaded IONODE_VNET_AHEAD rows ahead of their
+    // use into a ring of AHEAD + 1 row buffers: scalar loads return out of order, so every wait is lgkmcnt(0) -- the wait for row r is
+    // therefore placed BEFORE the loads of row r + AHEAD are issued (an empty asm consumes one scalar of row r), and those loads then
+    // fly during the vector work of rows r .. r + AHEAD - 1.  With one wavefront per SIMD (launches below ~200 k trajectories) nothing
+    // else hides the scalar-cache latency; without the ring a row costs ~4x its 13 vector instructions.
+    constexpr int AH = IONODE_VNET_AHEAD > 0 ? IONODE_VNET_AHEAD : 1, NB = AH + 1;
+    static_assert(N % NB == 0, "the ring position of a row must not depend on the layer");
+    if constexpr (IONODE_VNET_AHEAD == 0) {
+      for (int l = 0; l < L; ++l) {   // (A/B: every row waits for its own scalar loads)
+        float g[N];
 #pragma unroll
-      for (int j0 = 0; j0 < N; j0 += IONODE_VNET_GROUP) {
-#pragma unroll
-        for (int j = j0; j < j0 + IONODE_VNET_GROUP && j < N; ++j) {
+        for (int j = 0; j < N; ++j) {
           const cfloat *row = ws + ((size_t)l * N + j) * RS;
           float acc = row[N];
 #pragma unroll
           for (int pos = 0; pos < N; ++pos) acc = fmaf(row[pos], h[k_at(pos)], acc);
           g[j] = lrelu(acc);
+          __builtin_amdgcn_sched_barrier(0);
         }
+#pragma unroll
+        for (int j = 0; j < N; ++j) h[j] = g[j];
+      }
+    } else {
+    const int rows = L * N;
+    float wb[NB][RS];
+    auto load_row = [&](int r, float (&dst)[RS]) {
+      const cfloat *row = ws + (size_t)r * RS;
+#pragma unroll
+      for (int e = 0; e <= N; ++e) dst[e] = row[e];
+    };
+#pragma unroll
+    for (int r = 0; r < AH; ++r)
+      if (r < rows) load_row(r, wb[r % NB]);
+    for (int l = 0; l < L; ++l) {
+      float g[N];
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const int r = l * N + j;
+        asm volatile("" :: "s"(wb[j % NB][N]));          // row r is needed now: the wait lands here ...
+        __builtin_amdgcn_sched_barrier(0);
+        if (r + AH < rows) load_row(r + AH, wb[(j + AH) % NB]);   // ... and only then the loads of row r + AHEAD are issued
+        __builtin_amdgcn_sched_barrier(0);
+        float acc = wb[j % NB][N];
+#pragma unroll
+        for (int pos = 0; pos < N; ++pos) acc = fmaf(wb[j % NB][pos], h[k_at(pos)], acc);
+        g[j] = lrelu(acc);
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int j = 0; j < N; ++j) h[j] = g[j];
+    }
     }
     float part[4];
 #pragma unroll
@@ -1407,8 +1455,11 @@ template <typename S> __device__ __forceinline__ S abs_(S x) { return x < 0 ? -x
 #ifndef IONODE_T64_WAVES
 #define IONODE_T64_WAVES 1
 #endif
+#ifndef IONODE_N100_WAVES
+#define IONODE_N100_WAVES 1   // N = 100 tile (NT = 7): 2 = ask hipcc for a 256-register build, two tiles per compute unit (A/B)
+#endif
 #define IONODE_WAVES_PER_SIMD(MODEL, G, NT, RT) \
-  (((MODEL) >= IONODE_MODEL_NNF && (RT) == 64) ? IONODE_T64_WAVES : IONODE_CF_WAVES(MODEL, G))
+  (((MODEL) >= IONODE_MODEL_NNF && (RT) == 64) ? IONODE_T64_WAVES : (((MODEL) >= IONODE_MODEL_NNF && (NT) == 7) ? IONODE_N100_WAVES : IONODE_CF_WAVES(MODEL, G)))
 
 template <typename S, int D> __device__ __forceinline__ void store_state(S *dst, const S *v) {
   if constexpr (D == 2 && sizeof(S) == 8) {
@@ -1451,10 +1502,6 @@ __global__ void __launch_bounds__(64 * (IONODE_IS_LW(MODEL, RT) ? IONODE_LW_TILE
   //   TAIL & 8 of an MLP tile kernel: uniform protocol grid, VERIFIED uniform output grid, no step log, no checkpoints (states,
   //                current trace and fused objective stay run-time choices)
   constexpr bool LEANM = IONODE_LEAN && MT::MLP && G > 1 && (TAIL & 8);
-#ifndef IONODE_M6_LEAN_PAD
-#define IONODE_M6_LEAN_PAD 0   // A/B: 1 = the lean 6-state kernels claim AGPRs up to a47, so that only ONE wavefront fits a SIMD
-#endif
-  if constexpr (IONODE_M6_LEAN_PAD && MODEL == IONODE_MODEL_MARKOV6 && LEAN) asm volatile("" ::: "a47");
   KArgs a = a_in;
   if constexpr (LEANM) a.te_exact = 1;
   if constexpr (LEAN || LEANT || LEANM) { a.prot_t = nullptr; a.step_log = nullptr; a.step_log_cap = 0; a.ckpt = nullptr; a.ckpt_cap = 0; }

@@ -44,7 +44,6 @@ struct GArgs {
   int64_t record_floats;
   double *packets;            // two-phase sweep: the adjoint-independent scalars of every (tile, step): [n_tiles][it_end - it_begin][16][GRAD_PACKET] fp64
   int32_t phase;              // 0: one-phase sweep; 1: phase A (recompute kernel); 2: phase B (walk kernel)
-  unsigned long long *signs;  // (unused: slot of the first two-phase form, which passed LeakyReLU' bits from phase A to the walk)
 };
 constexpr int GRAD_SIGN_WORDS = 8;   // 64-bit words per lane and evaluation (Signs below)
 // packet of one trajectory and step (doubles): [0] dts, [1] step, [2] initev, [4 + c*2 + d] G_c (interpolant-coefficient adjoint

@@ -86,7 +86,7 @@ int ionode_grad_pack(const float *w, int32_t L, int32_t N, float *out) {
 static int backward_impl(int mode, const ionode_desc *d, int32_t it_begin, int32_t it_end, int32_t n_iter, const float *grad_image,
                          const double *params, const double *prot_v, const double *prot_t, const int32_t *prot_of_traj,
                          const double *t_eval, const int32_t *n_accepted, const void *grad_y, double *state,
-                         float *records, uint64_t *signs, double *packets, double *grad_params, double *grad_y0, void *stream) {
+                         float *records, double *packets, double *grad_params, double *grad_y0, void *stream) {
   if (!d) { gerr("null descriptor"); return IONODE_ERR_ARG; }
   if (mode != 0 && (!packets || (d->model != IONODE_MODEL_NNF && d->model != IONODE_MODEL_NND))) {
     gerr("two-phase sweep: NN-f / NN-d only, `packets` required"); return IONODE_ERR_ARG;
@@ -126,7 +126,6 @@ static int backward_impl(int mode, const ionode_desc *d, int32_t it_begin, int32
   a.records = hh2 ? nullptr : records; a.grad_params = grad_params; a.grad_y0 = grad_y0;
   a.it_begin = it_begin; a.it_end = it_end; a.n_iter = n_iter;
   a.record_floats = ionode::grad_record_floats(L, NT);
-  a.signs = reinterpret_cast<unsigned long long *>(mode != 0 ? signs : nullptr);
   a.packets = mode != 0 ? packets : nullptr;
   a.phase = mode;
   if (mode != 0 && ionode::grad_lds_bytes(L, NT) + 16 + 16 * ionode::GRAD_PACKET * 8 > 160 * 1024) { gerr("two-phase sweep: LDS"); return IONODE_ERR_UNSUPPORTED; }
@@ -141,27 +140,26 @@ int ionode_dopri5_backward(const ionode_desc *d, int32_t it_begin, int32_t it_en
                            const double *t_eval, const int32_t *n_accepted, const void *grad_y, double *state,
                            float *records, double *grad_params, double *grad_y0, void *stream) {
   return backward_impl(0, d, it_begin, it_end, n_iter, grad_image, params, prot_v, prot_t, prot_of_traj, t_eval, n_accepted, grad_y,
-                       state, records, nullptr, nullptr, grad_params, grad_y0, stream);
+                       state, records, nullptr, grad_params, grad_y0, stream);
 }
 
-size_t ionode_grad_sign_words(void) { return (size_t)ionode::GRAD_SIGN_WORDS * 256; }
 size_t ionode_grad_packet_doubles(void) { return (size_t)16 * ionode::GRAD_PACKET; }
 
 int ionode_dopri5_backward_recompute(const ionode_desc *d, int32_t it_begin, int32_t it_end, int32_t n_iter, const float *grad_image,
                                      const double *params, const double *prot_v, const double *prot_t, const int32_t *prot_of_traj,
                                      const double *t_eval, const int32_t *n_accepted, const void *grad_y, float *records,
-                                     uint64_t *signs, double *packets, void *stream) {
+                                     double *packets, void *stream) {
   return backward_impl(1, d, it_begin, it_end, n_iter, grad_image, params, prot_v, prot_t, prot_of_traj, t_eval, n_accepted, grad_y,
-                       nullptr, records, signs, packets, nullptr, nullptr, stream);
+                       nullptr, records, packets, nullptr, nullptr, stream);
 }
 
 int ionode_dopri5_backward_sweep(const ionode_desc *d, int32_t it_begin, int32_t it_end, int32_t n_iter, const float *grad_image,
                                  const double *params, const double *prot_v, const double *prot_t, const int32_t *prot_of_traj,
                                  const double *t_eval, const int32_t *n_accepted, const void *grad_y, double *state,
-                                 float *records, const uint64_t *signs, const double *packets, double *grad_params, double *grad_y0,
+                                 float *records, const double *packets, double *grad_params, double *grad_y0,
                                  void *stream) {
   return backward_impl(2, d, it_begin, it_end, n_iter, grad_image, params, prot_v, prot_t, prot_of_traj, t_eval, n_accepted, grad_y,
-                       state, records, const_cast<uint64_t *>(signs), const_cast<double *>(packets), grad_params, grad_y0, stream);
+                       state, records, const_cast<double *>(packets), grad_params, grad_y0, stream);
 }
 
 static int reduce_impl(int32_t L, int32_t N, const float *records, int64_t n_records, int32_t n_slabs, float *partials, void *stream,

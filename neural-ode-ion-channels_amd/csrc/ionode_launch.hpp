@@ -52,7 +52,9 @@ hipError_t launch(const KArgs &a, unsigned grid, size_t lds, hipStream_t s) {
       /* ... and both N = 200 tiles as LEAN variants (TAIL & 8: uniform protocol grid, verified output grid, no step log / checkpoints) */ \
       IONODE_VARIANT(MODEL, S, F32, 4, 4, 13, 13, 8), IONODE_VARIANT(MODEL, S, F32, 4, 4, 13, 13, 12),    \
       /* N = 200 at FOUR trajectories per tile (TAIL & 16: MlpTile4, small batches / single calls), general and lean */ \
-      IONODE_VARIANT(MODEL, S, F32, 4, 4, 13, 13, 16), IONODE_VARIANT(MODEL, S, F32, 4, 4, 13, 13, 24)
+      IONODE_VARIANT(MODEL, S, F32, 4, 4, 13, 13, 16), IONODE_VARIANT(MODEL, S, F32, 4, 4, 13, 13, 24),   \
+      /* lean variants of the N = 100 and N = 500 tiles */                                              \
+      IONODE_VARIANT(MODEL, S, F32, 4, 4, 7, 7, 8), IONODE_VARIANT(MODEL, S, F32, 4, 8, 32, 4, 8)
 
 // one table per translation unit (they compile in parallel)
 const Variant *variants_closed(int *n);

@@ -209,7 +209,6 @@ class _Solve(torch.autograd.Function):
             n_chunks = (n_iter + chunk - 1) // chunk
             n_buf = 2 if n_chunks > 1 else 1
         records = [torch.empty(tiles * chunk * 6 * recf, dtype=torch.float32, device=dev) for _ in range(n_buf)] if need_w else [None] * n_buf
-        signs = [None] * n_buf   # (ABI 6 slot of the first two-phase form; unused by the factored one)
         pkd = int(lib.ionode_grad_packet_doubles()) if two_phase else 0
         packets = [torch.empty(tiles * chunk * pkd, dtype=torch.float64, device=dev) for _ in range(n_buf)] if two_phase else [None] * n_buf
         side = torch.cuda.Stream(dev) if (need_w and n_buf == 2) else main          # reductions
@@ -229,7 +228,7 @@ class _Solve(torch.autograd.Function):
             if free[b] is not None:
                 pre.wait_event(free[b])
             rc = lib.ionode_dopri5_backward_recompute(C.byref(desc), it0, it1, n_iter, *common, _ptr(gy), _ptr(records[b]),
-                                                      _ptr(signs[b]), _ptr(packets[b]), C.c_void_p(pre.cuda_stream))
+                                                      _ptr(packets[b]), C.c_void_p(pre.cuda_stream))
             if rc != 0:
                 raise capi.IonodeError(f"ionode_dopri5_backward_recompute failed ({rc}): {lib.ionode_grad_last_error().decode()}")
             ev = torch.cuda.Event()
@@ -246,7 +245,7 @@ class _Solve(torch.autograd.Function):
                     phase_a(k + 1)                      # one chunk ahead, beside this chunk's walk
                 main.wait_event(ready[b])
                 rc = lib.ionode_dopri5_backward_sweep(C.byref(desc), it0, it1, n_iter, *common, _ptr(gy), _ptr(state), _ptr(rec),
-                                                      _ptr(signs[b]), _ptr(packets[b]), _ptr(g_params), _ptr(g_y0),
+                                                      _ptr(packets[b]), _ptr(g_params), _ptr(g_y0),
                                                       C.c_void_p(main.cuda_stream))
             else:
                 if free[b] is not None:

@@ -24,7 +24,8 @@ def test_no_kernel_uses_scratch():
     assert not bad, bad
     # the hand-scheduled N = 200 kernels: the asm stream owns a[0:91]; the compiler's own spills must fit the other AGPRs
     for r in rows:
-        if "ionode_dopri5_kernel<" in r["kernel"] and ", 4, 4, 13, 13, " in r["kernel"]:
+        tail = int(r["kernel"].split(",")[-1].split(">")[0]) if "ionode_dopri5_kernel<" in r["kernel"] else 0
+        if "ionode_dopri5_kernel<" in r["kernel"] and ", 4, 4, 13, 13, " in r["kernel"] and not (tail & 16):   # (TAIL & 16: the 4-trajectory tile, no asm stream)
             assert r["vgpr"] <= 512 and 92 <= r["agpr"] <= 256 and r["scratch_bytes"] == 0, r   # vgpr = unified VGPR + AGPR count
 
 

@@ -27,7 +27,7 @@ ap.add_argument("--model", default="hh", choices=["hh", "m6", "nnf"])
 ap.add_argument("--width", type=int, default=10, help="nnf: MLP width N")
 ap.add_argument("--layers", type=int, default=5, help="nnf: hidden layers L")
 ap.add_argument("--reps", type=int, default=3)
-ap.add_argument("--tpw", type=int, default=0, help="closed-form: trajectories per wavefront, 64 or 16 (0 = dispatcher default)")
+ap.add_argument("--tpw", type=int, default=0, help="trajectories per wavefront: closed-form 64 or 16, N <= 16 nets 64 or 1 (0 = dispatcher default)")
 ap.add_argument("--protocol-major", action="store_true", help="trajectories of one protocol adjacent (lanes of a wavefront share it)")
 ap.add_argument("--index-order", action="store_true", help="launch_order=None: trajectory b in launch slot b (default: the library's auto = protocol-major)")
 ap.add_argument("--stamps", action="store_true", help="library built with -DIONODE_STAMPS: print the phase cycles of wavefront 0")
