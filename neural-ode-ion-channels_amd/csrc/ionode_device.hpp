@@ -986,11 +986,11 @@ struct MlpTile4 {
   static constexpr int ACT = SLOTS * 16;             // float4 per activation buffer: [slot][q][trajectory]
   static constexpr size_t layer_floats() { return (size_t)4 * NT * 4 * 256 + (size_t)4 * 256; }   // fragments + bias float4 per (wave, lane)
   static __host__ __device__ constexpr size_t lds_bytes(int L) {
-    return ((size_t)2 * ACT + (size_t)2 * 4 * 16 + NP) * 16 + ((size_t)NP + 4) * 4;   // activations x2, partial sums x2, W0 rows, wl + bl
+    return ((size_t)2 * ACT + (size_t)2 * 4 * 16 + NP) * 16 + ((size_t)NP + 4) * 4 + (size_t)L * 64 * 16;   // activations x2, partial sums x2, W0 rows, wl + bl, accumulator starts [L][wave][block]
   }
   f32x4 ring[NT][4];
   f32x4 *Hs, *Ps;
-  const f32x4 *W0s;
+  const f32x4 *W0s, *B4s;
   const float *wlS;
   __amdgpu_buffer_rsrc_t rsrc;
   unsigned voff, sec0, lbytes;
@@ -1007,12 +1007,6 @@ struct MlpTile4 {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, lbase + (unsigned)n * 1024u, 0);
     return __builtin_bit_cast(f32x4, v);
   }
-  // accumulator start of this lane's block: {bias of row 0..3} (0 for the remainder chains w > 0), behind the layer's fragments
-  __device__ __forceinline__ f32x4 bias4(unsigned lbase) const {
-    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)(lane * 16), lbase + (unsigned)(4 * NT * 4 * 1024 + wave * 1024), 0);
-    return __builtin_bit_cast(f32x4, v);
-  }
   __device__ __forceinline__ void init(const KArgs &a, unsigned char *smem, int wave_, int lane_, int first_traj = 0) {
     L = a.L; wave = wave_; lane = lane_;
     const float *__restrict__ img = a.mlp + (a.traj_per_img > 0 ? (size_t)(first_traj / a.traj_per_img) * (size_t)a.mlp_stride : (size_t)0);
@@ -1026,7 +1020,15 @@ struct MlpTile4 {
     const float *wl = img + 4 * (size_t)NP + (size_t)L * ((size_t)4 * 43 * 256 + NP);
     for (int i = tid; i < NP + 4; i += 256) ws[i] = wl[i];
     W0s = w0; wlS = ws;
+    // accumulator starts of every layer and block (the four lanes of a block share them) into LDS: fetched from the image at the start
+    // of a layer they would cost an L2 round trip per layer on the critical path of a single trajectory
+    f32x4 *b4 = reinterpret_cast<f32x4 *>(ws + NP + 4);
     const size_t sec = section_off(L);
+    for (int i = tid; i < L * 64; i += 256) {
+      const int l = i >> 6, wv = (i >> 4) & 3, bb = i & 15;
+      b4[i] = *reinterpret_cast<const f32x4 *>(img + sec + (size_t)l * layer_floats() + (size_t)4 * NT * 4 * 256 + (size_t)wv * 256 + (size_t)bb * 16);
+    }
+    B4s = b4;
     const size_t img_bytes = (sec + (size_t)L * layer_floats()) * 4;
     rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(img), 0, (int)img_bytes, 0x00020000);
     sec0 = (unsigned)(sec * 4);
@@ -1058,6 +1060,7 @@ struct MlpTile4 {
   }
   __device__ __forceinline__ float eval(float x0, float x1) {
     const int j = lane & 3, b = lane >> 2, g = b >> 2, u = b & 3;
+    MSTAMP(0);  // slot 0: everything outside the MLP
     // layer 0: Linear(2, N) + LeakyReLU; the lane fills output block (kt, q) = (4 wave + b / 4, b % 4) of its trajectory
     {
       const int kq = 16 * wave + b;
@@ -1072,21 +1075,23 @@ struct MlpTile4 {
       }
     }
     __syncthreads();
+    MSTAMP(1);  // slot 1: layer 0 + barrier
     for (int l = 0; l < L; ++l) {
       f32x4 *__restrict__ Hin = Hs + (l & 1) * ACT;
       f32x4 *__restrict__ Hout = Hs + ((l + 1) & 1) * ACT;
       const f32x4 *__restrict__ Pin = Ps + (l & 1) * 64;
       f32x4 *__restrict__ Pout = Ps + ((l + 1) & 1) * 64;
       const int ln = (l + 1 < L) ? l + 1 : 0;   // the ring runs cyclically over the hidden stack (see MlpTile)
-      const unsigned lcur = sec0 + (unsigned)l * lbytes, lnext = sec0 + (unsigned)ln * lbytes;
+      const unsigned lnext = sec0 + (unsigned)ln * lbytes;
       // accumulators: D[i][j] = VGPR i: bias of row i of my block (the remainder chain w > 0 starts at 0: the image says so)
-      f32x4 acc = bias4(lcur);
+      f32x4 acc = B4s[(l * 4 + wave) * 16 + b];
       if (l > 0) fold_remainder(Hin, Pin);
       // this wavefront's walk: k-tile (s + wave) mod 13 = slot s + wave; B operands one step ahead of their use
       const f32x4 *__restrict__ Bw = Hin + (wave * 4) * 4 + j;
       f32x4 hn[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) hn[q] = Bw[q * 4];
+      MSTAMP(2);  // slot 2: layer prologue (accumulator start, remainder fold, first B reads issued)
 #pragma unroll
       for (int s = 0; s < NT; ++s) {
         f32x4 hq[4];
@@ -1107,6 +1112,7 @@ struct MlpTile4 {
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      MSTAMP(3);  // slot 3: the 13 x 16 MFMA walk
       if (g < 3) {
         f32x4 h;
 #pragma unroll
@@ -1116,6 +1122,7 @@ struct MlpTile4 {
         Pout[(wave * 4 + u) * 4 + j] = acc;   // partial chain `wave` of the remainder tile, pre-activation
       }
       __syncthreads();
+      MSTAMP(4);  // slot 4: LeakyReLU + store + layer barrier
     }
     // Linear(N, 1): chain q = b & 3 per lane (k = 16 kt + 4 q + r, kt ascending, r ascending), folded ((p0 + p1) + (p2 + p3)) + bl
     f32x4 *__restrict__ Hin = Hs + (L & 1) * ACT;
@@ -1132,6 +1139,7 @@ struct MlpTile4 {
     const float pair = part + __shfl_xor(part, 4);    // (p0 + p1) or (p2 + p3): lanes 4 apart hold neighbouring chains
     const float out = (pair + __shfl_xor(pair, 8)) + wlS[NP];
     __syncthreads();   // the next evaluation's layer 0 rewrites buffer 0; its partial sums reuse Ps
+    MSTAMP(5);  // slot 5: Linear(N, 1) + closing barrier
     return out;
   }
 };
@@ -2101,6 +2109,9 @@ __global__ void __launch_bounds__(64 * (IONODE_IS_LW(MODEL, RT) ? IONODE_LW_TILE
             }
           };
           const int slot = lane_e / PKL, kk = lane_e % PKL;
+          // (a software pipeline -- next pass's row and the entry after next in flight during this pass -- was measured: no gain, 35.9
+          // against 35.2 ms for the 2-state kernel, and 171 registers = two wavefronts per SIMD for the N = 10 kernel.  The phase stamps'
+          // long "emission" share is the stamped wavefront waiting while its two neighbours issue, not exposed latency.)
           for (int c0 = 0; c0 < C; c0 += 64 / PKL) {
             const bool has = c0 + slot < C;
             const unsigned e = clist[has ? c0 + slot : c0];   // (idle lane groups shadow the pass's first chunk, stores masked)

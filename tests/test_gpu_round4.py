@@ -82,3 +82,54 @@ def test_single_odeint_call_takes_the_small_tile(ion, gpu, oracle):
     o = oracle.solve(K.MODEL_NNF, K.MODELS["s1"][4], pv, K.NN_Y0, te, weights=K.load_weights("s1"), mlp_layers=5, mlp_width=200,
                      prot_t0=float(pt[0]), prot_dt=float(pt[1] - pt[0]), state_f32=True)
     assert np.array_equal(y[:, 0, :].double().cpu().numpy(), o["y"][0])
+
+
+@pytest.mark.parametrize("model,f32", [(K.MODEL_HH2, False), (K.MODEL_HH2, True), (K.MODEL_MARKOV6, False), (K.MODEL_MARKOV6, True)])
+@pytest.mark.parametrize("tpw", [64, 16])
+def test_work_list_emission_with_short_and_very_long_steps(ion, gpu, oracle, model, f32, tpw):
+    """The dense output of the lane-wise kernels is driven by a work list of 8-sample chunks; steps of more than 64 samples are emitted
+    by the whole wavefront.  Step protocols with long holds on a 1/16 ms output grid give both in one launch -- steps of 1 .. 3
+    samples right behind a voltage jump, steps of several hundred to > 1000 samples on the holds (two and more whole-wavefront
+    passes), trajectories that finish early -- in the lean variant (exact grid, states only), bit for bit against the oracle."""
+    rng = np.random.default_rng(17 + tpw + f32)
+    B = 150
+    D = 6 if model == K.MODEL_MARKOV6 else 2
+    base = K.P_M6 if model == K.MODEL_MARKOV6 else K.P_HH
+    params = np.tile(base, (B, 1)) * rng.uniform(0.7, 1.4, (B, base.size))
+    pv = np.stack([K.activation(v)[1][:601] for v in (-40, 20, 60)])
+    te = np.arange(0, 9601) * 0.0625   # (a binary fraction: the grid is exactly uniform, which the lean variant requires)
+    y0 = [0.0, 1.0] + [0.0] * (D - 2)
+    pot = rng.integers(0, 3, B).astype(np.int32)
+    kw = dict(prot_t0=0.0, prot_dt=1.0, prot_of_traj=pot)
+    o = oracle.solve(model, params, pv, y0, te, state_f32=f32, nthreads=8, **kw)
+    g = _kernel(ion, gpu, model, params, pv, y0, te, f32=f32, tile_waves=tpw, **kw)
+    assert ", 1, %d, 0, 0, 1>" % (0 if tpw == 64 else 16) in g["kernel"], g["kernel"]
+    steps = o["stats"][:, 0]
+    assert steps.min() < 9600 / 64          # some trajectory's average accepted step covers more than 64 output samples
+    assert np.array_equal(g["stats"], o["stats"]) and np.array_equal(g["y"], o["y"])
+    # ... and the same solve with the current trace (general / table variants) returns the same states
+    gi = _kernel(ion, gpu, model, params, pv, y0, te, f32=f32, tile_waves=tpw, current=True, obs_open_state_only=(D == 6), **kw)
+    assert np.array_equal(gi["y"], o["y"])
+
+
+def test_per_lane_net_with_several_weight_sets(ion, gpu, oracle):
+    """N = 10 at 64 trajectories per wavefront (MlpLane: weights as scalar operands) with traj_per_image = 64: every wavefront reads
+    its own image through the scalar cache; bit for bit one oracle run per weight set."""
+    rng = np.random.default_rng(5)
+    L, N, n_sets = 5, 10, 3
+    B = 64 * n_sets
+    ws = [rng.normal(0, 0.3, 2 * N + N + L * (N * N + N) + N + 1).astype(np.float32) for _ in range(n_sets)]
+    params = np.tile(K.P_HH, (B, 1)) * rng.uniform(0.9, 1.1, (B, 8))
+    pv = np.stack([K.atau(30)[1], K.atau(300)[1]])
+    te = K.atau(30)[2][:901]
+    pot = rng.integers(0, 2, B).astype(np.int32)
+    packed = torch.from_numpy(np.stack([ion.capi.mlp_pack(w, L, N) for w in ws])).to(gpu)
+    r = ion.capi.dopri5(K.MODEL_NNF, torch.from_numpy(params).to(gpu), torch.from_numpy(pv).to(gpu),
+                        torch.tensor([K.NN_Y0], dtype=torch.float64, device=gpu).repeat(B, 1).contiguous(), torch.from_numpy(te).to(gpu),
+                        mlp_packed=packed, mlp_layers=L, mlp_width=N, prot_t0=0.0, prot_dt=1.0,
+                        prot_of_traj=torch.from_numpy(pot).to(gpu), traj_per_image=64, tile_waves=64)
+    assert ", 1, 64, 1, 10, " in r["kernel"]
+    for k, w in enumerate(ws):
+        sl = slice(64 * k, 64 * (k + 1))
+        o = oracle.solve(K.MODEL_NNF, params[sl], pv, K.NN_Y0, te, weights=w, mlp_layers=L, mlp_width=N, prot_t0=0.0, prot_dt=1.0, prot_of_traj=pot[sl])
+        assert np.array_equal(r["y"][sl].cpu().numpy(), o["y"]) and np.array_equal(r["stats"][sl].cpu().numpy(), o["stats"])
