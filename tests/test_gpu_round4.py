@@ -133,3 +133,62 @@ def test_per_lane_net_with_several_weight_sets(ion, gpu, oracle):
         sl = slice(64 * k, 64 * (k + 1))
         o = oracle.solve(K.MODEL_NNF, params[sl], pv, K.NN_Y0, te, weights=w, mlp_layers=L, mlp_width=N, prot_t0=0.0, prot_dt=1.0, prot_of_traj=pot[sl])
         assert np.array_equal(r["y"][sl].cpu().numpy(), o["y"]) and np.array_equal(r["stats"][sl].cpu().numpy(), o["stats"])
+
+
+@pytest.mark.parametrize("L,N", [(5, 10), (2, 100), (1, 500)])
+def test_two_phase_sweep_equals_the_one_phase_sweep_at_other_widths(ion, gpu, L, N):
+    """the factored two-phase sweep (the default backward path) was only compared with the one-phase sweep at N = 200.
+    Widths 10, 100 and 500 (their own forward / backward tile kernels and reduce geometry), random nets, fp32 state:
+    dL/dW, dL/dp, dL/dy0 agree to fp32 rounding (1e-5; the checker's tolerance is 1e-4)."""
+    import importlib
+    import warnings
+    grad = importlib.import_module("neural-ode-ion-channels_amd.grad")
+    capi = ion.capi
+    B, Nt = 21, 2001
+    P = ion.protocols
+    pv = P.sinewave(P.sinewave_scales(0, B), n_samples=Nt, xp=torch, device=gpu)
+    te = torch.arange(0, Nt, 4, dtype=torch.float64, device=gpu) * 0.1
+    w0 = np.random.default_rng(N).normal(0, 0.1, 2 * N + N + L * (N * N + N) + N + 1).astype(np.float32)
+    got = {}
+    for tag, kw in (("one", dict(two_phase=False)), ("two", dict(two_phase=True))):
+        w = torch.from_numpy(w0.copy()).to(gpu).requires_grad_(True)
+        params = torch.from_numpy(np.tile(K.P_HH, (B, 1)) * np.random.default_rng(5).uniform(0.9, 1.1, (B, 8))).to(gpu).requires_grad_(True)
+        y0 = torch.tensor([[0.0, 1.0]], dtype=torch.float32, device=gpu).repeat(B, 1).requires_grad_(True)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            y, status = grad.solve(capi.MODEL_NNF, w, params, pv, y0, te, mlp_layers=L, mlp_width=N, prot_t0=0.0, prot_dt=0.1, **kw)
+        assert bool((status == 0).all())
+        (y[..., 0] * y[..., 1]).double().sum().backward()
+        got[tag] = (w.grad.clone(), params.grad.clone(), y0.grad.clone())
+    for a, b in zip(got["two"], got["one"]):
+        assert float((a.double() - b.double()).norm() / b.double().norm()) < 1e-5
+
+
+def test_two_phase_sweep_without_weight_gradients_over_several_packet_chunks(ion, gpu):
+    """weights that do NOT require a gradient and more than 256 accepted steps -- the branch of the two-phase sweep that keeps
+    no record stream, double-buffers the packets in chunks of <= 256 iterations and frees a buffer when the WALK (not a reduction) is
+    done with it.  dL/dp and dL/dy0 equal the one-phase sweep's bit for bit (the adjoint algebra does not depend on the chunking) and
+    the two-phase run WITH weight gradients."""
+    import importlib
+    import warnings
+    grad = importlib.import_module("neural-ode-ion-channels_amd.grad")
+    capi = ion.capi
+    B, Nt = 19, 20001
+    P = ion.protocols
+    pv = P.sinewave(P.sinewave_scales(3, B), n_samples=Nt, xp=torch, device=gpu)
+    te = torch.arange(0, Nt, 8, dtype=torch.float64, device=gpu) * 0.1
+    got = {}
+    for tag, wgrad, kw in (("two_nograd", False, dict(two_phase=True)), ("two_grad", True, dict(two_phase=True)), ("one_nograd", False, dict(two_phase=False))):
+        w = torch.from_numpy(K.load_weights("s1").copy()).to(gpu).requires_grad_(wgrad)
+        params = torch.from_numpy(np.tile(K.P_HH, (B, 1)) * np.random.default_rng(9).uniform(0.9, 1.1, (B, 8))).to(gpu).requires_grad_(True)
+        y0 = torch.tensor([[0.0, 1.0]], dtype=torch.float64, device=gpu).repeat(B, 1).requires_grad_(True)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            y, status = grad.solve(capi.MODEL_NNF, w, params, pv, y0, te, mlp_layers=5, mlp_width=200, prot_t0=0.0, prot_dt=0.1, **kw)
+        assert bool((status == 0).all())
+        (y[..., 0] * y[..., 1]).double().sum().backward()
+        got[tag] = (params.grad.clone(), y0.grad.clone())
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    for k in (0, 1):
+        assert rel(got["two_nograd"][k], got["one_nograd"][k]) < 1e-5, (k, rel(got["two_nograd"][k], got["one_nograd"][k]))
+        assert torch.equal(got["two_nograd"][k], got["two_grad"][k])   # same walk, with and without the record stream
