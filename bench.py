@@ -321,9 +321,11 @@ def closed_form_legs(ion, dev, weights):
                                         ("hh2_two_full_rounds_index_order", capi.MODEL_HH2, P_HH, [0.0, 1.0], 393216, None, False),
                                         # the 6-state model beyond two residency rounds: its two-wavefronts-per-SIMD build
                                         ("markov6_262144", capi.MODEL_MARKOV6, p_m6, [0.0, 1.0, 0, 0, 0, 0], 262144, None, False),
-                                        # 12 resident wavefronts per CU x 256 CUs x 64 trajectories = 196 608 per "round":
-                                        # 262 144 is 1.33 rounds (the last third runs on a third-full chip), 393 216 is 2.0
+                                        # rounds 2-3: 12 resident wavefronts per CU x 256 CUs x 64 trajectories = 196 608 per "round", 393 216
+                                        # two full rounds (the key keeps its name for the reviews' sake).  Since round 4 the lean 2-state kernel
+                                        # holds 16 per CU: 262 144 per round -- 393 216 is 1.5 rounds, 524 288 two
                                         ("hh2_two_full_rounds", capi.MODEL_HH2, P_HH, [0.0, 1.0], 393216, None, False),
+                                        ("hh2_524288", capi.MODEL_HH2, P_HH, [0.0, 1.0], 524288, None, False),
                                         ("markov6", capi.MODEL_MARKOV6, p_m6, [0.0, 1.0, 0, 0, 0, 0], 65536, None, False),
                                         ("nnf_s03_5x10", capi.MODEL_NNF, P_HH, [0.0, 1.0], 65536, (w10, L10, N10), False),
                                         # from 49 152 trajectories the N <= 16 nets run one trajectory per lane (64 per wavefront; N = 10: the per-lane vector-ALU net)

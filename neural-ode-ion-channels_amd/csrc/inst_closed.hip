@@ -5,7 +5,7 @@ namespace ionode {
 static const Variant kTab[] = {
     IONODE_VARIANT(1, double, 0, 1, 0, 0, 0, 0), IONODE_VARIANT(1, float, 1, 1, 0, 0, 0, 0),
     IONODE_VARIANT(1, double, 0, 1, 16, 0, 0, 0), IONODE_VARIANT(1, float, 1, 1, 16, 0, 0, 0),
-    // last parameter 1: states only on a verified uniform output grid (the lean variant; 2-state models: deferred aligned emission)
+    // last parameter 1: states only on a verified uniform output grid (the lean variant)
     IONODE_VARIANT(1, double, 0, 1, 0, 0, 0, 1), IONODE_VARIANT(1, float, 1, 1, 0, 0, 0, 1),
     IONODE_VARIANT(1, double, 0, 1, 16, 0, 0, 1), IONODE_VARIANT(1, float, 1, 1, 16, 0, 0, 1),
     // last parameter 2: current / objective epilogue through the protocol-at-outputs table (ionode_desc.v_at_outputs)

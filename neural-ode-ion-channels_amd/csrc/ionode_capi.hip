@@ -96,22 +96,19 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false, bool ex
     // 16 per wavefront / 9.7 at 64, 65 536: 11.6 / 10.1; 6-state 16 384: 9.1 / 13.8, 32 768: 17.5 / 15.0.  tile_waves = 64 / 16 forces a choice.
     const int tpw64_from = (D == 6) ? 24576 : 49152;
     const int tpw = (d->tile_waves == 64 || d->tile_waves == 16) ? d->tile_waves : (d->n_traj >= tpw64_from ? 64 : 16);
-    // deferred aligned emission (2-state models): the output grid must be VERIFIED uniform and no current trace requested
-    // ... or, with a current trace / fused objective and the protocol-at-outputs table given, the table variant (hint path)
     // The specialised variants are compiled under a CONTRACT (ionode_device.hpp, top of the kernel): uniform protocol grid, no step log,
     // no checkpoints -- anything else takes the general variant (TAIL slot 0).
     const bool lean_ok = !explicit_grid && !d->step_log && !d->ckpt;
-    //   1: states only on a VERIFIED uniform output grid (2-state models: deferred aligned emission)
+    //   1: the lean variant -- states only on a VERIFIED uniform output grid, no current trace / objective
     //   2: current trace / fused objective with the protocol-at-outputs table given (hint path)
-    const int defer = !lean_ok ? 0
+    const int tail = !lean_ok ? 0
                       : (want_current && d->v_at_outputs && d->t_eval_dt_hint > 0.0 && d->n_out > 1) ? 2
                       : ((d->t_eval_exact && d->t_eval_dt_hint > 0.0 && d->n_out > 1 && !want_current) ? 1 : 0);
     // (Rounds 2-3 kept two builds of the 2-state kernels -- 2 and 3 wavefronts per SIMD -- and switched at 2048 wavefronts; since round 4
-    // one build runs at three per SIMD without a spill: ionode_device.hpp IONODE_CF_WAVES.)
-    // 6-state model: one wavefront per SIMD (the whole register file) at every batch.
-    const int wslot = 0;
-    pl->v = find_variant(d->model, f32, 1, wslot, tpw == 64 ? 0 : 16, defer);
-    plan_lane_wise(pl, (size_t)((d->n_traj + tpw - 1) / tpw), (size_t)ionode::LwLds::bytes(D, defer == 1 && D == 2, f32 ? 4 : 8));   // (the deferred-emission LAYOUT is the 2-state kernels')
+    // one build per variant: the lean one fits four per SIMD, the others three, without a spill: ionode_device.hpp IONODE_WAVES_PER_SIMD.)
+    // 6-state model: two wavefronts per SIMD (lean), otherwise one.
+    pl->v = find_variant(d->model, f32, 1, 0, tpw == 64 ? 0 : 16, tail);
+    plan_lane_wise(pl, (size_t)((d->n_traj + tpw - 1) / tpw), (size_t)ionode::LwLds::bytes(D, tail));
   } else {
     if (d->mlp_width < 1 || d->mlp_layers < 0) { set_err("bad MLP shape"); return IONODE_ERR_ARG; }
     if (d->mlp_width <= 16 && d->mlp_layers > 10) { set_err("N <= 16 kernels keep at most 10 hidden layers resident"); return IONODE_ERR_UNSUPPORTED; }
@@ -127,8 +124,8 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false, bool ex
     // an explicit tile_waves = 64 with such a population is still an argument error, below)
     const bool img64 = d->traj_per_image <= 0 || d->traj_per_image % 64 == 0;
     const bool t64 = NT == 1 && (d->tile_waves == 64 || (d->tile_waves == 0 && d->n_traj >= IONODE_TINY64_FROM && img64));
-    // (deferred aligned emission as for the 2-state closed-form kernels: verified uniform output grid, no current / objective)
-    const int t64defer = (t64 && d->t_eval_exact && d->t_eval_dt_hint > 0.0 && d->n_out > 1 && !want_current && !explicit_grid && !d->step_log && !d->ckpt) ? 1 : 0;
+    // (the lean variant's contract as for the closed-form kernels: verified uniform output grid, no current / objective)
+    const int t64lean = (t64 && d->t_eval_exact && d->t_eval_dt_hint > 0.0 && d->n_out > 1 && !want_current && !explicit_grid && !d->step_log && !d->ckpt) ? 1 : 0;
     // N = 200: from two 16-trajectory tiles per compute unit on (8192 trajectories), 32-trajectory tiles -- two column sets per weight
     // fragment, the scalar integrator work replicated twice instead of four times (tile_waves = 8 forces it, 4 forces the 16-tile).
     // Needs a hidden layer (asm stream) and weight images that cover whole 32-trajectory tiles.
@@ -141,7 +138,7 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false, bool ex
                     (d->tile_waves == 2 || (d->tile_waves == 0 && d->n_traj <= IONODE_TILE4_UPTO));
     // N = 200 tiles: the lean variant when its contract holds (ionode_device.hpp LEANM)
     const bool leanm = !t64 && (NT == 13 || NT == 7 || NT == 32) && d->mlp_layers >= 1 && !explicit_grid && !d->step_log && !d->ckpt && d->t_eval_exact && d->t_eval_dt_hint > 0.0 && d->n_out > 1;
-    pl->v = t64 ? find_variant(d->model, f32, 1, NT, 64, t64defer, vnet ? 10 : 1)
+    pl->v = t64 ? find_variant(d->model, f32, 1, NT, 64, t64lean, vnet ? 10 : 1)
                 : find_variant(d->model, f32, ((d->tile_waves == 8 || d->tile_waves == 2) ? 4 : d->tile_waves), NT, NT == 1 ? 1 : -1, (t32 ? 4 : 0) | (leanm ? 8 : 0) | (t4 ? 16 : 0));
     if (!pl->v) {
       set_err("MLP width outside the compiled kernel variants: N must pad to 16, 112, 208 or 512 "
@@ -155,7 +152,7 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false, bool ex
     // the asm tile (N = 200): + scratch slot (+ the input exchange of the two-column-set tile), MlpTile::lds_total
     if (t4) pl->lds = ionode::MlpTile4::lds_bytes(d->mlp_layers);
     else if (Gv == 4 && NT == 13) pl->lds = t32 ? ionode::MlpTile<4, 4, 13, 13, 4>::lds_total(d->mlp_layers) : ionode::MlpTile<4, 4, 13, 13, 0>::lds_total(d->mlp_layers);
-    if (t64) plan_lane_wise(pl, (size_t)((d->n_traj + 63) / 64), (vnet ? (size_t)0 : ((pl->lds + 15) & ~(size_t)15)) + (size_t)ionode::LwLds::bytes(2, t64defer == 1, f32 ? 4 : 8));  // MlpTile region + the lane-wise region
+    if (t64) plan_lane_wise(pl, (size_t)((d->n_traj + 63) / 64), (vnet ? (size_t)0 : ((pl->lds + 15) & ~(size_t)15)) + (size_t)ionode::LwLds::bytes(2, t64lean));  // MlpTile region + the lane-wise region
   }
   if (!pl->v) { set_err("no kernel variant compiled for this descriptor"); return IONODE_ERR_UNSUPPORTED; }
   return IONODE_OK;
@@ -202,8 +199,9 @@ size_t ionode_mlp_packed_floats(int32_t L, int32_t N) {
   int G, RT;
   if (L < 0 || N < 1 || !tile_shape(N, &G, &RT)) return 0;
   const size_t NP = (size_t)np_of(N), NT = NP / 16;
-  // N <= 16: + the scalar section of the per-lane net (rows of RS floats: weights in the canonical k order, bias, pad)
-  const size_t scalar = (NT == 1) ? (size_t)L * (size_t)N * (size_t)((N + 1 + 3) & ~3) : 0;
+  // N <= 16: + the scalar section of the per-lane net (row PAIRS: layer 0, then per hidden layer the weights in the canonical k order, bias, pad)
+  const size_t npair = (size_t)(N + 1) / 2, pb = (size_t)((2 * (N + 1) + 3) & ~3);
+  const size_t scalar = (NT == 1) ? npair * 8 + (size_t)L * npair * pb : 0;
   // N = 200: + the section of the 4-trajectory tile (MlpTile4): its own fragment order and bias float4s
   const size_t tile4 = (NT == 13) ? (size_t)L * ionode::MlpTile4::layer_floats() : 0;
   return 4 * NP + (size_t)L * ((size_t)G * frags_per_wave((int)NT, G) * 256 + NP) + NP + 4 + scalar + tile4;
@@ -304,21 +302,36 @@ int ionode_mlp_pack(const float *w, int32_t L, int32_t N, float *out) {
     }
   }
   if (NT == 1) {
-    // scalar section (ionode_device.hpp MlpLane): hidden layer l, row j: W[j][k] for k = 4 q + r < N in the order r-major / q-minor
-    // (the order in which the 16 x 16 x 4 MFMA tile accumulates them), then the bias as bias + 0.0f (a -0 bias becomes +0: see MlpLane)
-    const int RS = (N + 1 + 3) & ~3;
+    // scalar section (ionode_device.hpp MlpLane), in row PAIRS (2 m, 2 m + 1) -- the two halves of a v_pk_fma_f32; an odd N's last
+    // pair has a zero second row.  Layer 0: {b0, b0'} {w00, w00'} {w01, w01'} {0, 0}.  Hidden layer l, pair m: {W[2m][k], W[2m+1][k]}
+    // for k = 4 q + r < N in the order r-major / q-minor (the order in which the 16 x 16 x 4 MFMA tile accumulates them), then the
+    // biases as bias + 0.0f (a -0 bias becomes +0: see MlpLane), pad to a multiple of 4 floats.
+    const int NPAIR = (N + 1) / 2, PB = (2 * (N + 1) + 3) & ~3;
     float *sc = dst + NP + 4;
+    for (int i = 0; i < NPAIR * 8 + L * NPAIR * PB; ++i) sc[i] = 0.0f;
+    for (int m = 0; m < NPAIR; ++m)
+      for (int e = 0; e < 2; ++e) {
+        const int j = 2 * m + e;
+        if (j >= N) continue;
+        sc[m * 8 + 0 + e] = b0[j];
+        sc[m * 8 + 2 + e] = W0[2 * j + 0];
+        sc[m * 8 + 4 + e] = W0[2 * j + 1];
+      }
+    float *sh = sc + NPAIR * 8;
     const float *lsrc = b0 + N;
     for (int l = 0; l < L; ++l) {
       const float *W = lsrc, *b = lsrc + (size_t)N * N;
-      for (int j = 0; j < N; ++j) {
-        float *row = sc + ((size_t)l * N + j) * RS;
-        int pos = 0;
-        for (int r = 0; r < 4; ++r)
-          for (int q = 0; q < 4; ++q)
-            if (4 * q + r < N) row[pos++] = W[(size_t)j * N + 4 * q + r];
-        row[N] = (N < 16) ? b[j] + 0.0f : b[j];
-      }
+      for (int m = 0; m < NPAIR; ++m)
+        for (int e = 0; e < 2; ++e) {
+          const int j = 2 * m + e;
+          if (j >= N) continue;
+          float *blk = sh + ((size_t)l * NPAIR + m) * PB;
+          int pos = 0;
+          for (int r = 0; r < 4; ++r)
+            for (int q = 0; q < 4; ++q)
+              if (4 * q + r < N) blk[2 * (pos++) + e] = W[(size_t)j * N + 4 * q + r];
+          blk[2 * N + e] = (N < 16) ? b[j] + 0.0f : b[j];
+        }
       lsrc += (size_t)N * N + N;
     }
   }

@@ -350,27 +350,29 @@ __device__ __forceinline__ int mbcnt(unsigned long long m, int acc = 0) {
 
 // LDS layout of the lane-wise kernels (one trajectory per lane: closed-form models and the N <= 16 nets at 64 per wavefront),
 // behind the MlpTile region when there is one.  Shared by the kernel and the host-side plan (ionode_capi.hip).
-//   rows   [64][ROWB]  a lane's interpolant: {t0, step length} {1/step, 8 spare bytes} {5 x D coefficients}; the deferred
-//                      aligned emission (TAIL == 1) appends {w, o, end, E} (cursors of the trajectory's emission, see `defer`)
-//   aux    tail buffers of the deferred emission [64][TAILB <= 48] -- or the fused objective's partial sums [64][8] fp64
-//   owp    [64] i32    deferred emission: next sample not yet in HBM; otherwise the lane's protocol index
-//   trl    [64] i32    the lane's trajectory index (not with the deferred emission: its rows carry it)
+//   rows   [64][ROWB]  a lane's interpolant: {t0, step length} {1/step, 8 spare bytes} {5 x D fp64 coefficients}
+//   aux    the fused objective's partial sums [64][8] fp64 (general and table variants; the lean variants sum no objective)
+//   owp    [64] i32    the lane's protocol index
+//   trl    [64] i32    the lane's trajectory index
 //   clist  [512] u16   the attempt's dense-output WORK LIST: one entry per 8-sample chunk {lane, 8 * chunk number}
-// gfx950 allocates LDS in 1280-byte granules and the 2-state kernels want 12 wavefronts per compute unit: <= 12 800 bytes.
+// gfx950 allocates LDS in 1280-byte granules; the lean 2-state kernels (<= 128 registers) want 16 wavefronts per compute unit:
+// <= 10 240 bytes, the others 12: <= 12 800.
+#ifndef IONODE_LEAN
+#define IONODE_LEAN 1   // 0: A/B build without the contract folding of the TAIL 1 / 2 / & 8 variants
+#endif
 struct LwLds {
-  // ss = sizeof(state scalar).  Deferred emission (2 states): coefficients kept in the state dtype; the four emission cursors of a
-  // trajectory live in their own array (row strides of 112 / 80 bytes spread consecutive rows over the LDS banks; 128-byte rows put
-  // every row on the same banks: measured 30 % of the LDS cycles in bank conflicts)
-  static __host__ __device__ constexpr int rowb(int D, bool defer, int ss) { return defer ? ((32 + 5 * D * ss + 15) & ~15) : (4 + 5 * D) * 8; }
-  static __host__ __device__ constexpr int cur_off(int D, bool defer, int ss) { return 64 * rowb(D, defer, ss); }
-  static __host__ __device__ constexpr int aux_off(int D, bool defer, int ss) { return cur_off(D, defer, ss) + (defer ? 64 * 16 : 0); }
-  static __host__ __device__ constexpr int aux_bytes(bool defer, int ss) { return (defer && ss == 8) ? 64 * 48 : 64 * 64; }
-  static __host__ __device__ constexpr int owp_off(int D, bool defer, int ss) { return aux_off(D, defer, ss) + aux_bytes(defer, ss); }
-  static __host__ __device__ constexpr int trl_off(int D, bool defer, int ss) { return owp_off(D, defer, ss) + 256; }
-  static __host__ __device__ constexpr int clist_off(int D, bool defer, int ss) { return trl_off(D, defer, ss) + (defer ? 0 : 256); }
-  static __host__ __device__ constexpr int bytes(int D, bool defer, int ss) { return clist_off(D, defer, ss) + 1024; }
+  // (D, tail): model states, the kernel's TAIL slot (0 general, 1 lean, 2 table).  Row stride (4 + 5 D) * 8 = 112 / 272 bytes:
+  // consecutive rows start on different LDS banks (128-byte rows put every row on the same banks: measured 30 % of the LDS
+  // cycles in bank conflicts).
+  static __host__ __device__ constexpr int rowb(int D) { return (4 + 5 * D) * 8; }
+  static __host__ __device__ constexpr int aux_off(int D) { return 64 * rowb(D); }
+  static __host__ __device__ constexpr int aux_bytes(int tail) { return (tail == 1 && IONODE_LEAN) ? 0 : 64 * 64; }
+  static __host__ __device__ constexpr int owp_off(int D, int tail) { return aux_off(D) + aux_bytes(tail); }
+  static __host__ __device__ constexpr int trl_off(int D, int tail) { return owp_off(D, tail) + 256; }
+  static __host__ __device__ constexpr int clist_off(int D, int tail) { return trl_off(D, tail) + 256; }
+  static __host__ __device__ constexpr int bytes(int D, int tail) { return clist_off(D, tail) + 1024; }
 };
-static_assert(LwLds::bytes(2, true, 8) <= 12800 && LwLds::bytes(2, true, 4) <= 12800 && LwLds::bytes(2, false, 8) <= 12800, "2-state kernels: 12 wavefronts per compute unit");
+static_assert(LwLds::bytes(2, 1) <= 10240 && LwLds::bytes(2, 0) <= 12800 && LwLds::bytes(2, 2) <= 12800, "2-state kernels: 16 / 12 wavefronts per compute unit");
 
 #ifndef IONODE_PK_SAMPLES
 #define IONODE_PK_SAMPLES 1
@@ -1085,7 +1087,6 @@ struct MlpTile4 {
       const unsigned lnext = sec0 + (unsigned)ln * lbytes;
       // accumulators: D[i][j] = VGPR i: bias of row i of my block (the remainder chain w > 0 starts at 0: the image says so)
       f32x4 acc = B4s[(l * 4 + wave) * 16 + b];
-      if (l > 0) fold_remainder(Hin, Pin);
       // this wavefront's walk: k-tile (s + wave) mod 13 = slot s + wave; B operands one step ahead of their use
       const f32x4 *__restrict__ Bw = Hin + (wave * 4) * 4 + j;
       f32x4 hn[4];
@@ -1097,6 +1098,9 @@ struct MlpTile4 {
         f32x4 hq[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) hq[q] = hn[q];
+        // the remainder fold rides in the walk: slot 12 is first read at step 9 (wavefront 3), and the dependent MFMA chain leaves most
+        // issue slots free (17 cycles per MFMA, 8 of them issue)
+        if (s == 2 && l > 0) fold_remainder(Hin, Pin);
         if (s + 1 < NT) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) hn[q] = Bw[((s + 1) * 4 + q) * 4];
@@ -1138,7 +1142,7 @@ struct MlpTile4 {
     }
     const float pair = part + __shfl_xor(part, 4);    // (p0 + p1) or (p2 + p3): lanes 4 apart hold neighbouring chains
     const float out = (pair + __shfl_xor(pair, 8)) + wlS[NP];
-    __syncthreads();   // the next evaluation's layer 0 rewrites buffer 0; its partial sums reuse Ps
+    if ((L & 1) == 0) __syncthreads();   // the next evaluation's layer 0 rewrites buffer 0, which an even stack's last layer reads (odd: buffer 1)
     MSTAMP(5);  // slot 5: Linear(N, 1) + closing barrier
     return out;
   }
@@ -1148,32 +1152,59 @@ struct MlpTile4 {
 // N = 10 nets (architectures s03-s05) at one trajectory per lane: the net evaluated PER LANE on the vector ALU, weights as
 // SCALAR operands.  The MFMA form of this path (MlpTile::eval_tiny64) spends 80 MFMAs = 2560 cycles per evaluation on 16 x 16
 // tiles of a 10 x 10 layer, gathers its inputs across lanes and keeps four accumulator tiles; per lane the net is 530 fmaf + 2 x 60
-// LeakyReLU operations = 2.6 k cycles with no cross-lane traffic, and ~25 registers instead of ~110.  Every weight is used by all 64
-// lanes at once, so it is read through the scalar cache (constant address space: s_load_dwordx8/x16) and enters v_fmac_f32 as its
+// LeakyReLU operations with no cross-lane traffic, and ~25 registers instead of ~110.  Every weight is used by all 64
+// lanes at once, so it is read through the scalar cache (constant address space: s_load_dwordx8/x16) and enters the FMA as its
 // one SGPR operand.  Same canonical order as the oracle / the MFMA tile with NT = 1:
 //   hidden row j:  acc = bias; for r = 0..3: for q = 0..3: k = 4 q + r < N: acc = fmaf(W[j][k], h[k], acc)
 //   Linear(N, 1):  part_q = 0; for r: k = 4 q + r < N: part_q = fmaf(wl[k], h[k], part_q); out = ((p0 + p1) + (p2 + p3)) + bl
 // The padded terms the tile executes (k >= N: fmaf(0, 0, acc)) are skipped: they return acc for every acc except -0, and an
 // accumulator can only be -0 if its bias is -0 (x + (-x) rounds to +0; +0 + -0 = +0), which ionode_mlp_pack rules out by writing
 // bias + 0.0f into this section (N < 16; the tile's own trailing padded term does the same to its result).
-// Image section (ionode_mlp_pack, behind wl / bl): L x N rows of RS = 12 floats {W[j][k] in the canonical k order, bias, pad}.
+// TWO ROWS PER INSTRUCTION: rows 2 m and 2 m + 1 run the same k sequence on the same inputs, so their chains are the two halves of
+// one v_pk_fma_f32 -- weights {W[2m][k], W[2m+1][k]} in an SGPR pair, h[k] broadcast from its half of the activation pair
+// (op_sel), accumulators in a VGPR pair: one exact fmaf per half, 4 cycles for both (gfx950's vector fp32 peak IS the packed rate).
+// A layer's output pair m = {h[2m], h[2m+1]} is the next layer's input pair.  The LeakyReLU multiply is packed as well.
+// Image section (ionode_mlp_pack, behind wl / bl): row pair m of layer 0: {b0, b0'} {w00, w00'} {w01, w01'} {0, 0}; then, per hidden
+// layer and row pair, PB floats: {W[2m][k], W[2m+1][k]} in the canonical k order, {bias, bias'}, pad.
 // ---------------------------------------------------------------------------------------------
-#ifndef IONODE_VNET_AHEAD
-#define IONODE_VNET_AHEAD 0   // 0 (default): every row waits for its own scalar loads.  1 or 4: a ring of AHEAD + 1 row buffers with the loads issued AHEAD rows early -- measured SLOWER (262 144 x 20 001: 46.3 ms at 0, 53.6 at 1, 55.3 at 4: the ring costs SGPRs, i.e. v_readlane traffic around each evaluation, and pins the schedule); kept for A/B
+#ifndef IONODE_VNET_PAIRS
+#define IONODE_VNET_PAIRS 2   // row pairs of a hidden layer evaluated together: their scalar loads are in flight at once (22 SGPRs per pair), their chains independent
 #endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// acc + w * h.lo / acc + w * h.hi in both halves (one fused multiply-add each); w: SGPR pair
+__device__ __forceinline__ f32x2 pk_fma_lo(f32x2 w, f32x2 h, f32x2 acc) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "s"(w), "v"(h));
+  return acc;
+}
+__device__ __forceinline__ f32x2 pk_fma_hi(f32x2 w, f32x2 h, f32x2 acc) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(w), "v"(h));
+  return acc;
+}
+__device__ __forceinline__ f32x2 lrelu2(f32x2 x) {
+  f32x2 t, h;
+  const f32x2 c = {0.01f, 0.01f};
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(t) : "v"(x), "s"(c));
+  float h0, h1;
+  asm("v_max_f32 %0, %1, %2" : "=v"(h0) : "v"(x.x), "v"(t.x));
+  asm("v_max_f32 %0, %1, %2" : "=v"(h1) : "v"(x.y), "v"(t.y));
+  h.x = h0; h.y = h1;
+  return h;
+}
 template <int N> struct MlpLane {
   static_assert(N == 10, "the per-lane net is instantiated for N = 10 (architectures s03-s05)");
   static constexpr int GW = 1;
   static constexpr int NP = 16;
-  static constexpr int RS = (N + 1 + 3) & ~3;   // floats per row of the scalar section
+  static constexpr int NPAIR = (N + 1) / 2;
+  static constexpr int PB = (2 * (N + 1) + 3) & ~3;   // floats per (layer, row pair) block of the scalar section
   typedef const float __attribute__((address_space(4))) cfloat;   // constant address space: uniform loads are scalar loads
+  typedef const f32x2 __attribute__((address_space(4))) cfloat2;
   const cfloat *img;   // the tile's packed image
   int L;
 #ifdef IONODE_STAMPS
   Stamps *sp;
 #endif
   static __host__ __device__ constexpr size_t lds_bytes(int) { return 0; }
-  static __host__ __device__ constexpr size_t scalar_floats(int L) { return (size_t)L * N * RS; }
+  static __host__ __device__ constexpr size_t scalar_floats(int L) { return (size_t)NPAIR * 8 + (size_t)L * NPAIR * PB; }
   __device__ __forceinline__ void init(const KArgs &a, unsigned char *, int, int, int first_traj = 0) {
     L = a.L;
     const float *g = a.mlp + (a.traj_per_img > 0 ? (size_t)(first_traj / a.traj_per_img) * (size_t)a.mlp_stride : (size_t)0);
@@ -1188,64 +1219,42 @@ template <int N> struct MlpLane {
     return -1;
   }
   __device__ __forceinline__ float eval_tiny64(float x0, float x1) {
-    float h[N];
-    const cfloat *w0 = img;                       // [NP][4] {b0, w00, w01, 0}
-#pragma unroll
-    for (int j = 0; j < N; ++j) h[j] = lrelu(fmaf(w0[4 * j + 2], x1, fmaf(w0[4 * j + 1], x0, w0[4 * j + 0])));
     constexpr size_t lstride = (size_t)256 + NP;  // MlpTile<1, 1, 1, 1>::layer_floats(): one fragment + bias[NP]
     const cfloat *wl = img + 4 * NP + (size_t)L * lstride;   // wl[NP], bl, 3 pad
-    const cfloat *ws = wl + NP + 4;               // the scalar section
-    // Hidden layers.  A row's 11 scalars (10 weights in the canonical k order + bias) are loaded IONODE_VNET_AHEAD rows ahead of their
-    // use into a ring of AHEAD + 1 row buffers: scalar loads return out of order, so every wait is lgkmcnt(0) -- the wait for row r is
-    // therefore placed BEFORE the loads of row r + AHEAD are issued (an empty asm consumes one scalar of row r), and those loads then
-    // fly during the vector work of rows r .. r + AHEAD - 1.  With one wavefront per SIMD (launches below ~200 k trajectories) nothing
-    // else hides the scalar-cache latency; without the ring a row costs ~4x its 13 vector instructions.
-    constexpr int AH = IONODE_VNET_AHEAD > 0 ? IONODE_VNET_AHEAD : 1, NB = AH + 1;
-    static_assert(N % NB == 0, "the ring position of a row must not depend on the layer");
-    if constexpr (IONODE_VNET_AHEAD == 0) {
-      for (int l = 0; l < L; ++l) {   // (A/B: every row waits for its own scalar loads)
-        float g[N];
+    const cfloat2 *s0 = reinterpret_cast<const cfloat2 *>(wl + NP + 4);   // the scalar section: layer 0 ...
+    const cfloat2 *sh = s0 + NPAIR * 4;                                    // ... and the hidden layers
+    f32x2 h[NPAIR];
+    {
+      const f32x2 xx = {x0, x1};
 #pragma unroll
-        for (int j = 0; j < N; ++j) {
-          const cfloat *row = ws + ((size_t)l * N + j) * RS;
-          float acc = row[N];
-#pragma unroll
-          for (int pos = 0; pos < N; ++pos) acc = fmaf(row[pos], h[k_at(pos)], acc);
-          g[j] = lrelu(acc);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int j = 0; j < N; ++j) h[j] = g[j];
-      }
-    } else {
-    const int rows = L * N;
-    float wb[NB][RS];
-    auto load_row = [&](int r, float (&dst)[RS]) {
-      const cfloat *row = ws + (size_t)r * RS;
-#pragma unroll
-      for (int e = 0; e <= N; ++e) dst[e] = row[e];
-    };
-#pragma unroll
-    for (int r = 0; r < AH; ++r)
-      if (r < rows) load_row(r, wb[r % NB]);
-    for (int l = 0; l < L; ++l) {
-      float g[N];
-#pragma unroll
-      for (int j = 0; j < N; ++j) {
-        const int r = l * N + j;
-        asm volatile("" :: "s"(wb[j % NB][N]));          // row r is needed now: the wait lands here ...
-        __builtin_amdgcn_sched_barrier(0);
-        if (r + AH < rows) load_row(r + AH, wb[(j + AH) % NB]);   // ... and only then the loads of row r + AHEAD are issued
-        __builtin_amdgcn_sched_barrier(0);
-        float acc = wb[j % NB][N];
-#pragma unroll
-        for (int pos = 0; pos < N; ++pos) acc = fmaf(wb[j % NB][pos], h[k_at(pos)], acc);
-        g[j] = lrelu(acc);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#pragma unroll
-      for (int j = 0; j < N; ++j) h[j] = g[j];
+      for (int m = 0; m < NPAIR; ++m) h[m] = lrelu2(pk_fma_hi(s0[4 * m + 2], xx, pk_fma_lo(s0[4 * m + 1], xx, s0[4 * m + 0])));
     }
+    constexpr int GP = IONODE_VNET_PAIRS;
+    for (int l = 0; l < L; ++l) {
+      f32x2 g[NPAIR];
+#pragma unroll
+      for (int m0 = 0; m0 < NPAIR; m0 += GP) {
+        // a group's scalar loads are issued together (one wait); its chains are independent of each other (a lone dependent
+        // chain stalls a SIMD that holds few wavefronts)
+#pragma unroll
+        for (int u = 0; u < GP; ++u)
+          if (m0 + u < NPAIR) g[m0 + u] = sh[((size_t)l * NPAIR + m0 + u) * (PB / 2) + N];
+#pragma unroll
+        for (int pos = 0; pos < N; ++pos)
+#pragma unroll
+          for (int u = 0; u < GP; ++u)
+            if (m0 + u < NPAIR) {
+              const f32x2 w = sh[((size_t)l * NPAIR + m0 + u) * (PB / 2) + pos];
+              const int k = k_at(pos);
+              g[m0 + u] = (k & 1) ? pk_fma_hi(w, h[k >> 1], g[m0 + u]) : pk_fma_lo(w, h[k >> 1], g[m0 + u]);
+            }
+#pragma unroll
+        for (int u = 0; u < GP; ++u)
+          if (m0 + u < NPAIR) g[m0 + u] = lrelu2(g[m0 + u]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int m = 0; m < NPAIR; ++m) h[m] = g[m];
     }
     float part[4];
 #pragma unroll
@@ -1253,7 +1262,7 @@ template <int N> struct MlpLane {
       part[q] = 0.0f;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (4 * q + r < N) part[q] = fmaf(wl[4 * q + r], h[4 * q + r], part[q]);
+        if (4 * q + r < N) part[q] = fmaf(wl[4 * q + r], h[(4 * q + r) >> 1][(4 * q + r) & 1], part[q]);
     }
     return ((part[0] + part[1]) + (part[2] + part[3])) + wl[NP];
   }
@@ -1348,15 +1357,36 @@ __device__ __forceinline__ void rhs(const KArgs &a, const double *p, double v, b
     // (the 4-trajectory tile keeps a 208-register weight ring: the branchy form with one exp in flight, same bits)
     constexpr bool TIGHT = std::is_same<MLP, MlpTile4>::value;
     auto dexp = [](double x) { if constexpr (TIGHT) return det_exp_ldexp(x); else if constexpr (MT::MLP && !WIDE) return det_exp_s(x); else return det_exp(x); };
-    const double k3 = p[4] * dexp(p[5] * v);
-    const double k4 = p[6] * dexp(-p[7] * v);
-    const double drdt = -k3 * (double)rv + k4 * (double)one_m_r;
-    double dadt = 0.0;
-    if constexpr (HAS_HH_A) {
-      const double k1 = p[0] * dexp(p[1] * v);
-      const double k2 = p[2] * dexp(-p[3] * v);
-      dadt = k1 * (double)one_m_a - k2 * (double)av;
+    double k3, k4, dadt = 0.0;
+    if constexpr (MT::MLP && WIDE) {
+      // one trajectory per lane (N <= 16): the closed-form kernels' exp -- addend constants as scalar operands, one v_ldexp_f64, and
+      // the three range cases skipped when every lane's arguments are in range (closed_rates); same operations, same bits
+      constexpr int NX = HAS_HH_A ? 4 : 2;
+      double x[NX], e[NX];
+      x[0] = p[5] * v; x[1] = -p[7] * v;
+      if constexpr (HAS_HH_A) { x[2] = p[1] * v; x[3] = -p[3] * v; }
+      bool in = true;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) in = in && (__builtin_fabs(x[i]) <= 708.0);
+      if (__ballot(!in) == 0ull) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) e[i] = det_exp_inrange(x[i]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) e[i] = det_exp_ldexp(x[i]);
+      }
+      k3 = p[4] * e[0]; k4 = p[6] * e[1];
+      if constexpr (HAS_HH_A) dadt = (p[0] * e[2]) * (double)one_m_a - (p[2] * e[3]) * (double)av;
+    } else {
+      k3 = p[4] * dexp(p[5] * v);
+      k4 = p[6] * dexp(-p[7] * v);
+      if constexpr (HAS_HH_A) {
+        const double k1 = p[0] * dexp(p[1] * v);
+        const double k2 = p[2] * dexp(-p[3] * v);
+        dadt = k1 * (double)one_m_a - k2 * (double)av;
+      }
     }
+    const double drdt = -k3 * (double)rv + k4 * (double)one_m_r;
     if constexpr (MT::MLP) dadt = (MODEL == IONODE_MODEL_NND) ? dadt + (double)net : (double)net;
     f[0] = (S)dadt;
     f[1] = (S)drdt;
@@ -1447,10 +1477,11 @@ template <typename S, int D> __device__ __forceinline__ S rms_norm(const S *x) {
 template <typename S> __device__ __forceinline__ S abs_(S x) { return x < 0 ? -x : x; }
 
 // Wavefronts per SIMD asked of hipcc (__launch_bounds__).  2-state closed-form kernels: TWO -- a 256-register budget, of which hipcc
-// uses 147-157 (round 4: constants as scalar operands, lane- and parameter-derived invariants kept out of the attempt loop), so the
-// hardware runs THREE per SIMD (<= 168 registers) without a spill; asked for three, hipcc's scheduler fills the 168 and spills 2-6
-// registers to scratch.  6-state: ONE wavefront per SIMD (the whole register file): at 2 per SIMD it spilled 48 dwords into scratch
-// inside the stage loop and ran 1.6x (65 536 trajectories) to 2x (16 384) slower.  MLP tiles: 1 per SIMD.
+// uses 118 (lean variant: FOUR resident per SIMD), 125-131 (table variant) or 150-158 (general: three per SIMD) -- round 4: constants
+// as scalar operands, lane- and parameter-derived invariants kept out of the attempt loop, plain work-list emission; asked for three,
+// hipcc's scheduler fills the 168 and spills 2-6 registers to scratch.  6-state: ONE (the whole register file; the lean variant
+// comes out at 232 -- two resident per SIMD): asked for two, the general variant spilled 48 dwords into scratch inside the stage loop
+// and ran 1.6x (65 536 trajectories) to 2x (16 384) slower.  MLP tiles: 1 per SIMD.
 #ifndef IONODE_M6_WAVES
 #define IONODE_M6_WAVES 1
 #endif
@@ -1502,9 +1533,6 @@ __global__ void __launch_bounds__(64 * (IONODE_IS_LW(MODEL, RT) ? IONODE_LW_TILE
   //   TAIL == 1 of a lane-wise kernel (LEAN): uniform protocol grid, VERIFIED uniform output grid, states only (no current trace, no
   //                fused objective), no step log, no checkpoints
   //   TAIL == 2 of a closed-form kernel (table variant): uniform protocol grid, no step log, no checkpoints
-#ifndef IONODE_LEAN
-#define IONODE_LEAN 1   // 0: A/B build without the contract folding
-#endif
   constexpr bool LEAN = IONODE_LEAN && (!MT::MLP || RT == 64) && TAIL == 1;
   constexpr bool LEANT = IONODE_LEAN && !MT::MLP && TAIL == 2;
   //   TAIL & 8 of an MLP tile kernel: uniform protocol grid, VERIFIED uniform output grid, no step log, no checkpoints (states,
@@ -1523,8 +1551,8 @@ __global__ void __launch_bounds__(64 * (IONODE_IS_LW(MODEL, RT) ? IONODE_LW_TILE
   // (16: lanes replicated 4x) for small batches, where 4x more wavefronts matter more than lane efficiency
   // N <= 16 nets also at 64 per wavefront: RT slot == 64 of an MLP kernel (MlpTile::eval_tiny64).  Such a kernel is
   // "lane-wise" (LW) like the closed-form ones -- one trajectory per lane -- and shares their dense-output machinery:
-  // interpolant rows in LDS (behind the MlpTile region), arithmetic output times, carried stage voltages, deferred aligned
-  // emission (TAIL == 1).
+  // interpolant rows in LDS (behind the MlpTile region), arithmetic output times, carried stage voltages, work-list
+  // emission.
   constexpr bool T64 = MT::MLP && RT == 64;
   static_assert(!T64 || (G == 1 && NT == 1), "64 trajectories per wavefront is the resident-weights (N <= 16) path");
   constexpr bool LW = !MT::MLP || T64;
@@ -1548,6 +1576,12 @@ __global__ void __launch_bounds__(64 * (IONODE_IS_LW(MODEL, RT) ? IONODE_LW_TILE
   // protocol-major launch order deals the protocols out per XCD on that assumption): workgroup b, wavefront w -> tile (b % 8) + 8 (4 (b / 8) + w)
   const int tile = LW ? (int)((blockIdx.x & 7u) + 8u * ((blockIdx.x >> 3) * (unsigned)IONODE_LW_TILES_PER_WG + (unsigned)wgw)) : (int)blockIdx.x;
   unsigned char *const smem_t = LW ? smem + (size_t)wgw * (size_t)a.lw_bytes : smem;
+  if constexpr (LW) {
+    // the grid is rounded up to whole workgroups on every XCD: a tile past the batch leaves at once (it has no trajectory, and with
+    // several weight images no image: its index would point past the caller's array).  No barrier joins the tiles of a lane-wise
+    // workgroup after this point except MlpTile::init's, which the hardware completes without the wavefronts that have ended.
+    if (tile * (MT::MLP ? 64 : (RT > 0 ? RT : 64)) >= a_in.B) return;
+  }
   const int j = lane % LPS;
   const int cset = (NSETS > 1) ? wave / WPS : 0, wis = wave % WPS;  // column set of this wavefront, wavefront index inside the set
   const bool primary = (lane < LPS) && (wis == 0);  // the replica that writes per-trajectory scalars
@@ -1632,57 +1666,42 @@ __global__ void __launch_bounds__(64 * (IONODE_IS_LW(MODEL, RT) ? IONODE_LW_TILE
     if (dt > a.dt_max) dt = a.dt_max;
   }
 
-  // ---- closed-form kernels, 2 states, exact uniform output grid, no current trace: "deferred aligned emission" ----
+  // ---- lane-wise kernels: where the dense output goes through ----
   // gfx9 counts loads and stores in ONE in-order counter (vmcnt): a load issued behind a store cannot be consumed before that
   // store has been acknowledged by L2 -- for a store to a cold line that is an HBM round trip.  The round-1 emission loop
   // loaded t_eval once per 64-sample chunk behind the previous chunk's store, and the stage voltages of the next attempt
-  // behind all of them: waves sat in s_waitcnt 82 % of the time (SQ_WAIT_ANY, profiles/r02_closed_form.md).  Here
-  //   * output times are formed arithmetically (te_exact), the next attempt's protocol lookups are issued and consumed BEFORE
-  //     the emission, so the emission is LDS reads + VALU + stores only and nothing waits on a store;
-  //   * stores are whole 64-byte sectors inside 1 KiB-aligned blocks of the row: samples behind the last sector boundary wait
-  //     in an LDS tail buffer (< 4 samples per trajectory in fp64) for the next step -- no partial-sector write, no
-  //     read-for-ownership.  (64 B, not the 128-B line: 8 KiB of LDS per wavefront instead of 14 keeps 12 wavefronts per CU.)
+  // behind all of them: waves sat in s_waitcnt 82 % of the time (SQ_WAIT_ANY, profiles/r02_closed_form.md).  On a verified
+  // uniform output grid (te_exact) output times are formed arithmetically and the next attempt's protocol lookups are issued
+  // and consumed BEFORE the emission, so the emission is LDS reads + VALU + stores only and nothing waits on a store.
+  // (Rounds 2-3 also held samples back in LDS tail buffers until a whole 64-byte sector could be written; L2 merges the partial
+  // sectors of neighbouring steps on its own, and without the tail logic the lean 2-state kernel fits 128 registers and
+  // 8.5 KiB of LDS -- four wavefronts per SIMD instead of three: 35.6 -> 30.5 ms at 393 216 x 20 001, profiles/r04_emission_ab.md.)
   constexpr bool CF2 = LW && D == 2;
-  constexpr int LS = 64 / (D * (int)sizeof(S));                      // samples per 64-byte sector, the unit of an L2 -> HBM
-                                                                     // write request (TCC_EA0_WRREQ_64B): D == 2: 4 or 8
-  constexpr int TAILB = (((LS - 1) * D * (int)sizeof(S)) + 15) & ~15;  // bytes of one trajectory's tail buffer
-  // compile-time variant (template parameter TAIL == 1 of a closed-form kernel); the dispatcher selects it only when
-  // te_dt > 0, te_exact and i_out == NULL hold (ionode_capi.hip)
-  constexpr bool defer = CF2 && TAIL == 1;
-  constexpr int SS = (int)sizeof(S);
-  constexpr int ROWB = LwLds::rowb(D, defer, SS);
-  int4 *const curs = reinterpret_cast<int4 *>(lsm + LwLds::cur_off(D, defer, SS));   // deferred emission: {w, o, end, E} of every lane's trajectory
+  constexpr int LT = MT::MLP ? (TAIL == 1 ? 1 : 0) : TAIL;   // the LDS layout's variant key (MLP kernels at 64 per wavefront: lean or general)
+  constexpr int ROWB = LwLds::rowb(D);
   // TAIL == 2 of a closed-form kernel: the current / objective epilogue reads V(t_k) from the pre-pass table a.v_tab (selected
   // by the dispatcher when ionode_desc.v_at_outputs is given); a compile-time variant so that neither variant carries the
   // other's code and registers
   constexpr bool VTAB = !MT::MLP && TAIL == 2;
-  unsigned char *const tails = lsm + LwLds::aux_off(D, defer, SS);
-  double *const ssep = reinterpret_cast<double *>(tails);  // [64][8] partial sums of the fused objective (never together with defer)
+  double *const ssep = reinterpret_cast<double *>(lsm + LwLds::aux_off(D));  // [64][8] partial sums of the fused objective (not in the lean variants)
   if constexpr (LW) {
     if (a.sse_out != nullptr) {
 #pragma unroll
       for (int m = 0; m < 8; ++m) ssep[lane * 8 + m] = 0.0;
     }
   }
-  // defer: owp[j] = next sample index of trajectory j not yet written to HBM (owp <= oi, oi - owp < LS); otherwise the lane's
-  // protocol index.  trl: trajectory index of every lane (the deferred emission keeps it in the row).  clist: the work list.
-  int *const owp = reinterpret_cast<int *>(lsm + LwLds::owp_off(D, defer, SS));
-  int *const trl = reinterpret_cast<int *>(lsm + LwLds::trl_off(D, defer, SS));
-  unsigned short *const clist = reinterpret_cast<unsigned short *>(lsm + LwLds::clist_off(D, defer, SS));
-  if constexpr (LW && !defer) { if (lane < LPS) trl[lane] = traj; }
-  if constexpr (LW && !defer) {
-    if (lane < LPS) owp[lane] = pidx;   // packed emission: the trajectory's protocol index, read per lane group
-  }
-  if constexpr (defer) {
-    static_assert(64 * TAILB <= LwLds::aux_bytes(true, SS), "tail buffers fit the reserved region");
-    if (lane < LPS) owp[lane] = 0;
-    if (valid && lane < LPS) *reinterpret_cast<S *>(tails + lane * TAILB) = y[0], *(reinterpret_cast<S *>(tails + lane * TAILB) + 1) = y[1];
+  // owp: protocol index of every lane's trajectory, trl: its trajectory index (read per lane group by the emission).  clist: the work list.
+  int *const owp = reinterpret_cast<int *>(lsm + LwLds::owp_off(D, LT));
+  int *const trl = reinterpret_cast<int *>(lsm + LwLds::trl_off(D, LT));
+  unsigned short *const clist = reinterpret_cast<unsigned short *>(lsm + LwLds::clist_off(D, LT));
+  if constexpr (LW) {
+    if (lane < LPS) trl[lane] = traj, owp[lane] = pidx;
   }
   auto te_at = [&](int idx) -> double { return a.te_t0 + (double)idx * a.te_dt; };
 
-  // solution[0] = y0  (deferred emission: it waits in the tail buffer for its line)
+  // solution[0] = y0
   double sse = 0.0;  // fused objective: this lane's trajectory (accumulated by the owner wavefront's replica lanes)
-  if (valid && primary && !(CF2 && defer)) {
+  if (valid && primary) {
     if (a.y_out) store_state<S, D>(yout, y);
     if (iout) {
       double v0;
@@ -1711,7 +1730,7 @@ __global__ void __launch_bounds__(64 * (IONODE_IS_LW(MODEL, RT) ? IONODE_LW_TILE
   const S nan_s = (S)__builtin_nan("");
 
   // stage voltages of the coming attempt: pure functions of (t, dt).  Closed-form kernels carry them across iterations: they
-  // are looked up for the NEXT attempt right after the controller, ahead of the emission's stores (see `defer` above)
+  // are looked up for the NEXT attempt right after the controller, ahead of the emission's stores (see "where the dense output goes through" above)
   double vst[5];
   bool inst[5];
   auto lookup_stages = [&](double tt, double dd) {
@@ -1928,16 +1947,6 @@ __global__ void __launch_bounds__(64 * (IONODE_IS_LW(MODEL, RT) ? IONODE_LW_TILE
         row[0] = make_double2(t0, den);
         row[1] = make_double2(rden, 0.0);
         static_assert(D % 2 == 0, "rows hold component pairs");
-        if constexpr (defer) {
-          // deferred emission: coefficients stay in the state dtype (fp32 state: 96-byte rows, five LDS reads per chunk)
-          using S2 = typename std::conditional<SS == 8, double2, float2>::type;
-          S ca[5], cb2[5];
-          fit(0, ca);
-          fit(1, cb2);
-          S2 *cr = reinterpret_cast<S2 *>(lsm + lane * ROWB + 32);
-#pragma unroll
-          for (int c = 0; c < 5; ++c) { S2 v2; v2.x = ca[c]; v2.y = cb2[c]; cr[c] = v2; }
-        } else
 #pragma unroll
         for (int d = 0; d < D; d += 2) {
           S ca[5], cb2[5];
@@ -1967,7 +1976,9 @@ __global__ void __launch_bounds__(64 * (IONODE_IS_LW(MODEL, RT) ? IONODE_LW_TILE
       if (acc_now) {
         const double gf = floor((t1 - a.te_t0) * a.te_rdt);  // a guess: verified below
         long long g = (gf < (double)(oi - 1)) ? (long long)(oi - 1) : ((gf > (double)(Nt - 1)) ? (long long)(Nt - 1) : (long long)gf);
-        if ((CF2 && defer) || (!LW && a.te_exact)) {  // verified uniform output grid: t_k is formed arithmetically, no load
+        // lean lane-wise kernels: the 6-state one verifies its cursor against arithmetic times too (262 144 x 20 001: 76.1 -> 72.1 ms);
+        // the 2-state ones keep the load -- the two scalars cost them 24 spilled SGPRs (393 216: 31.1 -> 38.0 ms)
+        if ((LW && LEAN && D > 2) || (!LW && a.te_exact)) {  // verified uniform output grid: t_k is formed arithmetically, no load
           while (g >= oi && te_at((int)g) > t1) --g;
           while (g + 1 < Nt && te_at((int)g + 1) <= t1) ++g;
         } else {
@@ -1977,161 +1988,7 @@ __global__ void __launch_bounds__(64 * (IONODE_IS_LW(MODEL, RT) ? IONODE_LW_TILE
         n_out = (int)(g - oi + 1);
       }
       STAMP(stamps_, 9);  // slot 9: output cursor
-      if constexpr (CF2 && defer) {
-        // ---- deferred aligned emission (lane-wise kernels, D == 2): whole 64-byte sectors, driven by a WORK LIST of 8-sample chunks ----
-        // Steps differ wildly in the number of output samples they cover (sine-wave legs: 10 % of the accepted steps cover <= 5
-        // samples, the median 39, 10 % >= 170).  Round 3 handed each group of 8 lanes one emitting trajectory at a time and ran a
-        // pass until the longest of its 8 trajectories was done: 78 iterations per attempt where 36 would do (a CPU replay of the
-        // step logs of one wavefront), and the dense output was 72 % of the kernel (phase stamps).  Round 4: every emitting lane
-        // appends its trajectory's chunks {lane, 8 * chunk number} to a list in LDS (offsets from a ballot-plane prefix sum); a pass
-        // takes the next 8 list entries, one per group of 8 lanes, whatever trajectories they belong to.  A lane reads what used to be
-        // wave-uniform per trajectory (interpolant, cursors, trajectory index) from the owner's LDS row.  Steps of more than 8 chunks
-        // are emitted by the whole wavefront, 64 consecutive samples per pass.  Same samples, same arithmetic, same sector-aligned
-        // stores (a chunk = 8 consecutive samples from an 8-sample-aligned position = 1-2 whole sectors).
-        // Round 4b: with one sample per lane and pass, every lane re-read its trajectory's 96-128-byte row per sample and the LDS pipe
-        // (128 B / clk / CU, 12 wavefronts) became the bound.  A chunk is now served by PKL = 4 lanes x NSL = 2 samples each (lane kk:
-        // samples kk and kk + 4 of the chunk, so every store instruction still writes whole runs of 4 consecutive samples): half the
-        // LDS bytes and half the per-entry overhead per sample, 16 chunks per pass.  The two samples of a lane are evaluated as a
-        // 2-vector: v_pk_mul_f32 / v_pk_add_f32 for fp32 state (separate multiply and add, as the canonical arithmetic demands).
-#ifndef IONODE_DEFER_PKL
-#define IONODE_DEFER_PKL 4   // lanes per 8-sample chunk (8: one sample per lane)
-#endif
-        constexpr int PK = 8, NCH_MAX = 8, PKL = IONODE_DEFER_PKL, NSL = PK / PKL;
-        static_assert(PK % LS == 0 && 64 % PKL == 0, "a chunk is made of whole sectors");
-        using S2 = typename std::conditional<SS == 8, double2, float2>::type;
-        typedef S SV __attribute__((ext_vector_type(NSL)));
-        // an opaque per-attempt copy of the lane id: everything derived from it below (row / tail / list addresses, list entries, group and
-        // sample numbers) is then computed here, per attempt, instead of being hoisted out of the attempt loop into a dozen VGPRs that stay
-        // live through the stage loop (the three-per-SIMD builds have 168)
-        int lane_e = lane;
-        asm volatile("" : "+v"(lane_e));
-        const bool em_lane = n_out > 0 && lane_e < LPS;
-        const unsigned long long emd = __ballot(em_lane);
-        if (emd) {
-          int nch = 0, E_own = 0;
-          if (em_lane) {
-            const int w = owp[lane_e], endx = oi + n_out;
-            const long long G0 = (long long)traj * Nt;  // global sample index of the row's first sample
-            int E = Nt;                                  // samples [w, E) go to HBM now, [E, end) wait in the tail buffer
-            if (endx < Nt) {
-              E = (int)(((G0 + endx) & ~(long long)(LS - 1)) - G0);
-              if (E < w) E = w;
-            }
-            const int b0 = (int)(((G0 + w) & ~(long long)(PK - 1)) - G0);   // first chunk: the aligned block that holds sample w
-            nch = (endx - b0 + PK - 1) / PK;
-            E_own = E;
-            *reinterpret_cast<int2 *>(lsm + lane_e * ROWB + 24) = make_int2(b0, traj);       // the row's spare slot
-            curs[lane_e] = make_int4(w, oi, endx, E);
-          }
-          // work list of the short steps: exclusive prefix sum of the chunk counts (1 .. 8) over the lanes, from ballots of the
-          // three bit planes of nch - 1 -- no cross-lane data movement
-          const bool shortl = em_lane && nch <= NCH_MAX;
-          const int x = nch - 1;
-          const unsigned long long ms = __ballot(shortl), m0 = __ballot(shortl && (x & 1)), m1 = __ballot(shortl && (x & 2)),
-                                   m2 = __ballot(shortl && (x & 4));
-          const int q = mbcnt(m0, mbcnt(ms)) + 2 * mbcnt(m1) + 4 * mbcnt(m2);
-          const int C = __builtin_popcountll(ms) + __builtin_popcountll(m0) + 2 * __builtin_popcountll(m1) + 4 * __builtin_popcountll(m2);
-#pragma unroll
-          for (int i = 0; i < NCH_MAX; ++i)
-            if (shortl && i < nch) clist[q + i] = (unsigned short)(lane_e | (i * PK) << 6);
-          struct Row { double t0, den, rden; int b0, tr, w, o, end, E; S cb[5][2]; };
-          auto load_row = [&](int jj) {
-            Row r;
-            const unsigned char *rp = lsm + jj * ROWB;
-            const double2 h0 = *reinterpret_cast<const double2 *>(rp);
-            r.t0 = h0.x; r.den = h0.y;
-            r.rden = *reinterpret_cast<const double *>(rp + 16);
-            const int2 bt = *reinterpret_cast<const int2 *>(rp + 24);
-            r.b0 = bt.x; r.tr = bt.y;
-            const S2 *cr = reinterpret_cast<const S2 *>(rp + 32);
-#pragma unroll
-            for (int c = 0; c < 5; ++c) { const S2 cc = cr[c]; r.cb[c][0] = cc.x; r.cb[c][1] = cc.y; }
-            const int4 cu = curs[jj];
-            r.w = cu.x; r.o = cu.y; r.end = cu.z; r.E = cu.w;
-            return r;
-          };
-          // NSL samples of one lane: idx0, idx0 + stride, ...
-          auto samples = [&](bool has, int idx0, int stride, const Row &r, int jj) {
-            unsigned char *const tj = tails + jj * TAILB;
-            // Samples computed by an earlier step wait in the tail buffer; samples behind the last sector boundary go INTO it.  Every
-            // tail read of a pass comes before any tail write of the pass (as with one sample per lane): the lane's second sample may be
-            // an old one while another lane's first sample -- of a later chunk of the same trajectory, same pass -- already parks a new one
-            S told[NSL][D];
-            bool isold[NSL];
-#pragma unroll
-            for (int u = 0; u < NSL; ++u) {
-              const int idx = idx0 + u * stride;
-              isold[u] = has && idx >= r.w && idx < r.o;
-              told[u][0] = told[u][1] = (S)0;
-              if (isold[u]) {
-                const S *ts = reinterpret_cast<const S *>(tj) + (size_t)(idx - r.w) * D;
-                told[u][0] = ts[0]; told[u][1] = ts[1];
-              }
-            }
-            auto put = [&](int u, int idx, S o0, S o1) {
-              if (has && idx >= r.w && idx < r.end) {
-                S out[D] = {isold[u] ? told[u][0] : o0, isold[u] ? told[u][1] : o1};
-                if (idx < r.E) store_state<S, D>(reinterpret_cast<S *>(a.y_out) + ((size_t)r.tr * Nt + idx) * D, out);
-                else store_state<S, D>(reinterpret_cast<S *>(tj) + (size_t)(idx - r.E) * D, out);
-              }
-            };
-            if constexpr (SS == 4 && IONODE_PK_SAMPLES) {
-              // fp32 state: the lane's NSL samples as one vector -- v_pk_mul_f32 / v_pk_add_f32 (separate multiply and add)
-              SV xv;
-#pragma unroll
-              for (int u = 0; u < NSL; ++u) xv[u] = (S)div_pos(te_at(idx0 + u * stride) - r.t0, r.den, r.rden);  // _interp_evaluate: x in fp64, cast
-              SV ov[D], xp = xv;   // running powers
-#pragma unroll
-              for (int d = 0; d < D; ++d) ov[d] = r.cb[0][d] + xv * r.cb[1][d];
-#pragma unroll
-              for (int c = 2; c < 5; ++c) {
-                xp = xp * xv;
-#pragma unroll
-                for (int d = 0; d < D; ++d) ov[d] = ov[d] + xp * r.cb[c][d];
-              }
-#pragma unroll
-              for (int u = 0; u < NSL; ++u) put(u, idx0 + u * stride, ov[0][u], ov[1][u]);
-            } else {
-              // fp64 state: one sample after the other (no packed fp64 arithmetic; interleaving them only costs registers)
-#pragma unroll
-              for (int u = 0; u < NSL; ++u) {
-                const int idx = idx0 + u * stride;
-                const S x_ = (S)div_pos(te_at(idx) - r.t0, r.den, r.rden);
-                S xp = x_, o0 = r.cb[0][0] + x_ * r.cb[1][0], o1 = r.cb[0][1] + x_ * r.cb[1][1];
-#pragma unroll
-                for (int c = 2; c < 5; ++c) {
-                  xp = xp * x_;
-                  o0 = o0 + xp * r.cb[c][0];
-                  o1 = o1 + xp * r.cb[c][1];
-                }
-                put(u, idx, o0, o1);
-              }
-            }
-          };
-          const int slot = lane_e / PKL, kk = lane_e % PKL;
-          // (a software pipeline -- next pass's row and the entry after next in flight during this pass -- was measured: no gain, 35.9
-          // against 35.2 ms for the 2-state kernel, and 171 registers = two wavefronts per SIMD for the N = 10 kernel.  The phase stamps'
-          // long "emission" share is the stamped wavefront waiting while its two neighbours issue, not exposed latency.)
-          for (int c0 = 0; c0 < C; c0 += 64 / PKL) {
-            const bool has = c0 + slot < C;
-            const unsigned e = clist[has ? c0 + slot : c0];   // (idle lane groups shadow the pass's first chunk, stores masked)
-            const int jj = (int)(e & 63u);
-            const Row r = load_row(jj);
-            samples(has, r.b0 + (int)(e >> 6) + kk, PKL, r, jj);
-          }
-          // long steps (more than 64 samples): the whole wavefront, 128 consecutive samples per pass, rows at uniform addresses
-          unsigned long long lm = __ballot(em_lane && !shortl);
-          while (lm) {
-            const int jj = __builtin_ctzll(lm);
-            lm &= lm - 1;
-            const Row r = load_row(jj);
-            const int b0u = __builtin_amdgcn_readfirstlane(r.b0), endu = __builtin_amdgcn_readfirstlane(r.end);
-            for (int b = b0u; b < endu; b += 64 * NSL) samples(true, b + lane_e, 64, r, jj);
-          }
-          if (em_lane) owp[lane_e] = E_own;
-        }
-        oi += n_out;
-      } else if constexpr (!LW && G > 1) {
+      if constexpr (!LW && G > 1) {
       // ---- MLP tile kernels: the owner wavefront emits its NS = TPW / G trajectories.  Everything that has to come from
       // memory for the first 64-sample chunk of ALL of them -- output times (unless the grid is verified uniform: arithmetic),
       // the two protocol samples per output time of the observation model -- is issued before anything is evaluated: one
@@ -2217,8 +2074,11 @@ __global__ void __launch_bounds__(64 * (IONODE_IS_LW(MODEL, RT) ? IONODE_LW_TILE
       }
       oi += n_out;
       } else {
-      // ---- lane-wise kernels on a verified uniform output grid: WORK-LIST emission (see the deferred variant above for the why).
-      // A step of the 6-state model covers ~20 output samples (2-state: ~34), with a long-tailed spread.  Every emitting lane
+      // ---- lane-wise kernels on a verified uniform output grid: WORK-LIST emission.
+      // Steps differ wildly in the number of output samples they cover (2-state, sine-wave legs: 10 % of the accepted steps cover
+      // <= 5 samples, the median 39, 10 % >= 170; 6-state: ~20 on average).  Round 3 handed each group of 8 lanes one emitting
+      // trajectory at a time and ran a pass until the longest of its 8 trajectories was done: 78 iterations per attempt where 36 would
+      // do (a CPU replay of the step logs of one wavefront, tools/emit_replay.py), and the dense output was 72 % of the kernel.  Every emitting lane
       // appends its step's 8-sample chunks {lane, 8 * chunk number} to the LDS work list; a pass takes the next 8 entries, one per
       // group of 8 lanes; what used to be wave-uniform per trajectory (interpolant row, cursor, protocol, trajectory index) is read
       // per lane from LDS: the owner's row, whose spare slot carries (oi, n_out), the protocol index parked in `owp`, the
@@ -2226,7 +2086,7 @@ __global__ void __launch_bounds__(64 * (IONODE_IS_LW(MODEL, RT) ? IONODE_LW_TILE
       // 8 consecutive samples as before, partial sum number = chunk number -- which is why steps of more than 64 samples take the
       // one-trajectory-per-pass loop below); V(t_k) and the reference current of the NEXT pass are loaded before this pass's stores.
       bool packed_lane = false;   // my trajectory's samples are emitted by the work-list passes (the others: the loop below)
-      if constexpr (LW && (VTAB || D > 2)) {
+      if constexpr (LW && (VTAB || D > 2 || (CF2 && TAIL == 1))) {
         // a chunk of PK = 8 samples is served by PKL lanes x NSL samples each (lane kk: samples kk, kk + PKL, ...): one row read per
         // NSL samples -- with one sample per lane the LDS pipe, not the vector ALU, bounded these passes (the 6-state row is 272 bytes)
 #ifndef IONODE_PACK_PKL_D6
@@ -2240,7 +2100,8 @@ __global__ void __launch_bounds__(64 * (IONODE_IS_LW(MODEL, RT) ? IONODE_LW_TILE
         // (2-state kernels that also store the states keep the loop below: at ~34 samples per step its 64 consecutive samples per
         // store instruction touch half the cache lines of 8 x 8, and that path is store-bound: 41.5 against 44.7 ms packed)
         if (a.te_exact && (VTAB ? (want_i && (D > 2 || a.y_out == nullptr)) : (!want_i && a.y_out != nullptr))) {
-          int lane_e = lane;   // opaque per-attempt copy (see the deferred variant): keeps lane-derived addresses out of the attempt loop's live set
+          int lane_e = lane;   // opaque per-attempt copy: what is derived from it (row / list addresses, group and sample numbers) is computed here, per
+                               // attempt, instead of being hoisted out of the attempt loop into a dozen VGPRs that stay live through the stage loop
           asm volatile("" : "+v"(lane_e));
           packed_lane = n_out > 0 && lane_e < LPS && n_out <= 64;
           const unsigned long long emd = __ballot(packed_lane);
@@ -2465,7 +2326,7 @@ __global__ void __launch_bounds__(64 * (IONODE_IS_LW(MODEL, RT) ? IONODE_LW_TILE
           if constexpr (LW) {
             // lane-wise kernels: a full wavefront reduction per emitting trajectory (6 DPP steps + broadcast) was a quarter of
             // the epilogue's instructions.  Reduce over groups of 8 lanes only and keep 8 partial sums per trajectory in LDS
-            // (the tail-buffer region, which only the deferred-emission variant uses); they are added up once, at the end.
+            // (the aux region); they are added up once, at the end.
             const double g8 = group8_sum_f64(sacc);
             if ((lane & 7) == 0) ssep[jj * 8 + (lane >> 3)] += g8;
           } else {
@@ -2579,21 +2440,6 @@ __global__ void __launch_bounds__(64 * (IONODE_IS_LW(MODEL, RT) ? IONODE_LW_TILE
     if (active || acc_now) dt = dt_capped;
   }
 
-  if constexpr (CF2 && defer) {  // trajectories that did not end on their last sample (failed, or a single output): flush the tail
-    unsigned long long fl = __ballot(valid && lane < LPS && owp[lane < LPS ? lane : 0] < oi);
-    while (fl) {
-      const int jj = __builtin_ctzll(fl);
-      fl &= fl - 1;
-      const int w = owp[jj], o = __builtin_amdgcn_readlane(oi, jj);
-      const int tr = __builtin_amdgcn_readlane(traj, jj);
-      S *__restrict__ yo = reinterpret_cast<S *>(a.y_out) + (size_t)tr * Nt * D;
-      if (w + lane < o) {
-        const S *ts = reinterpret_cast<const S *>(tails + jj * TAILB) + (size_t)lane * D;
-        S out[D] = {ts[0], ts[1]};
-        store_state<S, D>(yo + (size_t)(w + lane) * D, out);
-      }
-    }
-  }
 #ifdef IONODE_STAMPS
   STAMP(stamps_, 0);
   if (blockIdx.x == 0 && threadIdx.x == 0 && a.step_log != nullptr && a.step_log_cap >= 4)

@@ -8,7 +8,7 @@ using LaunchFn = hipError_t (*)(const KArgs &, unsigned grid, size_t lds, hipStr
 
 struct Variant {
   int model, f32, G, RT, NT, PD;  // NT = k-tiles (16*NT = padded MLP width), PD = weight-ring depth
-  int tail;                       // closed-form kernels: 1 = deferred aligned emission variant (ionode_device.hpp `defer`), 2 = epilogue through v_at_outputs
+  int tail;                       // lane-wise kernels: 1 = lean variant (ionode_device.hpp LEAN: states only, verified uniform grids), 2 = epilogue through v_at_outputs
   LaunchFn fn;
   const char *name;  // as rocprofv3 --kernel-trace prints it
 };
@@ -21,7 +21,7 @@ hipError_t launch(const KArgs &a, unsigned grid, size_t lds, hipStream_t s) {
   constexpr bool mlp = (MODEL == IONODE_MODEL_NNF || MODEL == IONODE_MODEL_NND);
   if constexpr (!mlp || RT == 64) {
     constexpr int D = (MODEL == IONODE_MODEL_MARKOV6) ? 6 : 2;
-    const size_t need = (size_t)LwLds::bytes(D, D == 2 && TAIL == 1, (int)sizeof(S));
+    const size_t need = (size_t)LwLds::bytes(D, mlp ? (TAIL == 1 ? 1 : 0) : TAIL);
     if ((size_t)a.lw_bytes < need || (a.lw_bytes & 15) || lds < (size_t)IONODE_LW_TILES_PER_WG * (size_t)a.lw_bytes) return hipErrorInvalidValue;
   }
   if (lds > 64 * 1024) {
@@ -42,7 +42,7 @@ hipError_t launch(const KArgs &a, unsigned grid, size_t lds, hipStream_t s) {
 // the MLP shapes of the reference's architectures/s00-s11.py: N = 10, 100, 200, 500
 #define IONODE_MLP_VARIANTS(MODEL, S, F32)                                                      \
   IONODE_VARIANT(MODEL, S, F32, 1, 1, 1, 1, 0), IONODE_VARIANT(MODEL, S, F32, 4, 4, 7, 7, 0),        \
-      /* N <= 16 at 64 trajectories per wavefront (RT slot 64), plain and with the deferred aligned emission (TAIL 1) */ \
+      /* N <= 16 at 64 trajectories per wavefront (RT slot 64), general and lean (TAIL 1) */ \
       IONODE_VARIANT(MODEL, S, F32, 1, 64, 1, 1, 0), IONODE_VARIANT(MODEL, S, F32, 1, 64, 1, 1, 1),      \
       /* ... and N = 10 with the net evaluated per lane on the vector ALU (PD slot 10: MlpLane) */      \
       IONODE_VARIANT(MODEL, S, F32, 1, 64, 1, 10, 0), IONODE_VARIANT(MODEL, S, F32, 1, 64, 1, 10, 1),    \

@@ -255,7 +255,7 @@ def test_population_objective_over_network_weights(ion, gpu, oracle):
 @pytest.mark.parametrize("B,f32", [(40000, False), (40000, True), (140000, False), (140000, True)])
 def test_closed_form_three_per_simd_builds_at_large_batches(ion, gpu, oracle, B, f32):
     """The 2-state kernels at sizes beyond the small tests: 16 trajectories per wavefront (B = 40 000: below the dispatcher's 49 152
-    crossover) and 64 per wavefront (B = 140 000), several workgroups per compute unit, in all three emission variants (plain / deferred aligned stores / table epilogue): 24 random
+    crossover) and 64 per wavefront (B = 140 000), several workgroups per compute unit, in all three variants (general / lean / table epilogue): 24 random
     trajectories against the oracle bit for bit, repeated inputs repeat their bits, fused objective against the traces."""
     import torch
     rng = np.random.default_rng(B)
@@ -266,11 +266,11 @@ def test_closed_form_three_per_simd_builds_at_large_batches(ion, gpu, oracle, B,
     y0 = torch.tensor([[0.0, 1.0]], dtype=torch.float32 if f32 else torch.float64)
     pick = rng.choice(B // 2, 24, replace=False)
     ref = rng.normal(0, 0.3, (3, 401))
-    for name, te, kw in (("deferred", np.arange(0, 2001, 5) * 1.0, {}),                                   # exact grid, states only
+    for name, te, kw in (("lean", np.arange(0, 2001, 5) * 1.0, {}),                                   # exact grid, states only
                          ("plain", np.arange(0, 2001, 5) * 1.0 + 1e-9 * (np.arange(401) % 7 == 3), {}),    # grid not exactly uniform
                          ("table", np.arange(0, 2001, 5) * 1.0, dict(current=True, sse_ref=ref))):       # current + objective
         sol = ion.solve(K.MODEL_HH2, params, pv, y0, te, prot_t0=0.0, prot_dt=1.0, prot_of_traj=pot, **kw)
-        assert ", 1, %d, 0, 0, %d>" % (16 if B < 49152 else 0, {"deferred": 1, "plain": 0, "table": 2}[name]) in sol.kernel, sol.kernel
+        assert ", 1, %d, 0, 0, %d>" % (16 if B < 49152 else 0, {"lean": 1, "plain": 0, "table": 2}[name]) in sol.kernel, sol.kernel
         assert ("float" if f32 else "double") in sol.kernel
         o = oracle.solve(K.MODEL_HH2, params[pick], pv, [0.0, 1.0], te, prot_t0=0.0, prot_dt=1.0, prot_of_traj=pot[pick], nthreads=8,
                          state_f32=f32)
@@ -282,7 +282,7 @@ def test_closed_form_three_per_simd_builds_at_large_batches(ion, gpu, oracle, B,
 
 
 def test_tiny_net_kernel_chosen_for_large_batches(ion, gpu, oracle):
-    """From 49 152 trajectories the N <= 16 nets run one trajectory per lane by themselves (with the deferred aligned emission on an
+    """From 49 152 trajectories the N <= 16 nets run one trajectory per lane by themselves (the lean variant on an
     exact grid): 24 random trajectories of an 80 000-trajectory batch against the oracle, repeated inputs repeat their bits."""
     import torch
     rng = np.random.default_rng(8)

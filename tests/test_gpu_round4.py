@@ -123,7 +123,13 @@ def test_per_lane_net_with_several_weight_sets(ion, gpu, oracle):
     pv = np.stack([K.atau(30)[1], K.atau(300)[1]])
     te = K.atau(30)[2][:901]
     pot = rng.integers(0, 2, B).astype(np.int32)
-    packed = torch.from_numpy(np.stack([ion.capi.mlp_pack(w, L, N) for w in ws])).to(gpu)
+    host = np.stack([ion.capi.mlp_pack(w, L, N) for w in ws])
+    # the images sit at the very END of a device allocation of their own: the launch is rounded up to 32 tiles for 3 tiles of work,
+    # and a tile past the batch must not touch "its" image (image 3 .. 31 would lie past the array -- a GPU memory fault when the
+    # next page is unmapped, as it was on one box in round 4)
+    arena = torch.empty(64 << 20, dtype=torch.uint8, device=gpu)
+    packed = arena[arena.numel() - host.nbytes:].view(torch.float32).view(host.shape)
+    packed.copy_(torch.from_numpy(host))
     r = ion.capi.dopri5(K.MODEL_NNF, torch.from_numpy(params).to(gpu), torch.from_numpy(pv).to(gpu),
                         torch.tensor([K.NN_Y0], dtype=torch.float64, device=gpu).repeat(B, 1).contiguous(), torch.from_numpy(te).to(gpu),
                         mlp_packed=packed, mlp_layers=L, mlp_width=N, prot_t0=0.0, prot_dt=1.0,

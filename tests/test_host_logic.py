@@ -73,16 +73,25 @@ def test_weight_pack_is_a_permutation_with_zero_padding(ion, L, N):
     w = rng.permutation(n).astype(np.float32) + 1.0  # distinct, non-zero, exactly representable
     img = ion.capi.mlp_pack(w, L, N)
     if N <= 16:
-        # N <= 16: the image ends with the SCALAR section of the per-lane net (MlpLane): L x N rows of RS floats, a second copy of the
-        # hidden layers' weights in the canonical k order (r-major, q-minor over k = 4 q + r) followed by the bias
-        RS = (N + 1 + 3) & ~3
-        sc = img[-L * N * RS:].reshape(L, N, RS)
-        img = img[:-L * N * RS]
+        # N <= 16: the image ends with the SCALAR section of the per-lane net (MlpLane), in row PAIRS (the two halves of a
+        # v_pk_fma_f32): layer 0 {b0, b0'} {w00, w00'} {w01, w01'} {0, 0} per pair, then per hidden layer and pair the weights
+        # {W[2m][k], W[2m+1][k]} in the canonical k order (r-major, q-minor over k = 4 q + r), the bias pair, padding
+        NPAIR, PB = (N + 1) // 2, (2 * (N + 1) + 3) & ~3
+        n_sc = NPAIR * 8 + L * NPAIR * PB
+        s0 = img[-n_sc:][:NPAIR * 8].reshape(NPAIR, 4, 2)
+        sc = img[-n_sc:][NPAIR * 8:].reshape(L, NPAIR, PB // 2, 2)
+        img = img[:-n_sc]
         korder = [4 * q + r for r in range(4) for q in range(4) if 4 * q + r < N]
+        W0 = w[:2 * N].reshape(N, 2); b0 = w[2 * N:3 * N]
+        rows = np.arange(N).reshape(NPAIR, 2)   # (N even here)
+        assert np.array_equal(s0[:, 0], b0[rows]) and np.array_equal(s0[:, 1], W0[rows, 0]) and np.array_equal(s0[:, 2], W0[rows, 1]) and not s0[:, 3].any()
         off = 2 * N + N
         for l in range(L):
             W = w[off:off + N * N].reshape(N, N); b = w[off + N * N:off + N * N + N]; off += N * N + N
-            assert np.array_equal(sc[l, :, :N], W[:, korder]) and np.array_equal(sc[l, :, N], b) and not sc[l, :, N + 1:].any()
+            for m in range(NPAIR):
+                for e in range(2):
+                    assert np.array_equal(sc[l, m, :N, e], W[2 * m + e, korder]) and sc[l, m, N, e] == b[2 * m + e]
+            assert not sc[l, :, N + 1:].any()
     if N == 200:
         # N = 200: the image ends with the section of the 4-trajectory tile (MlpTile4): per layer 4 waves x 13 steps x 4 q x 64 lanes x 4
         # fragments (every hidden weight once more; -0.0 where the remainder block idles) + 4 x 64 bias float4s

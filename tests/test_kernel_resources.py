@@ -32,13 +32,16 @@ def test_no_kernel_uses_scratch():
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf") or shutil.which("c++filt") is None, reason="llvm tools")
 def test_two_state_kernels_fit_three_wavefronts_per_simd():
     """The 2-state closed-form kernels are vector-issue bound and need three resident wavefronts per SIMD: 512 / 3 -> 168 registers
-    (allocation granule 8).  They are compiled with a two-per-SIMD launch bound (hipcc then needs ~150); this guards the budget."""
+    (allocation granule 8); the lean variant (states only, verified uniform grids: the headline closed-form workload) four: 128.
+    They are compiled with a two-per-SIMD launch bound (hipcc then needs 118-158); this guards the budgets."""
     ion = importlib.import_module("neural-ode-ion-channels_amd")
     from kernel_resources import kernel_resources
     rows = [r for r in kernel_resources(ion.capi.LIB_PATH) if "ionode_dopri5_kernel<0, " in r["kernel"]]
-    assert len(rows) == 12, [r["kernel"] for r in rows]   # {fp64, fp32} x {64, 16 per wavefront} x {plain, deferred, table}
+    assert len(rows) == 12, [r["kernel"] for r in rows]   # {fp64, fp32} x {64, 16 per wavefront} x {general, lean, table}
     for r in rows:
-        assert r["vgpr"] <= 168 and r["vgpr_spill"] == 0 and r["scratch_bytes"] == 0, r
+        lean = r["kernel"].endswith(", 1>(ionode::KArgs)")
+        assert r["vgpr"] <= (128 if lean else 168) and r["vgpr_spill"] == 0 and r["scratch_bytes"] == 0, r
+    assert sum(r["kernel"].endswith(", 1>(ionode::KArgs)") for r in rows) == 4
 
 
 # Static instruction budgets of the attempt loops (tools/asm_stats.py: the unit compiled to assembly with the Makefile's flags).
