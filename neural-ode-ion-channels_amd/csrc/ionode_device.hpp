@@ -1168,7 +1168,7 @@ struct MlpTile4 {
 // layer and row pair, PB floats: {W[2m][k], W[2m+1][k]} in the canonical k order, {bias, bias'}, pad.
 // ---------------------------------------------------------------------------------------------
 #ifndef IONODE_VNET_PAIRS
-#define IONODE_VNET_PAIRS 2   // row pairs of a hidden layer evaluated together: their scalar loads are in flight at once (22 SGPRs per pair), their chains independent
+#define IONODE_VNET_PAIRS 5   // row pairs of a hidden layer evaluated together (scalar loads of the group in flight at once, independent chains): 65 536 x 20 001: 15.5 ms at 1, 14.3 at 2, 14.2 at 3, 13.6 at 5; 262 144: 38.4 / 36.6 / 36.6 / 36.0
 #endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // acc + w * h.lo / acc + w * h.hi in both halves (one fused multiply-add each); w: SGPR pair
