@@ -379,8 +379,10 @@ def closed_form_legs(ion, dev, weights):
                                        "note": "ms includes the protocol-at-outputs pre-pass (64 x 20001 lookups)"}
     del params, y0t, hold
     torch.cuda.empty_cache()
-    legs["note"] = ("fp64-VALU-issue bound, not HBM bound (DESIGN.md 5.1; counters: profiles/r04_pmc_summary.json cf1-cf6: "
-                    "SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles = 74 % for the 2-state kernel)")
+    legs["note"] = ("2-state: vector ALU 79 % busy AND on the ceiling of its store pattern -- a store-only probe of the same pattern "
+                    "(544-byte runs per trajectory and step) reaches 4.2 TB/s = 0.52 of peak (profiles/r04_hbm_write_probe.md); 6-state: "
+                    "latency-bound at two wavefronts per SIMD; 5x10 net: vector-issue bound (DESIGN.md 5.1; counters: "
+                    "profiles/r04_pmc_summary.json cf1-cf6)")
     return legs
 
 
