@@ -17,6 +17,7 @@ __global__ void fill(double2 *out, size_t n) {
 // (b) the dense-output pattern: wavefront w owns rows 64 w .. 64 w + 63 of [rows][nt] double2.  Per "attempt" every row advances by
 // `step` samples; a pass serves 16 chunks of 8 samples: lane = 4 c + kk writes samples kk and kk + 4 of chunk c (the work-list
 // emission's store shape).  Chunks are dealt out row after row.
+template <int NT_STORE>
 __global__ void __launch_bounds__(256) rows(double2 *out, int n_rows, int nt, int step) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int tile = blockIdx.x * 4 + wv;
@@ -34,7 +35,10 @@ __global__ void __launch_bounds__(256) rows(double2 *out, int n_rows, int nt, in
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const int idx = o + ch * 8 + kk + 4 * u;
-          if (idx < nt && idx < o + step) row[idx] = v;
+          if (idx < nt && idx < o + step) {
+            if (NT_STORE) { __builtin_nontemporal_store(v.x, &row[idx].x); __builtin_nontemporal_store(v.y, &row[idx].y); }
+            else row[idx] = v;
+          }
         }
       }
     }
@@ -101,7 +105,8 @@ int main(int argc, char **argv) {
   double2 *buf;
   if (hipMalloc(&buf, n * sizeof(double2)) != hipSuccess) { printf("hipMalloc failed\n"); return 1; }
   if (lds > 64 * 1024) {
-    hipFuncSetAttribute(reinterpret_cast<const void *>(rows), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(rows<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(rows<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute(reinterpret_cast<const void *>(rows6), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute(reinterpret_cast<const void *>(cols), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
@@ -117,10 +122,16 @@ int main(int argc, char **argv) {
   for (int step : {34, 8, 64, 128}) {
     for (int rep = 0; rep < 2; ++rep) {
       hipEventRecord(a);
-      rows<<<(n_rows / 64 + 3) / 4, 256, lds>>>(buf, n_rows, nt, step);
+      rows<0><<<(n_rows / 64 + 3) / 4, 256, lds>>>(buf, n_rows, nt, step);
       hipEventRecord(b); hipEventSynchronize(b); hipEventElapsedTime(&ms, a, b);
       printf("rows s=%-3d %8.3f ms  %7.1f GB/s\n", step, ms, n * 16.0 / ms / 1e6);
     }
+  }
+  for (int rep = 0; rep < 2; ++rep) {
+    hipEventRecord(a);
+    rows<1><<<(n_rows / 64 + 3) / 4, 256, lds>>>(buf, n_rows, nt, 34);
+    hipEventRecord(b); hipEventSynchronize(b); hipEventElapsedTime(&ms, a, b);
+    printf("rows s=34 nontemporal %8.3f ms  %7.1f GB/s\n", ms, n * 16.0 / ms / 1e6);
   }
   for (int jitter : {0, 8, 24}) {
     for (int rep = 0; rep < 2; ++rep) {
