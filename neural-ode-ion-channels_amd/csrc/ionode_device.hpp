@@ -944,6 +944,8 @@ struct MlpTile {
     const f32x4 *__restrict__ Hin = Hs + (L & 1) * tstride;
     const f32x4 *__restrict__ Pin = Ps + (L & 1) * pstride;
     float part = 0.0f;
+    // (issuing the LDS reads of several steps together was measured: no change at N = 200 / 100, -2 % at N = 500 -- the four wavefronts
+    // run this chain redundantly and its stalls overlap; the 4-trajectory tile, one chain per evaluation on the critical path, does it)
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
       const f32x4 w = *reinterpret_cast<const f32x4 *>(wlS + 16 * kt + 4 * q);
@@ -991,6 +993,9 @@ struct MlpTile4 {
     return ((size_t)2 * ACT + (size_t)2 * 4 * 16 + NP) * 16 + ((size_t)NP + 4) * 4 + (size_t)L * 64 * 16;   // activations x2, partial sums x2, W0 rows, wl + bl, accumulator starts [L][wave][block]
   }
   f32x4 ring[NT][4];
+  f32x4 wlr[NT];   // Linear(N, 1): this lane's chain q = (lane >> 2) & 3 of the output weights, resident (52 registers; read from LDS per
+                   // evaluation they cost thirteen exposed round trips on the critical path of a single trajectory)
+  f32x4 w0r[4];    // layer 0: the four rows {b0, w00, w01, 0} of this lane's output block
   f32x4 *Hs, *Ps;
   const f32x4 *W0s, *B4s;
   const float *wlS;
@@ -1040,6 +1045,13 @@ struct MlpTile4 {
     for (int s = 0; s < NT; ++s)
 #pragma unroll
       for (int q = 0; q < 4; ++q) ring[s][q] = (L > 0) ? frag(sec0, s * 4 + q) : f32x4{0, 0, 0, 0};
+    {
+      const int b = lane >> 2, kq0 = 16 * wave + b;
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt) wlr[kt] = *reinterpret_cast<const f32x4 *>(wl + 16 * kt + 4 * (b & 3));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w0r[r] = (kq0 < NP / 4) ? src[4 * kq0 + r] : f32x4{0, 0, 0, 0};
+    }
     __syncthreads();
   }
   // store an output block (4 rows of k-tile kt, lane group q, trajectory j); tiles 0..2 also at their second slot
@@ -1069,13 +1081,11 @@ struct MlpTile4 {
       if (kq < NP / 4) {
         f32x4 h;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const f32x4 w = W0s[4 * kq + r];
-          h[r] = lrelu(fmaf(w[2], x1, fmaf(w[1], x0, w[0])));
-        }
+        for (int r = 0; r < 4; ++r) h[r] = lrelu(fmaf(w0r[r][2], x1, fmaf(w0r[r][1], x0, w0r[r][0])));
         put_h(Hs, kq >> 2, kq & 3, j, h);
       }
     }
+    f32x4 acc_next = (L > 0) ? B4s[wave * 16 + b] : f32x4{0, 0, 0, 0};
     __syncthreads();
     MSTAMP(1);  // slot 1: layer 0 + barrier
     for (int l = 0; l < L; ++l) {
@@ -1085,8 +1095,10 @@ struct MlpTile4 {
       f32x4 *__restrict__ Pout = Ps + ((l + 1) & 1) * 64;
       const int ln = (l + 1 < L) ? l + 1 : 0;   // the ring runs cyclically over the hidden stack (see MlpTile)
       const unsigned lnext = sec0 + (unsigned)ln * lbytes;
-      // accumulators: D[i][j] = VGPR i: bias of row i of my block (the remainder chain w > 0 starts at 0: the image says so)
-      f32x4 acc = B4s[(l * 4 + wave) * 16 + b];
+      // accumulators: D[i][j] = VGPR i: bias of row i of my block (the remainder chain w > 0 starts at 0: the image says so);
+      // read one layer ahead
+      f32x4 acc = acc_next;
+      if (l + 1 < L) acc_next = B4s[((l + 1) * 4 + wave) * 16 + b];
       // this wavefront's walk: k-tile (s + wave) mod 13 = slot s + wave; B operands one step ahead of their use
       const f32x4 *__restrict__ Bw = Hin + (wave * 4) * 4 + j;
       f32x4 hn[4];
@@ -1130,15 +1142,18 @@ struct MlpTile4 {
     }
     // Linear(N, 1): chain q = b & 3 per lane (k = 16 kt + 4 q + r, kt ascending, r ascending), folded ((p0 + p1) + (p2 + p3)) + bl
     f32x4 *__restrict__ Hin = Hs + (L & 1) * ACT;
-    if (L > 0) fold_remainder(Hin, Ps + (L & 1) * 64);
     const int q = b & 3;
+    // all thirteen activation reads in flight at once (the remainder tile's after its fold): one LDS round trip instead of thirteen
+    f32x4 hl[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT - 1; ++kt) hl[kt] = Hin[(kt * 4 + q) * 4 + j];
+    if (L > 0) fold_remainder(Hin, Ps + (L & 1) * 64);
+    hl[NT - 1] = Hin[((NT - 1) * 4 + q) * 4 + j];
     float part = 0.0f;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
-      const f32x4 w = *reinterpret_cast<const f32x4 *>(wlS + 16 * kt + 4 * q);
-      const f32x4 h = Hin[(kt * 4 + q) * 4 + j];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) part = fmaf(w[r], h[r], part);
+      for (int r = 0; r < 4; ++r) part = fmaf(wlr[kt][r], hl[kt][r], part);
     }
     const float pair = part + __shfl_xor(part, 4);    // (p0 + p1) or (p2 + p3): lanes 4 apart hold neighbouring chains
     const float out = (pair + __shfl_xor(pair, 8)) + wlS[NP];
