@@ -82,6 +82,11 @@ const ionode::Variant *find_variant(int model, int f32, int G, int NT, int rt = 
 
 int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false, bool explicit_grid = false) {
   if (!d) { set_err("null descriptor"); return IONODE_ERR_ARG; }
+#ifdef IONODE_STAMPS
+  const bool has_step_log = false;   // diagnostic build: the step log carries the phase stamps and does not exclude the lean variants
+#else
+  const bool has_step_log = d->step_log != nullptr;
+#endif
   const bool mlp = d->model == IONODE_MODEL_NNF || d->model == IONODE_MODEL_NND;
   const int D = d->model == IONODE_MODEL_MARKOV6 ? 6 : 2;
   if (d->model < 0 || d->model > 3) { set_err("unknown model"); return IONODE_ERR_ARG; }
@@ -98,7 +103,7 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false, bool ex
     const int tpw = (d->tile_waves == 64 || d->tile_waves == 16) ? d->tile_waves : (d->n_traj >= tpw64_from ? 64 : 16);
     // The specialised variants are compiled under a CONTRACT (ionode_device.hpp, top of the kernel): uniform protocol grid, no step log,
     // no checkpoints -- anything else takes the general variant (TAIL slot 0).
-    const bool lean_ok = !explicit_grid && !d->step_log && !d->ckpt;
+    const bool lean_ok = !explicit_grid && !has_step_log && !d->ckpt;
     //   1: the lean variant -- states only on a VERIFIED uniform output grid, no current trace / objective
     //   2: current trace / fused objective with the protocol-at-outputs table given (hint path)
     const int tail = !lean_ok ? 0
@@ -125,7 +130,7 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false, bool ex
     const bool img64 = d->traj_per_image <= 0 || d->traj_per_image % 64 == 0;
     const bool t64 = NT == 1 && (d->tile_waves == 64 || (d->tile_waves == 0 && d->n_traj >= IONODE_TINY64_FROM && img64));
     // (the lean variant's contract as for the closed-form kernels: verified uniform output grid, no current / objective)
-    const int t64lean = (t64 && d->t_eval_exact && d->t_eval_dt_hint > 0.0 && d->n_out > 1 && !want_current && !explicit_grid && !d->step_log && !d->ckpt) ? 1 : 0;
+    const int t64lean = (t64 && d->t_eval_exact && d->t_eval_dt_hint > 0.0 && d->n_out > 1 && !want_current && !explicit_grid && !has_step_log && !d->ckpt) ? 1 : 0;
     // N = 200: from two 16-trajectory tiles per compute unit on (8192 trajectories), 32-trajectory tiles -- two column sets per weight
     // fragment, the scalar integrator work replicated twice instead of four times (tile_waves = 8 forces it, 4 forces the 16-tile).
     // Needs a hidden layer (asm stream) and weight images that cover whole 32-trajectory tiles.
@@ -137,7 +142,7 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false, bool ex
     const bool t4 = !t64 && !t32 && NT == 13 && d->mlp_layers >= 1 && (d->traj_per_image <= 0 || d->traj_per_image % 4 == 0) &&
                     (d->tile_waves == 2 || (d->tile_waves == 0 && d->n_traj <= IONODE_TILE4_UPTO));
     // N = 200 tiles: the lean variant when its contract holds (ionode_device.hpp LEANM)
-    const bool leanm = !t64 && (NT == 13 || NT == 7 || NT == 32) && d->mlp_layers >= 1 && !explicit_grid && !d->step_log && !d->ckpt && d->t_eval_exact && d->t_eval_dt_hint > 0.0 && d->n_out > 1;
+    const bool leanm = !t64 && (NT == 13 || NT == 7 || NT == 32) && d->mlp_layers >= 1 && !explicit_grid && !has_step_log && !d->ckpt && d->t_eval_exact && d->t_eval_dt_hint > 0.0 && d->n_out > 1;
     pl->v = t64 ? find_variant(d->model, f32, 1, NT, 64, t64lean, vnet ? 10 : 1)
                 : find_variant(d->model, f32, ((d->tile_waves == 8 || d->tile_waves == 2) ? 4 : d->tile_waves), NT, NT == 1 ? 1 : -1, (t32 ? 4 : 0) | (leanm ? 8 : 0) | (t4 ? 16 : 0));
     if (!pl->v) {
