@@ -130,7 +130,10 @@ size_t ionode_mlp_packed_floats(int32_t mlp_layers, int32_t mlp_width);
 
 /* HOST -> HOST.  Re-lays a state dict (flat fp32, order net.0.weight [N][2], net.0.bias [N],
  * {net.2i.weight [N][N], net.2i.bias [N]} x L, net.last.weight [1][N], net.last.bias [1]; row-major as
- * torch stores nn.Linear) into the MFMA-fragment order the kernels stream.  The caller uploads `packed`. */
+ * torch stores nn.Linear) into the MFMA-fragment order the kernels stream.  The caller uploads `packed`.
+ * The image is an opaque, derived artefact of THIS library build (its sections and their order follow the kernels:
+ * fragment streams, the 4-trajectory tile's section, the per-lane net's scalar row pairs): pack after loading the
+ * library, do not persist images across library versions. */
 int ionode_mlp_pack(const float *state_dict_flat, int32_t mlp_layers, int32_t mlp_width, float *packed);
 
 /*
