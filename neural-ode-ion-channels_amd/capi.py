@@ -263,8 +263,10 @@ def dopri5(model, params, prot_v, y0, t_eval, *, mlp_packed=None, mlp_layers=0, 
         if launch_order != "auto":
             raise IonodeError("launch_order: None, 'auto' or an int32 device tensor [B]")
         launch_order = None
-        lane_wise = model in (MODEL_HH2, MODEL_MARKOV6) or (mlp_width and mlp_width <= 16)
-        if lane_wise and prot_of_traj is not None and P > 1 and B >= 49152 and not traj_per_image:
+        # one trajectory per lane (64 per wavefront) from these batch sizes on -- the dispatcher's crossovers (ionode_capi.hip make_plan):
+        # there the 64 lanes of a wavefront should read ONE protocol
+        lane_from = {MODEL_HH2: 49152, MODEL_MARKOV6: 24576}.get(model, 32769 if (mlp_width and mlp_width <= 16) else None)
+        if lane_from is not None and prot_of_traj is not None and P > 1 and B >= lane_from and not traj_per_image:
             launch_order = _protocol_major(prot_of_traj)
     if launch_order is not None:
         _dev_ptr(launch_order, torch.int32, "launch_order", (B,))

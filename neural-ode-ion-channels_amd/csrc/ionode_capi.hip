@@ -17,7 +17,7 @@
 #define IONODE_TINY64_MFMA 0   // 1: N = 10 keeps the MFMA form at 64 trajectories per wavefront (A/B)
 #endif
 #ifndef IONODE_TINY64_FROM
-#define IONODE_TINY64_FROM 49152  // round 4 (per-lane net, even placement; 20 001 samples): 16 per wavefront 12.1 ms up to 32 768, 19.7 at 49 152, 23.3 at 65 536; 64 per wavefront 19.2-19.4 ms from 16 384 to 65 536
+#define IONODE_TINY64_FROM 32769  // round 4, final build (per-lane packed net, even placement; 20 001 samples): 16 per wavefront 12.0-12.1 ms from 16 384 to 32 768 (two wavefronts per SIMD), 19.6 at 49 152, 23.1 at 65 536; 64 per wavefront 13.3-13.7 ms from 8 192 to 65 536
 #endif
 
 namespace {
