@@ -282,7 +282,7 @@ def test_closed_form_three_per_simd_builds_at_large_batches(ion, gpu, oracle, B,
 
 
 def test_tiny_net_kernel_chosen_for_large_batches(ion, gpu, oracle):
-    """From 49 152 trajectories the N <= 16 nets run one trajectory per lane by themselves (the lean variant on an
+    """From 32 769 trajectories the N <= 16 nets run one trajectory per lane by themselves (the lean variant on an
     exact grid): 24 random trajectories of an 80 000-trajectory batch against the oracle, repeated inputs repeat their bits."""
     import torch
     rng = np.random.default_rng(8)
