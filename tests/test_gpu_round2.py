@@ -412,6 +412,8 @@ def test_tiny_nets_at_64_trajectories_per_wavefront(ion, gpu, oracle, model, L, 
     assert ion.capi.launch_geometry(d)["grid"] == 632 and form in ion.capi.kernel_name(d)      # 2500 tiles, four per workgroup, chosen by itself
     d.n_traj = 30000
     assert ion.capi.launch_geometry(d)["grid"] == 1875 and ", 1, 1, 1, 1, 0>" in ion.capi.kernel_name(d)
+    d.n_traj = 40000   # beyond two 16-trajectory wavefronts per SIMD (32 768): one trajectory per lane
+    assert form in ion.capi.kernel_name(d)
 
 
 @pytest.mark.parametrize("L,N,f32", [(5, 200, False), (2, 100, True), (5, 10, False), (1, 500, True)])
