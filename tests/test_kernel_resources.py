@@ -72,3 +72,20 @@ def test_attempt_loop_instruction_budgets(unit):
         assert a["mov_const32"] + a["mov_const64"] <= const_movs, (key, a)
         assert a["max_self"] <= max_self, (key, a)
         assert a["accvgpr"] <= agpr, (key, a)
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("c++filt") is None, reason="hipcc")
+def test_per_lane_net_issues_packed_fma_with_scalar_weights():
+    """The N = 10 kernel at one trajectory per lane evaluates two rows of a layer per v_pk_fma_f32, weights as an SGPR pair and the
+    activation broadcast by op_sel (round 4: the vector fp32 peak is the packed rate).  A change that silently falls back to one fmaf per
+    instruction, or that reintroduces canonicalising v_max x, x, x around LeakyReLU, fails here."""
+    import re
+    from asm_stats import compile_asm
+    asm = compile_asm("inst_nnf_f64")
+    start = asm.index("_ZN6ionode20ionode_dopri5_kernelILi2EdLi1ELi64ELi1ELi10ELi1EEEvNS_5KArgsE:")
+    body = asm[start:asm.index(".end_amdhsa_kernel", start)]
+    pk = re.findall(r"v_pk_fma_f32 v\[\d+:\d+\], s\[\d+:\d+\], v\[\d+:\d+\], v\[\d+:\d+\]", body)
+    assert len(pk) >= 400, len(pk)                       # 8 inlined evaluations x (10 layer-0 + 50 per hidden-layer body) = 480
+    assert sum("op_sel:[0,1,0]" in l for l in re.findall(r"v_pk_fma_f32[^\n]*", body)) >= 150   # both halves of the activation pairs are used
+    assert not re.search(r"v_max_f32(?:_e32|_e64)? (v\d+), \1, \1\b", body)
+    assert "scratch_" not in body
