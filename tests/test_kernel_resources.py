@@ -74,14 +74,38 @@ def test_attempt_loop_instruction_budgets(unit):
         assert a["accvgpr"] <= agpr, (key, a)
 
 
+_ASM_CACHE = {}
+
+
+def _nnf_f64_asm():
+    if "nnf64" not in _ASM_CACHE:
+        from asm_stats import compile_asm
+        _ASM_CACHE["nnf64"] = compile_asm("inst_nnf_f64")
+    return _ASM_CACHE["nnf64"]
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("c++filt") is None, reason="hipcc")
+def test_tile_kernels_keep_their_dense_output_stores():
+    """Every forward kernel writes its dense output itself.  (Round 4: an edit of the shared emission code dropped the MLP tile
+    kernels' block; the CPU suite stayed green and only the GPU parity suite noticed.)  The N = 200 / N = 100 / N = 500 tile kernels
+    and the 4-trajectory tile each keep their state stores (16-byte stores of a 2 x fp64 sample) in the code object."""
+    asm = _nnf_f64_asm()
+    # (minimum = ~80 % of the round-4 count: 4 owned trajectories x {first chunk, later chunks} per wavefront, + the initial sample)
+    for sym, least in (("ILi2EdLi4ELi4ELi13ELi13ELi8EE", 10), ("ILi2EdLi4ELi4ELi13ELi13ELi12EE", 16), ("ILi2EdLi4ELi4ELi13ELi13ELi24EE", 5),
+                       ("ILi2EdLi4ELi4ELi7ELi7ELi8EE", 10), ("ILi2EdLi4ELi8ELi32ELi4ELi8EE", 10), ("ILi2EdLi1ELi64ELi1ELi10ELi1EE", 6),
+                       ("ILi2EdLi1ELi1ELi1ELi1ELi0EE", 14)):
+        start = asm.index("_ZN6ionode20ionode_dopri5_kernel%sEvNS_5KArgsE:" % sym)
+        body = asm[start:asm.index(".end_amdhsa_kernel", start)]
+        assert body.count("global_store_dwordx4") >= least, (sym, body.count("global_store_dwordx4"))
+
+
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("c++filt") is None, reason="hipcc")
 def test_per_lane_net_issues_packed_fma_with_scalar_weights():
     """The N = 10 kernel at one trajectory per lane evaluates two rows of a layer per v_pk_fma_f32, weights as an SGPR pair and the
     activation broadcast by op_sel (round 4: the vector fp32 peak is the packed rate).  A change that silently falls back to one fmaf per
     instruction, or that reintroduces canonicalising v_max x, x, x around LeakyReLU, fails here."""
     import re
-    from asm_stats import compile_asm
-    asm = compile_asm("inst_nnf_f64")
+    asm = _nnf_f64_asm()
     start = asm.index("_ZN6ionode20ionode_dopri5_kernelILi2EdLi1ELi64ELi1ELi10ELi1EEEvNS_5KArgsE:")
     body = asm[start:asm.index(".end_amdhsa_kernel", start)]
     pk = re.findall(r"v_pk_fma_f32 v\[\d+:\d+\], s\[\d+:\d+\], v\[\d+:\d+\], v\[\d+:\d+\]", body)
