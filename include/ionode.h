@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define IONODE_ABI_VERSION 7
+#define IONODE_ABI_VERSION 8
 
 /* RHS families (func.forward variants of the reference) */
 #define IONODE_MODEL_HH2 0     /* 2-state Hodgkin-Huxley: Lambda, train-s1.py:134-177; candidate ODEFunc train-d0.py:321-374 */
@@ -75,8 +75,8 @@ typedef struct ionode_desc {
   double obs_e;
   int32_t obs_open_state_only; /* 1: gate = last state (6-state O, train-d1.py:299) */
   int32_t tile_waves;  /* tuning, 0 = auto.  MLP models: wavefronts cooperating on one 16-trajectory tile (1, 4); N <= 16 nets
-                          also 64 = one trajectory per lane, 64 per wavefront (auto from 73728 trajectories).
-                          Closed-form models: trajectories per wavefront (64 or 16; auto = 16 below 81920 (2-state) / 40960 (6-state) trajectories) */
+                          also 64 = one trajectory per lane, 64 per wavefront (auto from ionode_lane_wise_from() trajectories); N = 200 also 8 / 2 = 32 / 4
+                          trajectories per tile.  Closed-form models: trajectories per wavefront (64 or 16; auto = 16 below ionode_lane_wise_from()) */
   double *step_log;    /* optional DEVICE buffer [step_log_cap][4] fp64: (t0, dt, error ratio, accepted) of every
                           step attempt of trajectory 0 -- the per-step trace parity tests compare; NULL = off */
   int64_t step_log_cap;
@@ -174,6 +174,11 @@ const char *ionode_kernel_name(const ionode_desc *d);
 
 /* Name of the instantiation this thread's last successful ionode_dopri5 call launched ("" before the first). */
 const char *ionode_last_kernel_name(void);
+
+/* Batch size from which ionode_dopri5 (tile_waves = 0) takes the one-trajectory-per-lane kernel (64 trajectories per wavefront) of
+ * `model` (mlp_width: the net's width for the NN models, ignored otherwise); 0 if the model has no such kernel.  Callers that sort
+ * trajectories by protocol for those kernels (launch_order) read the crossover here instead of keeping a copy.  Since ABI 8. */
+int32_t ionode_lane_wise_from(int32_t model, int32_t mlp_width);
 
 const char *ionode_last_error(void);
 int32_t ionode_abi_version(void);

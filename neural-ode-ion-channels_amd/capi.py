@@ -21,11 +21,11 @@ STATUS_TEXT = {
     2: "non-finite values in state `y`",
     3: "max_num_steps exceeded",
 }
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 EXPORTS = (
     "ionode_abi_version", "ionode_last_error", "ionode_mlp_packed_floats", "ionode_mlp_pack",
-    "ionode_launch_geometry", "ionode_kernel_name", "ionode_last_kernel_name", "ionode_dopri5", "ionode_protocol_at_outputs",
+    "ionode_launch_geometry", "ionode_kernel_name", "ionode_last_kernel_name", "ionode_lane_wise_from", "ionode_dopri5", "ionode_protocol_at_outputs",
     "ionode_grad_image_floats", "ionode_grad_pack", "ionode_grad_record_floats", "ionode_dopri5_backward",
     "ionode_grad_packet_doubles", "ionode_dopri5_backward_recompute", "ionode_dopri5_backward_sweep",
     "ionode_grad_partial_floats", "ionode_grad_reduce", "ionode_grad_reduce_unit", "ionode_grad_last_error",
@@ -113,6 +113,8 @@ def lib():
         L.ionode_image_refresh.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ionode_last_kernel_name.restype = C.c_char_p
         L.ionode_last_kernel_name.argtypes = []
+        L.ionode_lane_wise_from.restype = C.c_int32
+        L.ionode_lane_wise_from.argtypes = [C.c_int32, C.c_int32]
         L.ionode_protocol_at_outputs.restype = C.c_int
         L.ionode_protocol_at_outputs.argtypes = [C.POINTER(IonodeDesc)] + [C.c_void_p] * 5
         if L.ionode_abi_version() != ABI_VERSION:
@@ -265,8 +267,8 @@ def dopri5(model, params, prot_v, y0, t_eval, *, mlp_packed=None, mlp_layers=0, 
         launch_order = None
         # one trajectory per lane (64 per wavefront) from these batch sizes on -- the dispatcher's crossovers (ionode_capi.hip make_plan):
         # there the 64 lanes of a wavefront should read ONE protocol
-        lane_from = {MODEL_HH2: 49152, MODEL_MARKOV6: 24576}.get(model, 32769 if (mlp_width and mlp_width <= 16) else None)
-        if lane_from is not None and prot_of_traj is not None and P > 1 and B >= lane_from and not traj_per_image:
+        lane_from = int(lib().ionode_lane_wise_from(int(model), int(mlp_width or 0)))
+        if lane_from > 0 and prot_of_traj is not None and P > 1 and B >= lane_from and not traj_per_image:
             launch_order = _protocol_major(prot_of_traj)
     if launch_order is not None:
         _dev_ptr(launch_order, torch.int32, "launch_order", (B,))

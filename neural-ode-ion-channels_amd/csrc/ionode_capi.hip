@@ -54,15 +54,31 @@ void plan_lane_wise(Plan *pl, size_t tiles, size_t per_wave_bytes) {
 #define IONODE_EVEN_PLACEMENT 1
 #endif
   if (IONODE_EVEN_PLACEMENT) {
-    const size_t ncu = 256;   // MI355X
+    // compute units of the current device (256 on an unpartitioned MI355X).  The padding assumes the 8-XCD round-robin of the whole
+    // chip: on a partitioned device (CPX / DPX) or without a device (the plan is also computed on hosts without a GPU) it is skipped
+    static const int ncu_dev = [] {
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+      return n;
+    }();
+    const size_t ncu = 256;
     const size_t per_cu = (pl->grid + ncu - 1) / ncu;
     const size_t natural = cap / (((lds + gran - 1) / gran) * gran);
-    if (per_cu >= 1 && per_cu < natural) {
+    if ((ncu_dev == 0 || ncu_dev == (int)ncu) && per_cu >= 1 && per_cu < natural) {
       const size_t pad = (cap / per_cu) / gran * gran;
       if (pad > lds) lds = pad;
     }
   }
   pl->lds = lds;
+}
+
+// Batch size from which the dispatcher takes the one-trajectory-per-lane (64 per wavefront) kernel of a model; 0: the model has none.
+// Exported as ionode_lane_wise_from() so that host code (capi.py: protocol-major launch order) does not keep a copy of the numbers.
+int lane_wise_from(int model, int mlp_width) {
+  if (model == IONODE_MODEL_HH2) return 49152;
+  if (model == IONODE_MODEL_MARKOV6) return 24576;
+  if ((model == IONODE_MODEL_NNF || model == IONODE_MODEL_NND) && mlp_width >= 1 && mlp_width <= 16) return IONODE_TINY64_FROM;
+  return 0;
 }
 
 // Closed-form kernels are registered with NT == 0 and RT = trajectories per wavefront (0 -> 64); rt < 0: any RT.
@@ -99,7 +115,7 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false, bool ex
     // small batches: 16 trajectories per wavefront (lanes replicated 4x, 4x the wavefronts) while the launch has fewer wavefronts than
     // the chip has SIMDs to spread them over; measured crossovers (round 4, tools/gpu/r4_t4b.sh, 20 001 samples): 2-state 32 768: 6.3 ms at
     // 16 per wavefront / 9.7 at 64, 65 536: 11.6 / 10.1; 6-state 16 384: 9.1 / 13.8, 32 768: 17.5 / 15.0.  tile_waves = 64 / 16 forces a choice.
-    const int tpw64_from = (D == 6) ? 24576 : 49152;
+    const int tpw64_from = lane_wise_from(d->model, 0);
     const int tpw = (d->tile_waves == 64 || d->tile_waves == 16) ? d->tile_waves : (d->n_traj >= tpw64_from ? 64 : 16);
     // The specialised variants are compiled under a CONTRACT (ionode_device.hpp, top of the kernel): uniform protocol grid, no step log,
     // no checkpoints -- anything else takes the general variant (TAIL slot 0).
@@ -160,6 +176,15 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false, bool ex
     if (t64) plan_lane_wise(pl, (size_t)((d->n_traj + 63) / 64), (vnet ? (size_t)0 : ((pl->lds + 15) & ~(size_t)15)) + (size_t)ionode::LwLds::bytes(2, t64lean));  // MlpTile region + the lane-wise region
   }
   if (!pl->v) { set_err("no kernel variant compiled for this descriptor"); return IONODE_ERR_UNSUPPORTED; }
+  if (mlp && d->traj_per_image > 0) {
+    // several weight images: a tile reads ONE image (first trajectory / traj_per_image), so an image's trajectories must fill whole
+    // tiles.  Tile size from the VARIANT (a lane-wise workgroup is 4 x 64 lanes: the block size says nothing about it).
+    const int tile = (pl->v->RT == 64) ? 64 : ((pl->v->tail & 4) && pl->v->G == 4 ? 32 : ((pl->v->tail & 16) ? 4 : 16));
+    if (d->traj_per_image % tile != 0 || d->mlp_image_stride < (int64_t)ionode_mlp_packed_floats(d->mlp_layers, d->mlp_width)) {
+      set_err("traj_per_image must be a multiple of the tile size (16; 64 with tile_waves = 64; 32 with tile_waves = 8) and mlp_image_stride at least one packed image");
+      return IONODE_ERR_ARG;
+    }
+  }
   return IONODE_OK;
 }
 
@@ -363,6 +388,8 @@ const char *ionode_kernel_name(const ionode_desc *d) {
 
 const char *ionode_last_kernel_name(void) { return g_last_kernel; }
 
+int32_t ionode_lane_wise_from(int32_t model, int32_t mlp_width) { return lane_wise_from(model, mlp_width); }
+
 int ionode_dopri5(const ionode_desc *d, const float *mlp_packed, const double *params, const double *prot_v,
                   const double *prot_t, const int32_t *prot_of_traj, const void *y0, const double *t_eval,
                   void *y_out, double *i_out, int32_t *status, int64_t *stats, void *stream) {
@@ -395,14 +422,7 @@ int ionode_dopri5(const ionode_desc *d, const float *mlp_packed, const double *p
   a.obs_g = d->obs_g; a.obs_e = d->obs_e; a.obs_open = d->obs_open_state_only;
   a.step_log = d->step_log; a.step_log_cap = d->step_log ? d->step_log_cap : 0;
   a.sse_ref = d->sse_ref; a.sse_out = d->sse_out; a.v_tab = d->v_at_outputs;
-  if (mlp && d->traj_per_image > 0) {
-    const int tile = (pl.block == 64 && pl.v->RT == 64) ? 64 : ((pl.v->tail & 4) && pl.v->G == 4 ? 32 : ((pl.v->tail & 16) ? 4 : 16));
-    if (d->traj_per_image % tile != 0 || d->mlp_image_stride < (int64_t)ionode_mlp_packed_floats(d->mlp_layers, d->mlp_width)) {
-      set_err("traj_per_image must be a multiple of the tile size (16; 64 with tile_waves = 64) and mlp_image_stride at least one packed image");
-      return IONODE_ERR_ARG;
-    }
-    a.mlp_stride = d->mlp_image_stride; a.traj_per_img = d->traj_per_image;
-  }
+  if (mlp && d->traj_per_image > 0) { a.mlp_stride = d->mlp_image_stride; a.traj_per_img = d->traj_per_image; }  // checked in make_plan
   if (d->launch_order) {
     if (a.traj_per_img > 0) { set_err("launch_order cannot be combined with traj_per_image (tiles of an image must stay together)"); return IONODE_ERR_ARG; }
     a.order = d->launch_order;

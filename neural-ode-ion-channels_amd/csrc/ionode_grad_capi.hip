@@ -105,6 +105,10 @@ static int backward_impl(int mode, const ionode_desc *d, int32_t it_begin, int32
     gerr("ionode_dopri5_backward: required buffer is NULL (ckpt / ckpt_cap come from the descriptor)"); return IONODE_ERR_ARG;
   }
   if (it_begin < 0 || it_end <= it_begin || it_end > n_iter) { gerr("bad iteration range"); return IONODE_ERR_ARG; }
+  if (mode == 1 && (int64_t)it_end - it_begin > (int64_t)65535 * ionode::GRAD_RECOMPUTE_IB) {
+    gerr("ionode_dopri5_backward_recompute: at most 65535 x 4 iterations per launch (HIP's grid.y limit): split the range");
+    return IONODE_ERR_ARG;
+  }
   if (d->traj_per_image > 0) { gerr("backward sweep: one weight set per launch (traj_per_image must be 0)"); return IONODE_ERR_UNSUPPORTED; }
   if (!hh2 && (d->mlp_layers < 1 || d->mlp_width < 1)) { gerr("bad MLP shape"); return IONODE_ERR_ARG; }
   const int NP = hh2 ? 16 : np_of(d->mlp_width), NT = NP / 16, L = hh2 ? 0 : d->mlp_layers;

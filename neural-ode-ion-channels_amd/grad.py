@@ -41,6 +41,9 @@ def _bounded_budget(requested, default, dev, share):
         return int(requested)
     try:
         free, _total = torch.cuda.mem_get_info(dev)
+        # memory the caching allocator holds but has handed out to nobody is reusable by the next allocation: without it the previous
+        # iteration's own freed checkpoint / record buffers would shrink the budget iteration by iteration
+        free += max(0, torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev))
     except Exception:  # no device query available: keep the default
         return int(default)
     return int(max(1 << 28, min(default, share * free)))
@@ -195,13 +198,15 @@ class _Solve(torch.autograd.Function):
         # only, one wavefront per tile); the reduction of a finished chunk (ionode_grad_reduce_unit: records scaled by the seeds
         # the walk wrote) runs on a third stream.  Records and packets are double-buffered.
         two_phase = bool(cfg.get("two_phase", os.environ.get("IONODE_GRAD_ONE_PHASE", "0") != "1")) and image is not None
+        if two_phase:   # small batch, small net, very long solve: every phase-A launch stays inside HIP's grid.y limit,
+            chunk = min(chunk, MAX_RECOMPUTE_ITERS)   # decided BEFORE the chunk count and the buffering that follow from it
         n_chunks = (n_iter + chunk - 1) // chunk
         n_buf = 2 if (n_chunks > 1 and (need_w or two_phase)) else 1
         if need_w and n_buf == 2:
             chunk = max(1, min(n_iter, (budget // 2) // (tiles * 6 * recf * 4)))
-            if two_phase and chunk > MAX_RECOMPUTE_ITERS:   # small batch, small net, very long solve: stay inside HIP's grid.y limit
-                chunk = MAX_RECOMPUTE_ITERS
-                n_chunks = (n_iter + chunk - 1) // chunk
+            if two_phase:
+                chunk = min(chunk, MAX_RECOMPUTE_ITERS)
+            n_chunks = (n_iter + chunk - 1) // chunk
         elif two_phase and not need_w:
             # no record stream: the packets are what a chunk holds (two buffers); bounded chunks also keep phase A one chunk ahead
             per_it = tiles * int(lib.ionode_grad_packet_doubles()) * 8

@@ -336,3 +336,38 @@ def test_protocol_major_launch_order_is_dealt_out_over_the_xcds(ion):
     ragged = (torch.arange(1000, dtype=torch.int32) % 7).contiguous()   # not a multiple of 512: plain protocol-major
     o2 = ion.capi._protocol_major(ragged).long()
     assert sorted(o2.tolist()) == list(range(1000)) and bool((ragged[o2][1:] >= ragged[o2][:-1]).all())
+
+
+def test_explicit_64_per_wavefront_rejects_images_that_do_not_fill_a_tile(ion):
+    """the tile size of a several-weight-sets launch comes from the kernel VARIANT (a lane-wise workgroup is 4 x 64 lanes,
+    so its block size says nothing): tile_waves = 64 with 16 / 32 / 48 trajectories per image must be an argument error, never a
+    launch in which 48 of 64 trajectories integrate with the wrong net."""
+    capi = ion.capi
+    kw = dict(model=capi.MODEL_NNF, n_state=2, n_out=10, n_prot=1, prot_n=100, mlp_layers=5, mlp_width=10, n_params=8,
+              prot_dt=0.1, rtol=1e-7, atol=1e-9, n_traj=64 * 600, mlp_image_stride=10**6)
+    for s in (16, 32, 48):
+        with pytest.raises(capi.IonodeError, match="traj_per_image must be a multiple of the tile size"):
+            capi.launch_geometry(capi.make_desc(tile_waves=64, traj_per_image=s, **kw))
+        assert capi.kernel_name(capi.make_desc(tile_waves=64, traj_per_image=s, **kw)) == ""
+    assert capi.launch_geometry(capi.make_desc(tile_waves=64, traj_per_image=64, **kw))["block"] == 256
+    kw200 = dict(kw, mlp_width=200, n_traj=64)
+    # 32-trajectory tiles need images of whole 32s: a request for them with 16 per image is served by the 16-trajectory tile
+    assert capi.launch_geometry(capi.make_desc(tile_waves=8, traj_per_image=16, **kw200))["grid"] == 4
+    assert capi.launch_geometry(capi.make_desc(tile_waves=8, traj_per_image=32, **kw200))["grid"] == 2
+    assert capi.launch_geometry(capi.make_desc(tile_waves=2, traj_per_image=4, **kw200))["grid"] == 16   # 4-trajectory tiles
+
+
+def test_lane_wise_crossovers_come_from_the_library(ion):
+    """capi.py reads the dispatcher's 16 -> 64 trajectories-per-wavefront crossovers through the C ABI."""
+    capi = ion.capi
+    L = capi.lib()
+    kw = dict(n_state=2, n_out=10, n_prot=1, prot_n=100, n_params=8, prot_dt=0.1, rtol=1e-7, atol=1e-9)
+    for model, extra in ((capi.MODEL_HH2, {}), (capi.MODEL_MARKOV6, dict(n_state=6, n_params=12)), (capi.MODEL_NNF, dict(mlp_layers=5, mlp_width=10))):
+        n = L.ionode_lane_wise_from(model, extra.get("mlp_width", 0))
+        assert n > 0
+        k = dict(kw, **extra)
+        below = capi.launch_geometry(capi.make_desc(model=model, n_traj=n - 1, **k))
+        at = capi.launch_geometry(capi.make_desc(model=model, n_traj=n, **k))
+        per_wave = lambda g, nt: nt / (g["grid"] * (4 if g["block"] == 256 else 1))
+        assert per_wave(below, n - 1) <= 16 and per_wave(at, n) > 16
+    assert L.ionode_lane_wise_from(capi.MODEL_NNF, 200) == 0
