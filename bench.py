@@ -241,25 +241,32 @@ def main():
             res["config"]["objective_sharded"] = {"error": repr(e)}
     lib_sha = capi.library_digest()
     res["config"]["libionode_sha256"] = lib_sha[:16]
-    pmc = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")
-    if os.path.exists(pmc) and B == 4096 and Nt == 100001:
+    pmc, pj_all = pmc_summary(lib_sha)
+    if pmc is not None and B == 4096 and Nt == 100001:
         # HBM bytes per launch from the rocprofv3 --pmc passes of this same command (profiles/README.md): FETCH_SIZE is
         # doubled (gfx950 counts 128-B requests as 64 B), WRITE_SIZE is exact; both are reported in KiB.  The counters belong
         # to ONE build of the library: the summary records its digest, and a different library in this process means the
         # byte count is stale -- reported as such, never silently carried over.
         try:
-            pj = json.load(open(pmc))
+            pj = pj_all
             kname = "void ionode::" + r["kernel"] + "(ionode::KArgs)"
             traffic = (2 * pj["pmc2"][kname]["FETCH_SIZE"] + pj["pmc3"][kname]["WRITE_SIZE"]) * 1024
             stale = pj.get("libionode_sha256") != lib_sha
             for key in ("roofline", "roofline_hbm"):
                 res[key]["traffic"] = None if stale else traffic
                 res[key]["traffic_stale"] = stale
-                res[key]["traffic_source"] = ("HBM bytes per launch, profiles/r04_pmc_summary.json (separate rocprofv3 --pmc "
+                res[key]["traffic_source"] = (f"HBM bytes per launch, profiles/{os.path.basename(pmc)} (separate rocprofv3 --pmc "
                                               "passes of this command; FETCH_SIZE x2 per the gfx950 note, WRITE_SIZE exact)"
                                               + ("; NOT reported: the counters were collected with another build of libionode.so "
                                                  f"({str(pj.get('libionode_sha256'))[:16]})" if stale else ""))
-        except (KeyError, ValueError):
+            # where the fraction goes (same stale guard): share of chip time the MFMA pipe is busy (ONE denominator: 1024 SIMDs x launch
+            # cycles, launch cycles = GRBM_GUI_ACTIVE / 8 XCDs), and useful / executed MFMA FLOP (padding 200 -> 208, lock-step tiles)
+            cyc = pj["pmc2"][kname]["GRBM_GUI_ACTIVE"] / 8.0 / max(1, pj["pmc2"][kname].get("dispatches", 1))
+            nd1 = max(1, pj["pmc1"][kname].get("dispatches", 1))
+            res["roofline"]["mfma_busy"] = None if stale else pj["pmc1"][kname]["SQ_VALU_MFMA_BUSY_CYCLES"] / nd1 / (1024.0 * cyc)
+            res["roofline"]["useful_over_executed"] = None if stale else flops / (pj["pmc1"][kname]["SQ_INSTS_MFMA"] / nd1 * 2048.0)
+            res["roofline"]["valu_insts_per_mfma"] = None if stale else pj["pmc1"][kname]["SQ_INSTS_VALU"] / pj["pmc1"][kname]["SQ_INSTS_MFMA"] - 1.0
+        except (KeyError, ValueError, ZeroDivisionError):
             pass
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(prot_v, weights, Nt, args.cpu_sample, out)
@@ -273,19 +280,88 @@ def main():
         del r, prot_v, i_ref
         out.clear()
         torch.cuda.empty_cache()
-        for key, fn in (("roofline_closed_form", closed_form_legs), ("gradient_config5", gradient_leg),
+        for key, fn in (("gradient_config5", gradient_leg),
                         ("regression_step", regression_leg), ("launch_order_16384", launch_order_leg),
                         ("objective_config4_share", objective_leg), ("config3_nnd_staircase_16384", config3_leg),
-                        ("other_architectures_4096", architectures_leg), ("config1_latency", config1_latency_leg)):
+                        ("other_architectures_4096", architectures_leg), ("config1_latency", config1_latency_leg),
+                        ("roofline_closed_form", closed_form_legs)):   # last: the driver's record keeps the tail of this line
             try:
                 res[key] = fn(ion, dev, weights)
             except Exception as e:  # informational legs only
                 res[key] = {"error": repr(e)}
             torch.cuda.empty_cache()
+        # BASELINE's metric names the HBM roofline; it applies to the lane-wise kernels (SURVEY.md finding 5).  Their figures go INSIDE
+        # `roofline` (the part of the line the driver's record keeps whole), each with the roof that actually binds it
+        res["roofline"]["hbm_side"] = hbm_side_block(res.get("roofline_closed_form"), pj_all, lib_sha, pmc)
+        res["roofline"]["other_legs"] = compact_legs(res)
     if rank == 0:
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def pmc_summary(lib_sha):
+    """The newest profiles/rNN_pmc_summary.json, preferring one collected with the library this process loaded."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_summary.json")), reverse=True)
+    loaded = []
+    for f in files:
+        try:
+            loaded.append((f, json.load(open(f))))
+        except ValueError:
+            continue
+    for f, pj in loaded:
+        if pj.get("libionode_sha256") == lib_sha:
+            return f, pj
+    return loaded[0] if loaded else (None, None)
+
+
+# bench leg -> (entry of the PMC summary: tools/collect_profiles.sh PART=2 runs the same launch through tools/bench_closed_form.py)
+HBM_SIDE = (("hh2_524288", "cf7"), ("hh2_two_full_rounds", "cf5"), ("markov6_262144", "cf6"), ("markov6", "cf2"),
+            ("nnf_s03_5x10_262144", "cf4"), ("nnf_s03_5x10", "cf3"), ("nnf_s03_5x10_262144_f32", "cf8"))
+
+
+def hbm_side_block(legs, pj, lib_sha, pmc_path):
+    """Compact per-kernel block for the driver-kept `roofline` dict: HBM fraction measured in THIS run (events on the launch stream) and,
+    from the matching rocprofv3 --pmc entry, the vector-issue fraction: SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x launch cycles), and
+    VALU-busy = SQ_ACTIVE_INST_VALU x 4 / (same denominator) -- null (+ stale flag) when the counters belong to another build."""
+    if not isinstance(legs, dict) or "error" in legs:
+        return {"error": "closed-form legs did not run"}
+    stale = pj is None or pj.get("libionode_sha256") != lib_sha
+    out = {"pmc": os.path.basename(pmc_path) if pmc_path else None, "pmc_stale": stale,
+           "valu_issue_frac": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)", "peak_GBs": PEAK_HBM_GBS}
+    for leg, cf in HBM_SIDE:
+        v = legs.get(leg)
+        if not isinstance(v, dict):
+            continue
+        e = {"kernel": v["kernel"].replace("ionode_dopri5_kernel", "k"), "trajectories": v["trajectories"], "kernel_ms": round(v["kernel_ms"], 3),
+             "frac": round(v["frac"], 4), "valu_issue_frac": None, "valu_busy": None, "binds": None}
+        try:
+            if not stale:
+                a = next(iter(pj[cf + "a"].values())); b = next(iter(pj[cf + "b"].values()))
+                cyc = b["GRBM_GUI_ACTIVE"] / 8.0 / max(1, b.get("dispatches", 1))
+                nd = max(1, a.get("dispatches", 1))
+                e["valu_issue_frac"] = round(a["SQ_INSTS_VALU"] / nd * 4.0 / (1024.0 * cyc), 4)
+                e["valu_busy"] = round(a["SQ_ACTIVE_INST_VALU"] / nd * 4.0 / (1024.0 * cyc), 4)
+                e["pmc_kernel_ms"] = round(cyc / 2.4e6, 3)
+                # the binding roof: vector issue when the VALU is busy most of the launch, else the store pattern / latency
+                e["binds"] = "valu-issue" if e["valu_busy"] >= 0.7 else ("store-pattern+valu" if e["valu_busy"] >= 0.55 else "latency")
+        except (KeyError, StopIteration, ZeroDivisionError):
+            pass
+        out[leg] = e
+    return out
+
+
+def compact_legs(res):
+    """One number per extra leg, inside `roofline` (see hbm_side_block): the review's targets can be read from the kept record."""
+    g = lambda d, *ks: (None if not isinstance(d, dict) else (g(d.get(ks[0]), *ks[1:]) if len(ks) > 1 else d.get(ks[0])))
+    r3 = lambda x: None if x is None else round(float(x), 4)
+    return {"config1_latency_ms_per_call": r3(g(res, "config1_latency", "ms_per_call")),
+            "gradient_config5": {k: r3(g(res, "gradient_config5", k)) for k in ("forward_with_checkpoints_s", "backward_s", "frac")},
+            "regression_step": {k: r3(g(res, "regression_step", k)) for k in ("ms_per_iteration", "frac")},
+            "architectures_frac": {k: r3(g(res, "other_architectures_4096", k, "frac")) for k in ("s09_5x100", "s11_10x100", "s06_5x500")},
+            "launch_order_16384_frac": {k: r3(g(res, "launch_order_16384", k, "frac_of_fp32_peak")) for k in ("arbitrary_order", "previous_nfe_order")},
+            "config3_nnd_16384_frac": {k: r3(g(res, "config3_nnd_staircase_16384", k, "frac_of_fp32_peak")) for k in ("index_order", "previous_nfe_order")}}
 
 
 def _timed(fn, reps):
@@ -379,10 +455,7 @@ def closed_form_legs(ion, dev, weights):
                                        "note": "ms includes the protocol-at-outputs pre-pass (64 x 20001 lookups)"}
     del params, y0t, hold
     torch.cuda.empty_cache()
-    legs["note"] = ("2-state: vector ALU 79 % busy AND on the ceiling of its store pattern -- a store-only probe of the same pattern "
-                    "(544-byte runs per trajectory and step) reaches 4.2 TB/s = 0.52 of peak (profiles/r04_hbm_write_probe.md); 6-state: "
-                    "latency-bound at two wavefronts per SIMD; 5x10 net: vector-issue bound (DESIGN.md 5.1; counters: "
-                    "profiles/r04_pmc_summary.json cf1-cf6)")
+    legs["note"] = "binding roof per kernel: roofline.hbm_side; store-pattern ceiling: profiles/r04_hbm_write_probe.md"
     return legs
 
 
@@ -434,6 +507,7 @@ def gradient_leg(ion, dev, weights):
         y, status = ion.grad.solve(capi.MODEL_NNF, w, params, pv, y0, te, mlp_layers=MLP_L, mlp_width=MLP_N, prot_t0=0.0,
                                    prot_dt=0.1, t_eval_hint=(0.0, 0.1))
         torch.cuda.synchronize(); t1 = time.perf_counter()
+        fwd_kernel = capi.lib().ionode_last_kernel_name().decode()   # the forward that was timed (with checkpoints)
         ((y[..., 0] * y[..., 1]).double() * vobs).abs().mean().backward()   # mean |i - 0| (train-s1.py:329)
         torch.cuda.synchronize(); t2 = time.perf_counter()
         times.append((t1 - t0, t2 - t1))
@@ -450,7 +524,7 @@ def gradient_leg(ion, dev, weights):
     f_bwd = float(stats[:, 0].sum()) * 6 * 3 * F_MLP
     return {"workload": "configs[4]: dL/dW through odeint, NN-f s00, 1024 trajectories (1/8 of the 8192-trajectory batch), "
                         "fp32 state, sine-wave protocols, N_t = N_p = 100001", "forward_with_checkpoints_s": fwd, "backward_s": bwd,
-            "forward_kernel": st["kernel"], "trajectories_per_s_fwd_bwd": B / (fwd + bwd), "grad_w_norm": gnorm, "ok": int((status == 0).sum().item()),
+            "forward_kernel": fwd_kernel, "trajectories_per_s_fwd_bwd": B / (fwd + bwd), "grad_w_norm": gnorm, "ok": int((status == 0).sum().item()),
             "flop_forward": f_fwd, "flop_backward": f_bwd, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
             "frac_forward": f_fwd / fwd / 1e12 / PEAK_FP32_TFLOPS, "frac_backward": f_bwd / bwd / 1e12 / PEAK_FP32_TFLOPS,
             "frac": (f_fwd + f_bwd) / (fwd + bwd) / 1e12 / PEAK_FP32_TFLOPS}

@@ -10,10 +10,11 @@ RHS modules (rhs.py) are integrated by the fused HIP kernel.  `func` is read at 
 
 Gradients.  Called with autograd enabled and a `func.net` parameter, a tensor-valued rate parameter or `y0` requiring
 grad, the result carries a graph: the backward sweep of grad.py (exact derivative of the executed discretisation, accepted
-steps as constants).  `odeint_adjoint` returns the same values and, when a gradient is requested, differentiates a step
-sequence capped at grad.stable_step_cap() (3 / lambda_max of the rate constants) unless the caller sets max_step: like
-torchdiffeq's continuous adjoint, that derivative stays bounded on long holds and converges to the continuous adjoint as
-rtol -> 0, whereas the exact derivative of the UNcapped sequence (odeint) amplifies rounding noise at equilibria (grad.py).
+steps as constants).  `odeint_adjoint` returns the same values and the same gradients (forward bit-identical to odeint, as
+torchdiffeq's); with `adjoint_options={"max_step": "auto"}` it differentiates a step sequence capped at grad.stable_step_cap()
+(3 / lambda_max of the rate constants): like torchdiffeq's continuous adjoint, that derivative stays bounded on long holds and
+converges to the continuous adjoint as rtol -> 0, whereas the exact derivative of the UNcapped sequence amplifies rounding noise
+at equilibria (grad.py warns).
 The reference's --adjoint flag only switches the import (train-s1.py:29-32) and never differentiates, so there is no
 reference behaviour to mirror beyond the forward values.  All RHS families of the reference are covered (NN-f / NN-d for the widths of architectures
 s00-s11 with at most 15 hidden layers; HH 2-state and 6-state in closed form); other shapes raise instead of silently returning a
@@ -130,35 +131,30 @@ def _odeint_with_grad(func, y0, t, spec, rtol, atol, options):
     return y[0].reshape((t.numel(),) + tuple(y0.shape)).to(y0.device)
 
 
-_warned_cap = False
-
-
 class StepCapNotice(UserWarning):
-    """Issued once: a differentiable odeint_adjoint call follows the capped step sequence (its forward values differ from odeint's)."""
+    """Kept for callers that filter on it (round 4 issued it when odeint_adjoint capped the step size by default; since round 5 the
+    cap is opt-in and nothing is capped silently, so it is no longer raised)."""
 
 
 def odeint_adjoint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, event_fn=None,
                    adjoint_rtol=None, adjoint_atol=None, adjoint_method=None, adjoint_options=None, adjoint_params=None):
-    """`from torchdiffeq import odeint_adjoint as odeint` (train-s1.py:29-32).  Under torch.no_grad() -- every call site of the
-    reference (SURVEY.md finding 3) -- this IS odeint: same kernel, same bits.
+    """`from torchdiffeq import odeint_adjoint as odeint` (train-s1.py:29-32).  Forward values are odeint's, bit for bit, with or
+    without a gradient requested -- as torchdiffeq's adjoint returns exactly odeint's forward.  Under torch.no_grad() -- every call
+    site of the reference (SURVEY.md finding 3) -- this IS odeint: same kernel, same bits.
 
-    With a gradient requested it is the STABILISED sweep: the forward solve runs with dt capped at grad.stable_step_cap()
-    (3 / lambda_max of the gating rates at the protocol's extreme voltages; `options={"max_step": ...}` or
-    `adjoint_options={"max_step": ...}` override, 0 switches the cap off) and the backward sweep differentiates that step
-    sequence.  What torchdiffeq's continuous adjoint buys -- a gradient that stays bounded where dopri5 coasts through an
-    equilibrium with h * lambda >> 1 -- is obtained this way without re-integrating the state backwards (unstable for
-    these dissipative gating equations); the capped discrete gradient converges to the continuous adjoint as rtol -> 0
-    (tests/test_gpu_round3.py::test_odeint_adjoint_is_the_stabilised_sweep).  torchdiffeq's other adjoint_* knobs tune its
+    With a gradient requested the backward is grad.py's sweep: the exact derivative of the executed step sequence.  For gradients
+    with respect to the RATE parameters through long holds that derivative amplifies rounding noise (dopri5 coasts through an
+    equilibrium with h * lambda >> 1; grad.solve raises a RuntimeWarning).  The STABILISED sweep is opt-in:
+    `adjoint_options={"max_step": "auto"}` (or a number of milliseconds; `options={"max_step": ...}` does the same for both names)
+    runs the forward with dt capped at grad.stable_step_cap() (3 / lambda_max of the gating rates at the protocol's extreme
+    voltages) and differentiates that step sequence.  What torchdiffeq's continuous adjoint buys -- a gradient that stays bounded
+    at equilibria -- is obtained this way without re-integrating the state backwards (unstable for these dissipative gating
+    equations); the capped discrete gradient converges to the continuous adjoint as rtol -> 0
+    (tests/test_gpu_round3.py::test_odeint_adjoint_is_the_stabilised_sweep); its forward values then follow the capped sequence and
+    differ from odeint's at the rtol level -- which is why it is never the default.  torchdiffeq's other adjoint_* knobs tune its
     adjoint ODE solve and have no counterpart here: accepted and ignored."""
     options = dict(options or {})
-    if torch.is_grad_enabled() and _wants_grad(func, y0) and "max_step" not in options:
-        options["max_step"] = (adjoint_options or {}).get("max_step", "auto")
-        global _warned_cap
-        if not _warned_cap and options["max_step"] == "auto":
-            # torchdiffeq's odeint_adjoint returns exactly odeint's forward values; here a differentiable call follows the CAPPED step
-            # sequence, so its forward values differ (at the solver's tolerance) from odeint's and from the same call under no_grad
-            _warned_cap = True
-            warnings.warn("odeint_adjoint with a gradient requested caps the step size (max_step='auto', the stabilised sweep): its "
-                          "forward values follow the capped step sequence and differ at the rtol level from odeint / the no_grad call. "
-                          "Pass adjoint_options={'max_step': 0} for the uncapped, reference-exact forward.", StepCapNotice, stacklevel=2)
+    cap = (adjoint_options or {}).get("max_step")
+    if cap is not None and "max_step" not in options and torch.is_grad_enabled() and _wants_grad(func, y0):
+        options["max_step"] = cap
     return odeint(func, y0, t, rtol=rtol, atol=atol, method=method, options=options, event_fn=event_fn)

@@ -13,6 +13,8 @@ no reference source file is imported, executed or copied.  Outputs (all little-e
   ap2hz.f64             35000 x 2 fp64: time [ms] (csv seconds * 1e3, as the reference
                         scales it, train-s1.py:44-45) and voltage [mV]
   kat_losses.json       the 26 recorded '--pred' losses of s1/s2/d1/d2 'log2'
+  fig0s_hh_r.f32        the reference's r(t) state trace of figure-0-s (fp32, every 10th sample): i_n / (a_n (v + 86)),
+                        figure-0-s.py:147-153,196-200
   fig0s_hh_current.f64  figure-0-s/i_n.pt minus its seeded noise (figure-0-s.py:31,141-144),
                         decimated x10 -> 8001 fp64 samples of the HH current trace
 """
@@ -82,6 +84,14 @@ def fig0s():
     noise = np.random.normal(0, 0.1, 80001)
     clean = i_n - noise
     clean[::10].astype("<f8").tofile(os.path.join(OUT, "fig0s_hh_current.f64"))
+    # the reference's own r(t) = odeint(...)[:, 0, 1] of the same solve family (figure-0-s.py:147-153), recovered from what the
+    # script cached: a_noisy = i_noisy / (g * r * (v - e)) (figure-0-s.py:196-200, g = 1, e = -86) => r = i_n / (a_n * (v + 86)).
+    # The quotient lands on the fp32 grid to 2e-16: these ARE the fp32 state values torchdiffeq returned -- a state-level golden.
+    a_n = torch.load(os.path.join(REF, "figure-0-s", "a_n.pt"), weights_only=True)[0].numpy().reshape(-1).astype(np.float64)
+    v = torch.load(os.path.join(REF, "figure-0-s", "v.pt"), weights_only=True)[0].numpy().reshape(-1).astype(np.float64)
+    r = i_n.astype(np.float64) / (a_n * (v + 86.0))
+    assert np.isfinite(r).all() and np.abs(r - r.astype(np.float32)).max() <= 1e-15 * np.abs(r).max() * 4
+    r[::10].astype("<f4").tofile(os.path.join(OUT, "fig0s_hh_r.f32"))
 
 
 if __name__ == "__main__":

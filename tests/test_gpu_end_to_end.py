@@ -91,7 +91,7 @@ def test_simulate_preprocess_train_predict_finetune(ion, gpu):
     t32 = torch.from_numpy(te).float()
 
     def trace_loss():
-        yy = odeint_adjoint(f_tr, torch.tensor([[0.0, 1.0]]), t32)[:, 0].double()
+        yy = odeint_adjoint(f_tr, torch.tensor([[0.0, 1.0]]), t32, adjoint_options={"max_step": "auto"})[:, 0].double()
         return torch.mean(torch.abs(yy[:, 0] * yy[:, 1] * vt - it))                           # train-s1.py:328-329
     l0 = trace_loss()
     l0.backward()

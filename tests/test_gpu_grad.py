@@ -92,13 +92,17 @@ def _module(name):
     return func
 
 
-@pytest.mark.parametrize("adjoint", [False, True])
+@pytest.mark.parametrize("adjoint", [False, True, "capped"])
 def test_dropin_odeint_gives_module_gradients(ion, gpu, adjoint):
     """`from torchdiffeq import odeint_adjoint as odeint` (train-s1.py:29-32) on a reference-style module: parameters of
-    func.net receive gradients equal to the batched path's -- odeint: the exact derivative of the reference step sequence,
-    odeint_adjoint: the stabilised sweep (step sequence capped at grad.stable_step_cap, round 3)."""
+    func.net receive gradients equal to the batched path's -- odeint and odeint_adjoint: the exact derivative of the reference step
+    sequence (round 5: the adjoint name no longer changes the forward); adjoint_options={"max_step": "auto"}: the stabilised sweep
+    (step sequence capped at grad.stable_step_cap, opt-in)."""
+    import functools
     import torchdiffeq
     odeint = torchdiffeq.odeint_adjoint if adjoint else torchdiffeq.odeint
+    if adjoint == "capped":
+        odeint = functools.partial(torchdiffeq.odeint_adjoint, adjoint_options={"max_step": "auto"})
     func = _module("d2")
     pv, te, params, pot, y0, coef = F.problem("d2")
     func.set_fixed_form_voltage_protocol(np.arange(pv.shape[1], dtype=np.float64), pv[0])
@@ -114,7 +118,7 @@ def test_dropin_odeint_gives_module_gradients(ion, gpu, adjoint):
     w = torch.from_numpy(K.load_weights("d2").copy()).to(gpu).requires_grad_(True)
     yb, _ = ion.grad.solve(K.MODEL_NND, w, torch.from_numpy(params[:1]).to(gpu), torch.from_numpy(pv[:1]).to(gpu),
                            torch.from_numpy(y0[:1]).to(gpu), torch.from_numpy(te).to(gpu), mlp_layers=5, mlp_width=200,
-                           prot_t0=0.0, prot_dt=1.0, max_step=("auto" if adjoint else 0.0))
+                           prot_t0=0.0, prot_dt=1.0, max_step=("auto" if adjoint == "capped" else 0.0))
     (yb[0] * torch.from_numpy(coef[0]).to(gpu)).sum().backward()
     assert np.array_equal(y.detach().numpy()[:, 0, :], yb.detach().cpu().numpy()[0])
     assert _rel(got, w.grad.cpu().numpy()) < 1e-6 and y0t.grad is not None

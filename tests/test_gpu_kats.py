@@ -58,3 +58,7 @@ def test_figure0s_golden_trace_on_gpu(ion, gpu):
     g = run_gpu(ion, gpu, K.MODEL_HH2, K.P_HH, v, [0.0, 1.0], te, f32=True, prot_t0=0.0, prot_dt=0.1, current=True)
     i = g["i"][0][::10]
     assert np.linalg.norm(i - gold) / np.linalg.norm(gold) <= 5e-6
+    # state-level golden: the reference's own r(t) (tests/golden/make_fixtures.py fig0s_hh_r.f32; figure-0-s.py:147-153,196-200)
+    gr = np.fromfile(K.GOLDEN + "/fig0s_hh_r.f32", dtype="<f4").astype(np.float64)
+    r = g["y"][0][::10, 1].astype(np.float64)
+    assert np.linalg.norm(r - gr) / np.linalg.norm(gr) <= 1e-6 and np.abs(r - gr).max() <= 2e-5   # north_star's 1e-6 relative L2

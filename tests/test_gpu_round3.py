@@ -219,8 +219,9 @@ def test_six_state_model_at_large_batches(ion, gpu, oracle, f32):
 
 
 def test_odeint_adjoint_is_the_stabilised_sweep(ion, gpu):
-    """`from torchdiffeq import odeint_adjoint` (train-s1.py:29-32).  Without a gradient request: odeint's bits.  With one: the step
-    sequence is capped at 3 / lambda_max, so the rate-parameter gradient of a long hold stays bounded in fp32 state and no warning is
+    """`from torchdiffeq import odeint_adjoint` (train-s1.py:29-32).  Forward values: odeint's bits, with or without a gradient request
+    (round 5: torchdiffeq's adjoint returns odeint's forward exactly, so the cap is opt-in).  With adjoint_options={"max_step": "auto"}
+    the step sequence is capped at 3 / lambda_max, so the rate-parameter gradient of a long hold stays bounded in fp32 state and no warning is
     raised; as the tolerance tightens the capped discrete gradient converges (to the continuous adjoint's value): rtol 1e-7 against
     rtol 1e-10 agree to 1e-4 relative, and both agree with central finite differences of the forward solve."""
     import ref_style_modules as M
@@ -238,13 +239,20 @@ def test_odeint_adjoint_is_the_stabilised_sweep(ion, gpu):
 
     f, y0 = make(torch.float32)
     with torch.no_grad():
-        assert torch.equal(odeint_adjoint(f, y0, te), odeint(f, y0, te))
+        plain = odeint(f, y0, te)
+        assert torch.equal(odeint_adjoint(f, y0, te), plain)
+    with pytest.warns(RuntimeWarning, match="UNCAPPED"):          # default: reference-exact forward, the uncapped derivative warns
+        yg = odeint_adjoint(f, y0, te)
+    assert yg.requires_grad and torch.equal(yg.detach(), plain)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        assert torch.equal(odeint(f, y0, te).detach(), plain)
     grads = {}
     for dtype, rtol in ((torch.float32, 1e-7), (torch.float64, 1e-7), (torch.float64, 1e-10)):
         f, y0 = make(dtype)
         with warnings.catch_warnings():
             warnings.simplefilter("error", RuntimeWarning)
-            y = odeint_adjoint(f, y0, te.to(dtype), rtol=rtol, atol=rtol * 1e-2)
+            y = odeint_adjoint(f, y0, te.to(dtype), rtol=rtol, atol=rtol * 1e-2, adjoint_options={"max_step": "auto"})
         (y[:, 0, 0] * y[:, 0, 1]).double().sum().backward()
         grads[(dtype, rtol)] = float(f.p7.grad)
         assert np.isfinite(grads[(dtype, rtol)])

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Run ON THE GPU BOX (gpurun): the round's evidence.  Every rocprofv3 run puts the program itself after `--`; counters are
 # collected in their own passes (no --kernel-trace with --pmc).  Results land under gpurun_out/${R}_prof/ (R = r03 by default);
-# tools/copy_profiles.py copies the summaries into profiles/ (tracked).  Usage on the box: R=r04 bash tools/collect_profiles.sh
+# tools/copy_profiles.py copies the summaries into profiles/ (tracked).  Usage on the box: R=r05 bash tools/collect_profiles.sh
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
-R=${R:-r04}
+R=${R:-r05}
 O=gpurun_out/${R}_prof; mkdir -p $O
 python3 -c "import importlib,sys; sys.path.insert(0,'.'); print(importlib.import_module('neural-ode-ion-channels_amd').capi.library_digest())" > $O/libionode.sha256
 # two halves (a gpurun call is limited to 20 minutes): PART=1 bench line + kernel traces + headline counters, PART=2 the lane-wise
@@ -26,14 +26,16 @@ if [[ $PART == *2* ]]; then
 # the HBM-side kernels: HH 2-state (two residency rounds), 6-state, both N <= 16 kernels (16 / 64 trajectories per wavefront),
 # HH again with the library's default (protocol-major) launch order, and the 6-state two-per-SIMD build (262144)
 i=0
-for C in "--model hh --batch 393216 --index-order" "--model m6 --batch 65536" "--model nnf --batch 65536" "--model nnf --batch 262144" "--model hh --batch 393216" "--model m6 --batch 262144"; do
+# (cf7, cf8 since round 5: the 2-state kernel at two full residency rounds, and the 5 x 10 net in the reference's fp32 state -- every
+# entry of bench.py's roofline.hbm_side has its counters)
+for C in "--model hh --batch 393216 --index-order" "--model m6 --batch 65536" "--model nnf --batch 65536" "--model nnf --batch 262144" "--model hh --batch 393216" "--model m6 --batch 262144" "--model hh --batch 524288" "--model nnf --batch 262144 --f32"; do
   i=$((i+1)); A="$C --nt 20001 --reps 1"
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_INSTS_SALU --output-format csv -d $O/cf${i}a -- python3 tools/bench_closed_form.py $A > /dev/null 2> $O/cf${i}a.err || exit 1
   rocprofv3 --pmc GRBM_GUI_ACTIVE FETCH_SIZE --output-format csv -d $O/cf${i}b -- python3 tools/bench_closed_form.py $A > /dev/null 2> $O/cf${i}b.err || exit 1
   rocprofv3 --pmc WRITE_SIZE TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/cf${i}c -- python3 tools/bench_closed_form.py $A > /dev/null 2> $O/cf${i}c.err || exit 1
 done
 fi
-for p in pmc1 pmc2 pmc3 pmc4 cf1a cf1b cf1c cf2a cf2b cf2c cf3a cf3b cf3c cf4a cf4b cf4c cf5a cf5b cf5c cf6a cf6b cf6c; do [ -d $O/$p ] && python3 tools/pmc_summary.py $O/$p > $O/$p.json; done
+for p in pmc1 pmc2 pmc3 pmc4 cf1a cf1b cf1c cf2a cf2b cf2c cf3a cf3b cf3c cf4a cf4b cf4c cf5a cf5b cf5c cf6a cf6b cf6c cf7a cf7b cf7c cf8a cf8b cf8c; do [ -d $O/$p ] && python3 tools/pmc_summary.py $O/$p > $O/$p.json; done
 [ -d $O/trace ] && find $O/trace -name "*kernel_stats.csv" -exec cp {} $O/${R}_kernel_stats.csv \;
 [ -d $O/trace_legs ] && find $O/trace_legs -name "*kernel_stats.csv" -exec cp {} $O/${R}_kernel_stats_legs.csv \;
 # keep the merge small: drop the raw per-dispatch traces
