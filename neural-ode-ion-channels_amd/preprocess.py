@@ -2,7 +2,8 @@
 path: numpy / SciPy, as in the reference.  It turns measured current traces into the (V, a) -> da/dt rows the MLP
 regression step (regression.py) trains on, and reads / writes the reference's checkpoint files.
 
-Reference: smoothing.py:73-129 (`smooth`), train-s1.py:603-808 (estimating a and da/dt from i(t)), train-r1.py:61-72
+Reference: smoothing.py:73-129 (`smooth`), train-s1.py:603-808 (estimating a and da/dt from i(t)), train-r1.py:422-679 (the
+real-data route: tri- / bi-exponential fits of a(t) per voltage step with analytic derivatives), train-r1.py:61-72
 (`save_ckp` / `load_ckp`), train-s1.py:891 ff. (the cached s1/{v,a,dadt}.pt these functions reproduce).
 """
 import numpy as np
@@ -52,6 +53,90 @@ def fit_current(t, i, prot_t, prot_v, window_len=61):
         didt = np.append(didt, spl.derivative()(t[idx]))
         t_lo = t_hi
     return i_fit, didt
+
+
+# ---- real-data route (train-r1.py:422-679): a(t) of a voltage step is a sum of decaying exponentials; fit it, differentiate analytically ----
+
+TRI_EXP_X0 = (1.0, 1.0 / 100.0, 0.5, 1.0 / 200.0, 0.25, 1.0 / 400.0, 0.1)      # train-r1.py:426 (activation protocol)
+TRI_EXP_X0_SLOW = (0.7, 1.0 / 50.0, 0.2, 1.0 / 100.0, 0.1, 1.0 / 200.0, 0.01)   # train-r1.py:425 (sine-wave / AP protocols)
+BI_EXP_X0 = (0.7, 1.0 / 50.0, 0.2, 1.0 / 100.0, 0.01)                           # train-r1.py:440
+
+
+def multi_exp(t, x, order=0):
+    """sum_j A_j exp(-b_j t) + offset and its first / second time derivative: x = (A_1, b_1, ..., A_n, b_n, offset) with n = 3
+    (tri_exp / dtri_exp / d2tri_exp, train-r1.py:427-438) or n = 2 (bi_exp / dbi_exp / d2bi_exp, train-r1.py:441-451)."""
+    t = np.asarray(t, dtype=np.float64)
+    x = np.asarray(x, dtype=np.float64)
+    if x.size not in (5, 7):
+        raise ValueError("multi_exp: 5 (bi-exponential) or 7 (tri-exponential) parameters")
+    amp, rate = x[0:-1:2], x[1:-1:2]
+    out = np.zeros(t.shape)
+    for a, b in zip(amp, rate):   # in the reference's order a*exp(-b t) + c*exp(-d t) + e*exp(-f t) [+ g]
+        out = out + ((-b) ** order * a) * np.exp(-b * t)
+    return out + x[-1] if order == 0 else out
+
+
+def fit_multi_exp(t, a, x0, restarts=0, seed=0):
+    """Nelder-Mead minimisation of the RMSE of multi_exp(t, x) against a (scipy.optimize.fmin, as train-r1.py:487-489).  The
+    reference hands its hardest segments (the -90 mV steps) to PINTS' CMA-ES (train-r1.py:553-555); PINTS is an absent third-party
+    dependency, so `restarts` > 0 re-runs the simplex from log-normal perturbations of x0 (seeded) and keeps the best."""
+    from scipy import optimize
+    t, a = np.asarray(t, dtype=np.float64), np.asarray(a, dtype=np.float64)
+    f = lambda x: np.sqrt(np.mean((multi_exp(t, x) - a) ** 2))
+    best = optimize.fmin(f, np.asarray(x0, dtype=np.float64), disp=False)
+    rng = np.random.default_rng(seed)
+    for _ in range(int(restarts)):
+        x = optimize.fmin(f, np.asarray(x0) * np.exp(rng.normal(0.0, 0.5, len(x0))), disp=False)
+        if f(x) < f(best):
+            best = x
+    return best
+
+
+def fit_activation(prot_t, a, change_mask, cap_mask, std_cutoff=0.01, x0=TRI_EXP_X0, bi_exp_at=(), spline_at=(), restart_segments=(),
+                   restarts=4, spline_window=51, spline_k=4, spline_s=0.2):
+    """a(t), da/dt, d2a/dt2 on the whole time grid of one real-data protocol, segment by segment (train-r1.py:453-679).
+
+    prot_t [n] sample times; a [n] the activation estimate i / (g r (V - E)); change_mask [n] False exactly AT the voltage change
+    points (the reference's `change_pt*`: t_split = prot_t[~change_mask]); cap_mask [n] True where the sample is usable (capacitive
+    spikes removed, `cap_mask*`).  Per constant-voltage segment:
+      * std(a) > std_cutoff: the gate is moving -- tri-exponential fit of the raw samples (bi-exponential where the segment contains
+        one of `bi_exp_at`, train-r1.py:631-636), evaluated with its analytic derivatives on the segment's full grid;
+        segments whose index is in `restart_segments` take the restarted simplex (the reference's CMA-ES cases);
+      * otherwise, or where the segment contains one of `spline_at` (the sine-wave window at 3500 ms: smooth(a, 21), k = 5,
+        train-r1.py:565-573): Hanning smoothing + UnivariateSpline(k = spline_k, s = spline_s), derivatives from the spline.
+    Returns (a_fit, dadt, d2adt2, kinds): arrays [n] (zero outside every fitted segment, as the reference leaves them) and the
+    list of (t_first, t_last, 'tri-exp' | 'bi-exp' | 'spline') per segment."""
+    from scipy.interpolate import UnivariateSpline
+    prot_t, a = np.asarray(prot_t, dtype=np.float64), np.asarray(a, dtype=np.float64).reshape(-1)
+    change_mask, cap_mask = np.asarray(change_mask, dtype=bool), np.asarray(cap_mask, dtype=bool)
+    within = lambda r, x: (np.min(r) < x) and (np.max(r) > x)
+    t_split = np.append(prot_t[~change_mask], prot_t[-1] + 1)
+    tt, aa = prot_t[cap_mask], a[cap_mask]
+    ao, d1, d2 = np.zeros(prot_t.shape), np.zeros(prot_t.shape), np.zeros(prot_t.shape)
+    kinds = []
+    t_lo = 0
+    for seg, t_hi in enumerate(t_split):
+        idx = np.where((tt >= t_lo) & (tt < t_hi))[0]
+        t_lo = t_hi
+        if idx.size == 0:
+            continue
+        tfit = tt[idx]
+        full = np.where((prot_t >= tfit[0]) & (prot_t <= tfit[-1]))[0]
+        sine = any(within(tfit, x) for x in spline_at)
+        if np.std(aa[idx]) > std_cutoff and not sine:
+            bi = any(within(tfit, x) for x in bi_exp_at)
+            t0 = tfit - tfit[0]
+            x = fit_multi_exp(t0, aa[idx], BI_EXP_X0 if bi else x0, restarts=restarts if seg in restart_segments else 0)
+            tf = prot_t[full] - tfit[0]
+            ao[full], d1[full], d2[full] = multi_exp(tf, x), multi_exp(tf, x, 1), multi_exp(tf, x, 2)
+            kinds.append((tfit[0], tfit[-1], "bi-exp" if bi else "tri-exp"))
+        else:
+            w, k = (21, 5) if sine else (spline_window, spline_k)
+            spl = UnivariateSpline(tfit, smooth(aa[idx], w)[w // 2:-(w // 2)], k=k)
+            spl.set_smoothing_factor(spline_s)
+            ao[full], d1[full], d2[full] = spl(prot_t[full]), spl(prot_t[full], 1), spl(prot_t[full], 2)
+            kinds.append((tfit[0], tfit[-1], "spline"))
+    return ao, d1, d2, kinds
 
 
 def state_space_samples(i_fit, didt, r, drdt, v, g=1.0, e=-86.0, dvdt=0.0):
