@@ -161,9 +161,20 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false, bool ex
     const bool leanm = !t64 && (NT == 13 || NT == 7 || NT == 32) && d->mlp_layers >= 1 && !explicit_grid && !has_step_log && !d->ckpt && d->t_eval_exact && d->t_eval_dt_hint > 0.0 && d->n_out > 1;
     pl->v = t64 ? find_variant(d->model, f32, 1, NT, 64, t64lean, vnet ? 10 : 1)
                 : find_variant(d->model, f32, ((d->tile_waves == 8 || d->tile_waves == 2) ? 4 : d->tile_waves), NT, NT == 1 ? 1 : -1, (t32 ? 4 : 0) | (leanm ? 8 : 0) | (t4 ? 16 : 0));
+    // any other width up to 512 (table-s1.py:145-153 builds nets of any (n_layers, n_nodes)): the run-time-width tile (MlpGen)
+    bool gen = false;
+    if (!pl->v && NT >= 2 && NT <= ionode::MlpGen::NT_MAX && (d->tile_waves == 0 || d->tile_waves == 4)) {
+      const bool leang = d->mlp_layers >= 1 && !explicit_grid && !has_step_log && !d->ckpt && d->t_eval_exact && d->t_eval_dt_hint > 0.0 && d->n_out > 1;
+      pl->v = find_variant(d->model, f32, 4, 0, 1, leang ? 8 : 0);
+      gen = pl->v != nullptr;
+      if (gen && ionode::MlpGen::lds_bytes(d->mlp_layers, NT) > 160 * 1024) {
+        set_err("this (layers, width) needs more than 160 KB of LDS for its biases and activations");
+        return IONODE_ERR_UNSUPPORTED;
+      }
+    }
     if (!pl->v) {
-      set_err("MLP width outside the compiled kernel variants: N must pad to 16, 112, 208 or 512 "
-              "(architectures s00-s11: N = 10, 100, 200, 500)");
+      set_err("MLP width outside the compiled kernel variants: 1 <= N <= 512 (tuned tiles for N = 10, 100, 200, 500 -- architectures "
+              "s00-s11 -- and the run-time-width tile for every other N; tile_waves must be 0 or 4 for the latter)");
       return IONODE_ERR_UNSUPPORTED;
     }
     pl->grid = t64 ? (unsigned)((d->n_traj + 63) / 64) : (t32 ? (unsigned)((d->n_traj + 31) / 32) : (t4 ? (unsigned)((d->n_traj + 3) / 4) : (unsigned)((d->n_traj + 15) / 16)));
@@ -171,7 +182,8 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false, bool ex
     const int Gv = pl->v->G, Rv = NT - Gv * (NT / Gv);  // remainder row tiles: K-split partial sums in LDS
     pl->lds = ((size_t)2 * (NT + Gv - 1) * 64 + (size_t)2 * Rv * Gv * 64 + NP) * 16 + ((size_t)d->mlp_layers * NP + NP + 4) * 4;
     // the asm tile (N = 200): + scratch slot (+ the input exchange of the two-column-set tile), MlpTile::lds_total
-    if (t4) pl->lds = ionode::MlpTile4::lds_bytes(d->mlp_layers);
+    if (gen) pl->lds = ionode::MlpGen::lds_bytes(d->mlp_layers, NT);
+    else if (t4) pl->lds = ionode::MlpTile4::lds_bytes(d->mlp_layers);
     else if (Gv == 4 && NT == 13) pl->lds = t32 ? ionode::MlpTile<4, 4, 13, 13, 4>::lds_total(d->mlp_layers) : ionode::MlpTile<4, 4, 13, 13, 0>::lds_total(d->mlp_layers);
     if (t64) plan_lane_wise(pl, (size_t)((d->n_traj + 63) / 64), (vnet ? (size_t)0 : ((pl->lds + 15) & ~(size_t)15)) + (size_t)ionode::LwLds::bytes(2, t64lean));  // MlpTile region + the lane-wise region
   }
@@ -225,8 +237,16 @@ static size_t frags_per_wave(int NT, int G) {
   return (size_t)NT * F + (size_t)NOWN * R;
 }
 
+// widths without a tuned tile: the image of the run-time-width tile (ionode_device.hpp MlpGen)
+static bool generic_width(int N) {
+  int G, RT;
+  const int NT = np_of(N) / 16;
+  return N >= 1 && !tile_shape(N, &G, &RT) && NT >= 2 && NT <= ionode::MlpGen::NT_MAX;
+}
+
 size_t ionode_mlp_packed_floats(int32_t L, int32_t N) {
   int G, RT;
+  if (L >= 0 && generic_width(N)) return ionode::MlpGen::image_floats(L, np_of(N) / 16);
   if (L < 0 || N < 1 || !tile_shape(N, &G, &RT)) return 0;
   const size_t NP = (size_t)np_of(N), NT = NP / 16;
   // N <= 16: + the scalar section of the per-lane net (row PAIRS: layer 0, then per hidden layer the weights in the canonical k order, bias, pad)
@@ -240,7 +260,36 @@ size_t ionode_mlp_packed_floats(int32_t L, int32_t N) {
 int ionode_mlp_pack(const float *w, int32_t L, int32_t N, float *out) {
   int G, RT;
   if (!w || !out || L < 0 || N < 1) { set_err("ionode_mlp_pack: bad argument"); return IONODE_ERR_ARG; }
-  if (!tile_shape(N, &G, &RT)) { set_err("ionode_mlp_pack: MLP width outside the compiled kernel variants"); return IONODE_ERR_UNSUPPORTED; }
+  if (generic_width(N)) {
+    // MlpGen: [NP][4]{b0, w00, w01, 0} | L x ([rt][kt][lane = 16 q + m] float4 over r of W[16 rt + m][16 kt + 4 q + r], then bias[NP]) | wl[NP], bl
+    const int NP = np_of(N), NT = NP / 16;
+    memset(out, 0, ionode_mlp_packed_floats(L, N) * sizeof(float));
+    const float *W0 = w, *b0 = w + (size_t)N * 2;
+    for (int r = 0; r < N; ++r) { out[4 * r + 0] = b0[r]; out[4 * r + 1] = W0[2 * r + 0]; out[4 * r + 2] = W0[2 * r + 1]; }
+    const float *src = b0 + N;
+    float *dst = out + 4 * (size_t)NP;
+    for (int l = 0; l < L; ++l) {
+      const float *W = src, *b = src + (size_t)N * N;
+      for (int rt = 0; rt < NT; ++rt)
+        for (int kt = 0; kt < NT; ++kt)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int m = lane & 15, q = lane >> 4, row = 16 * rt + m;
+            float *f = dst + (((size_t)rt * NT + kt) * 64 + lane) * 4;
+            for (int r = 0; r < 4; ++r) {
+              const int k = 16 * kt + 4 * q + r;
+              f[r] = (row < N && k < N) ? W[(size_t)row * N + k] : 0.0f;
+            }
+          }
+      float *bias = dst + (size_t)NT * NT * 256;
+      for (int r = 0; r < N; ++r) bias[r] = b[r];
+      src += (size_t)N * N + N;
+      dst += ionode::MlpGen::layer_floats(NT);
+    }
+    for (int k = 0; k < N; ++k) dst[k] = src[k];
+    dst[NP] = src[N];
+    return IONODE_OK;
+  }
+  if (!tile_shape(N, &G, &RT)) { set_err("ionode_mlp_pack: MLP width outside the supported range (1 <= N <= 512)"); return IONODE_ERR_UNSUPPORTED; }
   const int NP = np_of(N), NT = NP / 16;
   memset(out, 0, ionode_mlp_packed_floats(L, N) * sizeof(float));
   // layer 0: rows {b0, w00, w01, 0}

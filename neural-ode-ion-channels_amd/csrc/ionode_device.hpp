@@ -1284,6 +1284,138 @@ template <int N> struct MlpLane {
   __device__ __forceinline__ float eval(float x0, float x1) { return eval_tiny64(x0, x1); }
 };
 
+// ---------------------------------------------------------------------------------------------
+// ANY width up to 512 (round 5): the 16-trajectory MFMA tile with the k-tile count NT = ceil(N / 16) as a RUN-TIME value.  The widths of
+// architectures/s00-s11.py (N = 10, 100, 200, 500) have their own tuned tiles above; table-s1.py:145-153 builds Linear(2, N) ... Linear(N, 1)
+// for any (n_layers, n_nodes), and a user's --info file with N = 50 or 64 used to fall out of the fused path with an error.  No performance
+// target: weights are read from L2 as they are needed (one 16-byte load per lane and k-tile, the next one in flight), no register ring, no
+// generated stream.  SAME canonical accumulation order as every other form ("canonical arithmetic"): four wavefronts; NT = 4 F + R;
+// wavefront w owns the full row tiles rt = w, w + 4, ... < 4 F -- ONE chain seeded with the bias over the k-tiles in the rotated order
+// kt = (s + w) mod NT -- and partial chain w (k-tiles kt % 4 == w, ascending; chain 0 carries the bias) of each of the R remainder row
+// tiles, folded (p0 + p1) + (p2 + p3); Linear(N, 1): four chains by q.  lane = 16 q + m: A fragment = W[16 rt + m][16 kt + 4 q + r] over r,
+// B operand / accumulator = h[16 kt + 4 q + r][trajectory m].
+// Image (ionode_mlp_pack for widths without a tuned tile): [NP][4]{b0, w00, w01, 0} | L x ([rt][kt][lane] float4 over r, then bias[NP]) |
+// wl[NP], bl, 3 pad.
+// ---------------------------------------------------------------------------------------------
+struct MlpGen {
+  static constexpr int GW = 4;
+  static constexpr int NT_MAX = 32;
+  f32x4 *Hs, *Ps;
+  const f32x4 *W0s;
+  const float *biasS, *wlS;
+  const f32x4 *hid;    // hidden layer 0 in the image (global memory / L2)
+  size_t lstride4;     // float4 per hidden layer in the image
+  int L, NT, NP, F4, R, wave, lane;
+#ifdef IONODE_STAMPS
+  Stamps *sp;
+#endif
+  static __host__ __device__ constexpr size_t layer_floats(int NT) { return (size_t)NT * NT * 256 + (size_t)16 * NT; }
+  static __host__ __device__ constexpr size_t image_floats(int L, int NT) { return (size_t)4 * 16 * NT + (size_t)L * layer_floats(NT) + (size_t)16 * NT + 4; }
+  // activations x2, partial sums of the (at most three) remainder tiles x2, layer-0 rows; biases, output weights
+  static __host__ __device__ constexpr size_t lds_bytes(int L, int NT) {
+    return ((size_t)2 * NT * 64 + (size_t)2 * 3 * 4 * 64 + (size_t)16 * NT) * 16 + ((size_t)L * 16 * NT + (size_t)16 * NT + 4) * 4;
+  }
+  __device__ __forceinline__ void init(const KArgs &a, unsigned char *smem, int wave_, int lane_, int first_traj = 0) {
+    L = a.L; NT = a.NT; NP = 16 * NT; wave = wave_; lane = lane_;
+    F4 = 4 * (NT / 4); R = NT - F4;
+    const float *__restrict__ img = a.mlp + (a.traj_per_img > 0 ? (size_t)(first_traj / a.traj_per_img) * (size_t)a.mlp_stride : (size_t)0);
+    Hs = reinterpret_cast<f32x4 *>(smem);
+    Ps = Hs + 2 * NT * 64;
+    f32x4 *w0 = Ps + 2 * 3 * 4 * 64;
+    float *bs = reinterpret_cast<float *>(w0 + NP);
+    float *ws = bs + (size_t)L * NP;
+    const size_t lstride = layer_floats(NT);
+    const int tid = wave * 64 + lane;
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(img);
+    for (int i = tid; i < NP; i += 256) w0[i] = src[i];
+    for (int i = tid; i < L * NP; i += 256) bs[i] = img[4 * (size_t)NP + (size_t)(i / NP) * lstride + (lstride - NP) + (i % NP)];
+    const float *wl = img + 4 * (size_t)NP + (size_t)L * lstride;
+    for (int i = tid; i < NP + 4; i += 256) ws[i] = wl[i];
+    W0s = w0; biasS = bs; wlS = ws;
+    hid = src + NP;
+    lstride4 = lstride / 4;
+    __syncthreads();
+  }
+  __device__ __forceinline__ float eval(float x0, float x1) {
+    const int q = lane >> 4;
+    MSTAMP(0);
+    // layer 0: Linear(2, N) + LeakyReLU, row tile rt by wavefront rt % 4, accumulator layout
+    for (int rt = wave; rt < NT; rt += 4) {
+      f32x4 h;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const f32x4 w = W0s[16 * rt + 4 * q + r];
+        h[r] = lrelu(fmaf(w[2], x1, fmaf(w[1], x0, w[0])));
+      }
+      Hs[rt * 64 + lane] = h;
+    }
+    __syncthreads();
+    MSTAMP(1);
+    for (int l = 0; l < L; ++l) {
+      const f32x4 *__restrict__ Hin = Hs + (l & 1) * NT * 64 + lane;
+      f32x4 *__restrict__ Hout = Hs + ((l + 1) & 1) * NT * 64 + lane;
+      f32x4 *__restrict__ Pl = Ps + (l & 1) * 3 * 4 * 64 + lane;
+      const f32x4 *__restrict__ Wl = hid + (size_t)l * lstride4 + lane;
+      const float *__restrict__ bl_ = biasS + l * NP + 4 * q;
+      // full row tiles: one chain each, k-tiles in the rotated order (s + wave) mod NT; the next fragment and B operand are in flight
+      for (int rt = wave; rt < F4; rt += 4) {
+        f32x4 acc = *reinterpret_cast<const f32x4 *>(bl_ + 16 * rt);
+        const f32x4 *__restrict__ Wr = Wl + (size_t)rt * NT * 64;
+        int kt = wave;   // (wave < 4 <= F4 <= NT)
+        f32x4 a_n = Wr[kt * 64], b_n = Hin[kt * 64];
+        for (int s = 0; s < NT; ++s) {
+          const f32x4 av = a_n, bv = b_n;
+          kt = (kt + 1 == NT) ? 0 : kt + 1;
+          if (s + 1 < NT) { a_n = Wr[kt * 64]; b_n = Hin[kt * 64]; }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bv[r], acc, 0, 0, 0);
+        }
+        f32x4 h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = lrelu(acc[r]);
+        Hout[rt * 64] = h;
+      }
+      // remainder row tiles: partial chain `wave` over the k-tiles kt % 4 == wave, ascending (chain 0 is seeded with the bias)
+      for (int j = 0; j < R; ++j) {
+        const int rt = F4 + j;
+        f32x4 acc = f32x4{0, 0, 0, 0};
+        if (wave == 0) acc = *reinterpret_cast<const f32x4 *>(bl_ + 16 * rt);
+        const f32x4 *__restrict__ Wr = Wl + (size_t)rt * NT * 64;
+        for (int kt = wave; kt < NT; kt += 4) {
+          const f32x4 av = Wr[kt * 64], bv = Hin[kt * 64];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bv[r], acc, 0, 0, 0);
+        }
+        Pl[(j * 4 + wave) * 64] = acc;
+      }
+      __syncthreads();
+      // every wavefront folds the remainder tiles itself (identical bits; each reads the slot after its own write)
+      for (int j = 0; j < R; ++j) {
+        const f32x4 p0 = Pl[(j * 4 + 0) * 64], p1 = Pl[(j * 4 + 1) * 64], p2 = Pl[(j * 4 + 2) * 64], p3 = Pl[(j * 4 + 3) * 64];
+        f32x4 h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = lrelu((p0[r] + p1[r]) + (p2[r] + p3[r]));
+        Hout[(F4 + j) * 64] = h;
+      }
+      MSTAMP(3);
+    }
+    // Linear(N, 1): four partial chains (one per lane group q), fixed combine tree
+    const f32x4 *__restrict__ Hin = Hs + (L & 1) * NT * 64 + lane;
+    float part = 0.0f;
+    for (int kt = 0; kt < NT; ++kt) {
+      const f32x4 w = *reinterpret_cast<const f32x4 *>(wlS + 16 * kt + 4 * q);
+      const f32x4 h = Hin[kt * 64];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part = fmaf(w[r], h[r], part);
+    }
+    const float pair = part + __shfl_xor(part, 16);
+    const float out = (pair + __shfl_xor(pair, 32)) + wlS[NP];
+    if ((L & 1) == 0) __syncthreads();   // the next evaluation's layer 0 rewrites buffer 0
+    MSTAMP(5);
+    return out;
+  }
+};
+
 // Closed-form models carry an empty stand-in so the integrator code is shared.
 struct NoMlp {
   static constexpr int GW = 1;
@@ -1608,8 +1740,10 @@ __global__ void __launch_bounds__(64 * (IONODE_IS_LW(MODEL, RT) ? IONODE_LW_TILE
 
   // PD slot of a 64-per-wavefront MLP kernel: 1 = the MFMA form (any N <= 16), 10 = the per-lane vector-ALU net for N = 10 (MlpLane)
   constexpr bool VNET = T64 && PD > 1;
+  // NT slot == 0 of a four-wavefront MLP kernel: the run-time-width tile (MlpGen: any N <= 512 without a tuned tile of its own)
+  constexpr bool GEN = MT::MLP && G == 4 && NT == 0;
   using MlpTileT = MlpTile<G, (T64 ? 1 : (RT > 0 ? RT : 1)), (NT > 0 ? NT : 1), ((PD > 0 && !VNET) ? PD : 1), (NSETS > 1 ? 4 : 0)>;
-  using MlpT = typename std::conditional<VNET, MlpLane<(VNET ? PD : 10)>, typename std::conditional<T4, MlpTile4, MlpTileT>::type>::type;
+  using MlpT = typename std::conditional<VNET, MlpLane<(VNET ? PD : 10)>, typename std::conditional<T4, MlpTile4, typename std::conditional<GEN, MlpGen, MlpTileT>::type>::type>::type;
   typename std::conditional<MT::MLP, MlpT, NoMlp>::type mlp;
   if constexpr (MT::MLP) mlp.init(a, smem_t, wave, lane, tile * TPW);
   // lane-wise kernels: interpolant rows + tail buffers; behind the MlpTile region when there is one

@@ -54,7 +54,9 @@ hipError_t launch(const KArgs &a, unsigned grid, size_t lds, hipStream_t s) {
       /* N = 200 at FOUR trajectories per tile (TAIL & 16: MlpTile4, small batches / single calls), general and lean */ \
       IONODE_VARIANT(MODEL, S, F32, 4, 4, 13, 13, 16), IONODE_VARIANT(MODEL, S, F32, 4, 4, 13, 13, 24),   \
       /* lean variants of the N = 100 and N = 500 tiles */                                              \
-      IONODE_VARIANT(MODEL, S, F32, 4, 4, 7, 7, 8), IONODE_VARIANT(MODEL, S, F32, 4, 8, 32, 4, 8)
+      IONODE_VARIANT(MODEL, S, F32, 4, 4, 7, 7, 8), IONODE_VARIANT(MODEL, S, F32, 4, 8, 32, 4, 8),        \
+      /* any other width up to 512 (NT slot 0: MlpGen, the k-tile count is a run-time value), general and lean */ \
+      IONODE_VARIANT(MODEL, S, F32, 4, 1, 0, 1, 0), IONODE_VARIANT(MODEL, S, F32, 4, 1, 0, 1, 8)
 
 // one table per translation unit (they compile in parallel)
 const Variant *variants_closed(int *n);

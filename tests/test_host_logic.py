@@ -60,8 +60,8 @@ def test_dispatch_geometry_and_errors(ion):
     with pytest.raises(capi.IonodeError):
         capi.launch_geometry(d)
     d = capi.make_desc(model=capi.MODEL_NNF, n_state=2, n_out=10, n_traj=1, n_prot=1, prot_n=100, mlp_layers=5,
-                       mlp_width=64, n_params=8, prot_dt=0.1, rtol=1e-7, atol=1e-9)
-    with pytest.raises(capi.IonodeError, match="width"):
+                       mlp_width=640, n_params=8, prot_dt=0.1, rtol=1e-7, atol=1e-9)
+    with pytest.raises(capi.IonodeError, match="width"):      # beyond 512 (N = 64 is served since round 5: the run-time-width tile)
         capi.launch_geometry(d)
 
 
@@ -371,3 +371,36 @@ def test_lane_wise_crossovers_come_from_the_library(ion):
         per_wave = lambda g, nt: nt / (g["grid"] * (4 if g["block"] == 256 else 1))
         assert per_wave(below, n - 1) <= 16 and per_wave(at, n) > 16
     assert L.ionode_lane_wise_from(capi.MODEL_NNF, 200) == 0
+
+
+def test_every_width_up_to_512_has_a_kernel_and_an_image(ion):
+    """Round 5: widths without a tuned tile go to the run-time-width tile (NT slot 0) instead of
+    IONODE_ERR_UNSUPPORTED; the packed image of such a width is the generic layout, and beyond N = 512 the call still refuses."""
+    capi = ion.capi
+    kw = dict(model=capi.MODEL_NNF, n_state=2, n_out=10, n_traj=40, n_prot=1, prot_n=100, mlp_layers=3, n_params=8, prot_dt=0.1, rtol=1e-7, atol=1e-9)
+    tuned = {10: "1, 1, 1, 1", 16: "1, 1, 1, 1", 100: "4, 4, 7, 7", 200: "4, 4, 13, 13", 500: "4, 8, 32, 4"}
+    for N in (1, 10, 16, 17, 32, 50, 64, 96, 100, 112, 113, 150, 200, 208, 209, 300, 496, 500, 512):
+        name = capi.kernel_name(capi.make_desc(mlp_width=N, **kw))
+        NT = (N + 15) // 16
+        if NT in (1, 7, 13, 32):
+            assert name, N
+            if N in tuned:
+                assert tuned[N] in name
+        else:
+            assert ", 4, 1, 0, 1, " in name, (N, name)
+            g = capi.launch_geometry(capi.make_desc(mlp_width=N, **kw))
+            assert g["grid"] == 3 and g["block"] == 256 and g["lds_bytes"] <= 160 * 1024
+            n_w = 2 * N + N + 3 * (N * N + N) + N + 1
+            img = capi.mlp_pack(np.arange(1, n_w + 1, dtype=np.float32), 3, N)
+            NP = 16 * NT
+            assert img.size == 4 * NP + 3 * (NT * NT * 256 + NP) + NP + 4
+            # fragment (rt, kt) lane 16 q + m, component r  ==  W[16 rt + m][16 kt + 4 q + r] of hidden layer 0
+            W1 = np.arange(1, n_w + 1, dtype=np.float32)[3 * N:3 * N + N * N].reshape(N, N)
+            frag = img[4 * NP:4 * NP + NT * NT * 256].reshape(NT, NT, 64, 4)
+            for (rt, kt, lane, r) in ((0, 0, 0, 0), (NT - 1, 1, 37, 2), (1, NT - 1, 63, 3)):
+                row, k = 16 * rt + (lane & 15), 16 * kt + 4 * (lane >> 4) + r
+                assert frag[rt, kt, lane, r] == (W1[row, k] if row < N and k < N else 0.0)
+    assert capi.kernel_name(capi.make_desc(mlp_width=513, **kw)) == ""
+    with pytest.raises(capi.IonodeError):
+        capi.mlp_pack(np.zeros(2 * 600 + 600 + 600 + 1, dtype=np.float32), 0, 600)
+    assert capi.kernel_name(capi.make_desc(mlp_width=64, tile_waves=1, **kw)) == ""   # the generic tile is a four-wavefront tile
