@@ -13,6 +13,9 @@
 #ifndef IONODE_TILE4_UPTO
 #define IONODE_TILE4_UPTO 1024  // N = 200: up to this many trajectories, 4 per tile = at most one tile per compute unit (16-tiles would use <= 64 of the 256 CUs)
 #endif
+#ifndef IONODE_TILE1_UPTO
+#define IONODE_TILE1_UPTO 256   // N = 200: up to this many trajectories, ONE per tile (MlpRow1: a lane owns a row) = at most one tile per compute unit
+#endif
 #ifndef IONODE_TINY64_MFMA
 #define IONODE_TINY64_MFMA 0   // 1: N = 10 keeps the MFMA form at 64 trajectories per wavefront (A/B)
 #endif
@@ -134,8 +137,8 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false, bool ex
     if (d->mlp_width < 1 || d->mlp_layers < 0) { set_err("bad MLP shape"); return IONODE_ERR_ARG; }
     if (d->mlp_width <= 16 && d->mlp_layers > 10) { set_err("N <= 16 kernels keep at most 10 hidden layers resident"); return IONODE_ERR_UNSUPPORTED; }
     const int NP = np_of(d->mlp_width), NT = NP / 16;
-    if (d->tile_waves != 0 && d->tile_waves != 1 && d->tile_waves != 4 && !(d->tile_waves == 64 && NT == 1) && !((d->tile_waves == 8 || d->tile_waves == 2) && NT == 13)) {
-      set_err("tile_waves must be 0, 1 or 4 for MLP models (64: the N <= 16 kernel at 64 trajectories per wavefront; 8 / 2: the N = 200 kernel with 32 / 4 trajectories per tile)");
+    if (d->tile_waves != 0 && d->tile_waves != 1 && d->tile_waves != 4 && !(d->tile_waves == 64 && NT == 1) && !((d->tile_waves == 8 || d->tile_waves == 2 || d->tile_waves == 16) && NT == 13)) {
+      set_err("tile_waves must be 0, 1 or 4 for MLP models (64: the N <= 16 kernel at 64 trajectories per wavefront; 8 / 2 / 16: the N = 200 kernel with 32 / 4 / 1 trajectories per tile)");
       return IONODE_ERR_UNSUPPORTED;
     }
     // N <= 16 (architectures s03-s05): from IONODE_TINY64_FROM trajectories on, one trajectory per lane (64 per wavefront, four
@@ -155,12 +158,15 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false, bool ex
     // N = 10 (architectures s03-s05) at one trajectory per lane: the per-lane vector-ALU net (MlpLane), unless IONODE_TINY64_MFMA
     const bool vnet = t64 && d->mlp_width == 10 && !IONODE_TINY64_MFMA;
     // N = 200, small batches and single calls: 4 trajectories per tile (MlpTile4; tile_waves = 2 forces it, 4 / 8 exclude it)
-    const bool t4 = !t64 && !t32 && NT == 13 && d->mlp_layers >= 1 && (d->traj_per_image <= 0 || d->traj_per_image % 4 == 0) &&
+    // N = 200, single calls and the smallest batches: ONE trajectory per tile (MlpRow1; tile_waves = 16 forces it, 2 / 4 / 8 exclude it)
+    const bool t1 = !t64 && !t32 && NT == 13 && d->mlp_layers >= 1 && d->mlp_layers <= 15 &&
+                    (d->tile_waves == 16 || (d->tile_waves == 0 && d->n_traj <= IONODE_TILE1_UPTO));
+    const bool t4 = !t64 && !t32 && !t1 && NT == 13 && d->mlp_layers >= 1 && (d->traj_per_image <= 0 || d->traj_per_image % 4 == 0) &&
                     (d->tile_waves == 2 || (d->tile_waves == 0 && d->n_traj <= IONODE_TILE4_UPTO));
     // N = 200 tiles: the lean variant when its contract holds (ionode_device.hpp LEANM)
     const bool leanm = !t64 && (NT == 13 || NT == 7 || NT == 32) && d->mlp_layers >= 1 && !explicit_grid && !has_step_log && !d->ckpt && d->t_eval_exact && d->t_eval_dt_hint > 0.0 && d->n_out > 1;
     pl->v = t64 ? find_variant(d->model, f32, 1, NT, 64, t64lean, vnet ? 10 : 1)
-                : find_variant(d->model, f32, ((d->tile_waves == 8 || d->tile_waves == 2) ? 4 : d->tile_waves), NT, NT == 1 ? 1 : -1, (t32 ? 4 : 0) | (leanm ? 8 : 0) | (t4 ? 16 : 0));
+                : find_variant(d->model, f32, ((d->tile_waves == 8 || d->tile_waves == 2 || d->tile_waves == 16) ? 4 : d->tile_waves), NT, NT == 1 ? 1 : -1, (t32 ? 4 : 0) | (leanm ? 8 : 0) | (t4 ? 16 : 0) | (t1 ? 32 : 0));
     // any other width up to 512 (table-s1.py:145-153 builds nets of any (n_layers, n_nodes)): the run-time-width tile (MlpGen)
     bool gen = false;
     if (!pl->v && NT >= 2 && NT <= ionode::MlpGen::NT_MAX && (d->tile_waves == 0 || d->tile_waves == 4)) {
@@ -177,12 +183,13 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false, bool ex
               "s00-s11 -- and the run-time-width tile for every other N; tile_waves must be 0 or 4 for the latter)");
       return IONODE_ERR_UNSUPPORTED;
     }
-    pl->grid = t64 ? (unsigned)((d->n_traj + 63) / 64) : (t32 ? (unsigned)((d->n_traj + 31) / 32) : (t4 ? (unsigned)((d->n_traj + 3) / 4) : (unsigned)((d->n_traj + 15) / 16)));
+    pl->grid = t64 ? (unsigned)((d->n_traj + 63) / 64) : (t32 ? (unsigned)((d->n_traj + 31) / 32) : (t1 ? (unsigned)d->n_traj : (t4 ? (unsigned)((d->n_traj + 3) / 4) : (unsigned)((d->n_traj + 15) / 16))));
     pl->block = 64u * pl->v->G;
     const int Gv = pl->v->G, Rv = NT - Gv * (NT / Gv);  // remainder row tiles: K-split partial sums in LDS
     pl->lds = ((size_t)2 * (NT + Gv - 1) * 64 + (size_t)2 * Rv * Gv * 64 + NP) * 16 + ((size_t)d->mlp_layers * NP + NP + 4) * 4;
     // the asm tile (N = 200): + scratch slot (+ the input exchange of the two-column-set tile), MlpTile::lds_total
     if (gen) pl->lds = ionode::MlpGen::lds_bytes(d->mlp_layers, NT);
+    else if (t1) pl->lds = ionode::MlpRow1::lds_bytes(d->mlp_layers);
     else if (t4) pl->lds = ionode::MlpTile4::lds_bytes(d->mlp_layers);
     else if (Gv == 4 && NT == 13) pl->lds = t32 ? ionode::MlpTile<4, 4, 13, 13, 4>::lds_total(d->mlp_layers) : ionode::MlpTile<4, 4, 13, 13, 0>::lds_total(d->mlp_layers);
     if (t64) plan_lane_wise(pl, (size_t)((d->n_traj + 63) / 64), (vnet ? (size_t)0 : ((pl->lds + 15) & ~(size_t)15)) + (size_t)ionode::LwLds::bytes(2, t64lean));  // MlpTile region + the lane-wise region
@@ -191,7 +198,7 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false, bool ex
   if (mlp && d->traj_per_image > 0) {
     // several weight images: a tile reads ONE image (first trajectory / traj_per_image), so an image's trajectories must fill whole
     // tiles.  Tile size from the VARIANT (a lane-wise workgroup is 4 x 64 lanes: the block size says nothing about it).
-    const int tile = (pl->v->RT == 64) ? 64 : ((pl->v->tail & 4) && pl->v->G == 4 ? 32 : ((pl->v->tail & 16) ? 4 : 16));
+    const int tile = (pl->v->RT == 64) ? 64 : ((pl->v->tail & 4) && pl->v->G == 4 ? 32 : ((pl->v->tail & 32) ? 1 : ((pl->v->tail & 16) ? 4 : 16)));
     if (d->traj_per_image % tile != 0 || d->mlp_image_stride < (int64_t)ionode_mlp_packed_floats(d->mlp_layers, d->mlp_width)) {
       set_err("traj_per_image must be a multiple of the tile size (16; 64 with tile_waves = 64; 32 with tile_waves = 8) and mlp_image_stride at least one packed image");
       return IONODE_ERR_ARG;
@@ -254,7 +261,9 @@ size_t ionode_mlp_packed_floats(int32_t L, int32_t N) {
   const size_t scalar = (NT == 1) ? npair * 8 + (size_t)L * npair * pb : 0;
   // N = 200: + the section of the 4-trajectory tile (MlpTile4): its own fragment order and bias float4s
   const size_t tile4 = (NT == 13) ? (size_t)L * ionode::MlpTile4::layer_floats() : 0;
-  return 4 * NP + (size_t)L * ((size_t)G * frags_per_wave((int)NT, G) * 256 + NP) + NP + 4 + scalar + tile4;
+  // ... and behind it the section of the one-trajectory tile (MlpRow1)
+  const size_t row1 = (NT == 13) ? (size_t)L * ionode::MlpRow1::layer_floats() : 0;
+  return 4 * NP + (size_t)L * ((size_t)G * frags_per_wave((int)NT, G) * 256 + NP) + NP + 4 + scalar + tile4 + row1;
 }
 
 int ionode_mlp_pack(const float *w, int32_t L, int32_t N, float *out) {
@@ -377,6 +386,45 @@ int ionode_mlp_pack(const float *w, int32_t L, int32_t N, float *out) {
           }
         }
       }
+      lsrc += (size_t)N * N + N;
+    }
+    // section of the one-trajectory tile (ionode_device.hpp MlpRow1), behind the 4-trajectory tile's.  Per layer: wavefronts 0..2: [w][step s]
+    // [r][lane] float4 over q of W[64 w + lane][16 ((s + lane / 16) mod 13) + 4 q + r]; wavefront 3 (partial chains of the remainder rows):
+    // [step j][r][lane = 16 c + i] float4 over q of W[192 + i][16 (c + 4 j) + 4 q + r], -0.0f where c + 4 j > 12; then per (wavefront, lane) the
+    // accumulator start (the row's bias; chains c > 0: 0)
+    float *r1 = t4 + (size_t)L * ionode::MlpTile4::layer_floats();
+    lsrc = b0 + N;
+    for (int l = 0; l < L; ++l) {
+      const float *W = lsrc, *b = lsrc + (size_t)N * N;
+      float *lay = r1 + (size_t)l * ionode::MlpRow1::layer_floats();
+      for (int wv = 0; wv < 3; ++wv)
+        for (int st = 0; st < 13; ++st)
+          for (int r = 0; r < 4; ++r)
+            for (int lane = 0; lane < 64; ++lane) {
+              float *f = lay + ((((size_t)wv * 13 + st) * 4 + r) * 64 + lane) * 4;
+              const int row = 64 * wv + lane, kt = (st + (lane >> 4)) % 13;
+              for (int q = 0; q < 4; ++q) {
+                const int k = 16 * kt + 4 * q + r;
+                f[q] = (row < N && k < N) ? W[(size_t)row * N + k] : 0.0f;
+              }
+            }
+      float *rem = lay + (size_t)3 * 13 * 4 * 256;
+      for (int j = 0; j < 4; ++j)
+        for (int r = 0; r < 4; ++r)
+          for (int lane = 0; lane < 64; ++lane) {
+            float *f = rem + (((size_t)j * 4 + r) * 64 + lane) * 4;
+            const int row = 192 + (lane & 15), kt = (lane >> 4) + 4 * j;
+            for (int q = 0; q < 4; ++q) {
+              const int k = 16 * kt + 4 * q + r;
+              f[q] = (kt >= 13) ? -0.0f : ((row < N && k < N) ? W[(size_t)row * N + k] : 0.0f);
+            }
+          }
+      float *bias = rem + (size_t)4 * 4 * 256;
+      for (int wv = 0; wv < 4; ++wv)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int row = (wv < 3) ? 64 * wv + lane : 192 + (lane & 15);
+          bias[wv * 64 + lane] = (row < N && (wv < 3 || lane < 16)) ? b[row] : 0.0f;
+        }
       lsrc += (size_t)N * N + N;
     }
   }

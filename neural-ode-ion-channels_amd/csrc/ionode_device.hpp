@@ -1164,6 +1164,176 @@ struct MlpTile4 {
 };
 
 // ---------------------------------------------------------------------------------------------
+// N = 200 at ONE trajectory per tile (round 5): the form for the reference's own call shape -- odeint(func, y0, t) with y0 of shape
+// (1, 2) at all 155 call sites (train-s1.py:319-330; 32 sequential solves at :566-580).  One trajectory's evaluations are a serial
+// chain; what bounds a chain link is how fast ONE compute unit can run a 208 x 208 matrix-vector product five times.  On the 4-trajectory
+// tile that is the dependent-issue rate of v_mfma_f32_4x4x1 (17 cycles per k) for three idle columns out of four, and 208 weight loads
+// per layer through the compute unit's one vector-memory path.  Here a LANE owns a ROW: acc = fmaf(W[row][k], h[k], acc) is one
+// v_fmac_f32 per k (9 cycles dependent, tools/ubench/valu_chain.hip), with
+//   * the weight W[row][k] in the lane's own register (streamed from L2 into a ring one layer ahead, as in the other tiles), and
+//   * the activation h[k] broadcast by DPP: a lane holds {h[16 kt + 4 q + (lane & 3)]}, q = 0..3, of its current k-tile (ONE 16-byte LDS read
+//     per lane and k-tile from a buffer kept in that transposed order), and v_fmac_f32_dpp quad_perm:[r, r, r, r] hands every lane of a
+//     quad the value of its lane r: k = 16 kt + 4 q + r -- no cross-lane instruction, no SGPR traffic.  The LDS address is per lane, so the
+//     four 16-lane groups of a wavefront can walk the k-tiles in four different rotations.
+// Lanes: wavefronts 0..2, lane l: row 64 w + l = row tile 4 w + g (g = l / 16), whose canonical chain walks kt = (s + g) mod 13 -- every lane of
+// these wavefronts owns a full row; wavefront 3, lane 16 c + i: partial chain c of remainder row 192 + i (k-tiles c, c + 4, c + 8 (, 12): FOUR
+// steps instead of thirteen), folded (p0 + p1) + (p2 + p3) inside the wavefront.  172 weight loads per layer instead of 208: the vector-memory
+// path (64 B/clk per compute unit whatever the lanes carry: masking idle lanes or sending them out of range changed nothing) is what bounds
+// this tile.  Same canonical chains as every other form: bit-identical to the 16- and 4-trajectory tiles and to the oracle.
+// Linear(N, 1): chain q on the lanes with (lane & 3) == q (k = 16 kt + 4 q + r, kt and r ascending) from a copy of the activations in
+// natural order, folded by two DPP quad permutes.
+// Image section (ionode_mlp_pack, behind the 4-trajectory tile's): per layer: wavefronts 0..2: [w][step s][r][lane] float4 over q of
+// W[64 w + lane][16 ((s + lane / 16) mod 13) + 4 q + r]; wavefront 3: [step j][r][lane = 16 c + i] float4 over q of W[192 + i][16 (c + 4 j) + 4 q + r]
+// (-0.0f for c + 4 j > 12); then per (wavefront, lane) the accumulator start (the row's bias; chains c > 0: 0).
+// ---------------------------------------------------------------------------------------------
+struct MlpRow1 {
+  static constexpr int GW = 4, NT = 13, NP = 208;
+  static constexpr int SLOTS = NT + 3;       // activation buffer, transposed order: k-tile slots 0..15, tiles 0..2 stored twice (slot kt and kt + 13)
+  static constexpr int FRAGS_FULL = NT * 4, FRAGS_REM = 4 * 4;   // 1 KiB fragments per layer of a full-row wavefront / of the remainder wavefront
+  static __host__ __device__ constexpr size_t layer_floats() { return (size_t)(3 * FRAGS_FULL + FRAGS_REM) * 256 + 256; }
+  // floats: activations x2 (transposed) + natural copy x2 + accumulator starts [L][256] + wl[208] + bl(4)
+  static __host__ __device__ constexpr size_t lds_bytes(int L) { return ((size_t)2 * SLOTS * 16 + 2 * NP + (size_t)L * 256 + NP + 4) * 4; }
+  static __host__ __device__ constexpr size_t section_off(int L) { return MlpTile4::section_off(L) + (size_t)L * MlpTile4::layer_floats(); }
+  f32x4 ring[NT][4];
+  float w0b, w0x, w0y;          // this lane's layer-0 row {b0, w00, w01}
+  float *As, *Ns;
+  const float *B1s, *wlS;
+  __amdgpu_buffer_rsrc_t rsrc;
+  unsigned voff, sec0, lbytes;
+  int L, wave, lane, row, tpos;
+#ifdef IONODE_STAMPS
+  Stamps *sp;
+#endif
+  // fragment n = 4 s + r of this wavefront's stream of the layer at byte offset `lbase`
+  __device__ __forceinline__ f32x4 frag(unsigned lbase, int n) const {
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, lbase + (unsigned)n * 1024u, 0);
+    return __builtin_bit_cast(f32x4, v);
+  }
+  // position of activation k in the transposed order of its k-tile: k = 16 kt + 4 q + r  ->  16 kt + 4 r + q
+  static __device__ __forceinline__ int tp(int k) { return (k & ~15) + 4 * (k & 3) + ((k >> 2) & 3); }
+  __device__ __forceinline__ void init(const KArgs &a, unsigned char *smem, int wave_, int lane_, int first_traj = 0) {
+    L = a.L; wave = wave_; lane = lane_;
+    const float *__restrict__ img = a.mlp + (a.traj_per_img > 0 ? (size_t)(first_traj / a.traj_per_img) * (size_t)a.mlp_stride : (size_t)0);
+    row = (wave < 3) ? 64 * wave + lane : 192 + (lane & 15);
+    tpos = tp(row);
+    As = reinterpret_cast<float *>(smem);
+    Ns = As + 2 * SLOTS * 16;
+    float *b1 = Ns + 2 * NP;
+    float *ws = b1 + (size_t)L * 256;
+    const int tid = wave * 64 + lane;
+    const size_t sec = section_off(L);
+    for (int i = tid; i < L * 256; i += 256) b1[i] = img[sec + (size_t)(i >> 8) * layer_floats() + (size_t)(3 * FRAGS_FULL + FRAGS_REM) * 256 + (i & 255)];
+    const float *wl = img + 4 * (size_t)NP + (size_t)L * ((size_t)4 * 43 * 256 + NP);   // behind the 16-column tile's layers (FRAGS = 43 per wavefront)
+    for (int i = tid; i < NP + 4; i += 256) ws[i] = wl[i];
+    B1s = b1; wlS = ws;
+    w0b = img[4 * row + 0]; w0x = img[4 * row + 1]; w0y = img[4 * row + 2];
+    const size_t img_bytes = (sec + (size_t)L * layer_floats()) * 4;
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(img), 0, (int)img_bytes, 0x00020000);
+    sec0 = (unsigned)(sec * 4);
+    lbytes = (unsigned)(layer_floats() * 4);
+    voff = (unsigned)(wave * FRAGS_FULL * 1024 + lane * 16);
+#pragma unroll
+    for (int s = 0; s < NT; ++s)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ring[s][r] = (L > 0 && (wave < 3 || s < 4)) ? frag(sec0, s * 4 + r) : f32x4{0, 0, 0, 0};
+    __syncthreads();
+  }
+  // acc = fmaf(W[row][16 kt + 4 q + r], h[16 kt + 4 q + r], acc) for r = 0..3, q = 0..3 (the canonical order inside a k-tile): h[q] of lane r of the quad.
+  // ONE asm statement per step: between two inline-asm statements hipcc inserts `s_nop 0`, which costs 4 cycles on top of the 9 of a dependent
+  // v_fmac_f32 (tools/ubench/valu_chain.hip).  (A DPP source written by a VALU instruction needs two wait states: h comes straight from an LDS read.)
+  static __device__ __forceinline__ void step16(float &acc, const f32x4 h, const f32x4 w0, const f32x4 w1, const f32x4 w2, const f32x4 w3) {
+#define IONODE_R1_R(R, A, B, C, D) "v_fmac_f32_dpp %0, %1, " A " quad_perm:[" #R "," #R "," #R "," #R "] row_mask:0xf bank_mask:0xf\n\t" \
+                                   "v_fmac_f32_dpp %0, %2, " B " quad_perm:[" #R "," #R "," #R "," #R "] row_mask:0xf bank_mask:0xf\n\t" \
+                                   "v_fmac_f32_dpp %0, %3, " C " quad_perm:[" #R "," #R "," #R "," #R "] row_mask:0xf bank_mask:0xf\n\t" \
+                                   "v_fmac_f32_dpp %0, %4, " D " quad_perm:[" #R "," #R "," #R "," #R "] row_mask:0xf bank_mask:0xf\n\t"
+    asm(IONODE_R1_R(0, "%5", "%6", "%7", "%8") IONODE_R1_R(1, "%9", "%10", "%11", "%12") IONODE_R1_R(2, "%13", "%14", "%15", "%16") IONODE_R1_R(3, "%17", "%18", "%19", "%20")
+        : "+v"(acc)
+        : "v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]), "v"(w0[0]), "v"(w0[1]), "v"(w0[2]), "v"(w0[3]), "v"(w1[0]), "v"(w1[1]), "v"(w1[2]), "v"(w1[3]),
+          "v"(w2[0]), "v"(w2[1]), "v"(w2[2]), "v"(w2[3]), "v"(w3[0]), "v"(w3[1]), "v"(w3[2]), "v"(w3[3]));
+#undef IONODE_R1_R
+  }
+  // store an activation (row `row` at transposed position `tpos_`): transposed buffer (tiles 0..2 also at their second slot) and natural-order copy
+  static __device__ __forceinline__ void put_h(float *__restrict__ A, float *__restrict__ N, int row_, int tpos_, float h) {
+    A[tpos_] = h;
+    if (row_ < 48) A[tpos_ + 16 * NT] = h;
+    N[row_] = h;
+  }
+  // NS steps of this lane's chain: step s reads the lane's 16 bytes of slot (slot0 + s * STRIDE) and the ring's fragments 4 s .. 4 s + 3,
+  // which are refilled for the coming layer right behind their last use
+  template <int NS, int STRIDE>
+  __device__ __forceinline__ void walk(float &acc, const float *__restrict__ Hw, unsigned lnext) {
+    f32x4 hn = *reinterpret_cast<const f32x4 *>(Hw);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const f32x4 h = hn;
+      if (s + 1 < NS) hn = *reinterpret_cast<const f32x4 *>(Hw + (s + 1) * STRIDE * 16);
+      step16(acc, h, ring[s][0], ring[s][1], ring[s][2], ring[s][3]);
+#ifndef IONODE_ROW1_NOREFILL   // timing experiment only (wrong results for L > 1): what the walk costs without its weight stream
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ring[s][r] = frag(lnext, s * 4 + r);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  __device__ __forceinline__ float eval(float x0, float x1) {
+    MSTAMP(0);
+    {
+      const float h = lrelu(fmaf(w0y, x1, fmaf(w0x, x0, w0b)));
+      if (wave < 3 || lane < 16) put_h(As, Ns, row, tpos, h);
+    }
+    float acc_next = (L > 0) ? B1s[wave * 64 + lane] : 0.0f;
+    __syncthreads();
+    MSTAMP(1);
+    const int c4 = (lane & 3) * 4, g16 = (lane >> 4) * 16;
+    for (int l = 0; l < L; ++l) {
+      const float *__restrict__ Ain = As + (l & 1) * SLOTS * 16;
+      float *__restrict__ Aout = As + ((l + 1) & 1) * SLOTS * 16, *__restrict__ Nout = Ns + ((l + 1) & 1) * NP;
+      const int ln = (l + 1 < L) ? l + 1 : 0;
+      const unsigned lnext = sec0 + (unsigned)ln * lbytes;
+      float acc = acc_next;
+      if (l + 1 < L) acc_next = B1s[(l + 1) * 256 + wave * 64 + lane];
+      MSTAMP(2);
+      if (wave < 3) {
+        // full rows: lane group g walks k-tile (s + g) mod 13 = slot s + g; the lane's 16 bytes of a slot: {h[16 kt + 4 q + (lane & 3)]}, q = 0..3
+        walk<NT, 1>(acc, Ain + g16 + c4, lnext);
+        MSTAMP(3);
+        put_h(Aout, Nout, row, tpos, lrelu(acc));
+      } else {
+        // remainder rows: lane group c runs partial chain c over the k-tiles c, c + 4, c + 8 (, 12: chain 0 only -- the others' step 3 reads
+        // the duplicate slots 13..15 against -0.0f weights), then the four chains of a row meet across the lane groups: (p0 + p1) + (p2 + p3)
+        walk<4, 4>(acc, Ain + g16 + c4, lnext);
+        MSTAMP(3);
+        const float pair = acc + __shfl_xor(acc, 16);
+        const float tot = pair + __shfl_xor(pair, 32);
+        if (lane < 16) put_h(Aout, Nout, row, tpos, lrelu(tot));
+      }
+      __syncthreads();
+      MSTAMP(4);
+    }
+    // Linear(N, 1): chain q = lane & 3 over k = 16 kt + 4 q + r, folded ((p0 + p1) + (p2 + p3)) + bl
+    const float *__restrict__ Nin = Ns + (L & 1) * NP;
+    f32x4 hl[NT], wv[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      hl[kt] = *reinterpret_cast<const f32x4 *>(Nin + 16 * kt + c4);
+      wv[kt] = *reinterpret_cast<const f32x4 *>(wlS + 16 * kt + c4);
+    }
+    float part = 0.0f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part = fmaf(wv[kt][r], hl[kt][r], part);
+    }
+    const float pair = part + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(part), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]: (p0 + p1) / (p2 + p3)
+    const float out = (pair + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(pair), 0x4E, 0xf, 0xf, false))) + wlS[NP];   // quad_perm [2,3,0,1]
+    if ((L & 1) == 0) __syncthreads();   // the next evaluation's layer 0 rewrites buffer 0, which an even stack's output layer reads
+    MSTAMP(5);
+    return out;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
 // N = 10 nets (architectures s03-s05) at one trajectory per lane: the net evaluated PER LANE on the vector ALU, weights as
 // SCALAR operands.  The MFMA form of this path (MlpTile::eval_tiny64) spends 80 MFMAs = 2560 cycles per evaluation on 16 x 16
 // tiles of a 10 x 10 layer, gathers its inputs across lanes and keeps four accumulator tiles; per lane the net is 530 fmaf + 2 x 60
@@ -1502,7 +1672,7 @@ __device__ __forceinline__ void rhs(const KArgs &a, const double *p, double v, b
     // (not for the 64-per-wavefront N <= 16 kernel: two interleaved branch-free exps cost ~30 registers -- it went from 252 to 284
     // VGPRs, i.e. from two wavefronts per SIMD to one, 58 -> 87 ms)
     // (the 4-trajectory tile keeps a 208-register weight ring: the branchy form with one exp in flight, same bits)
-    constexpr bool TIGHT = std::is_same<MLP, MlpTile4>::value;
+    constexpr bool TIGHT = std::is_same<MLP, MlpTile4>::value || std::is_same<MLP, MlpRow1>::value;
     auto dexp = [](double x) { if constexpr (TIGHT) return det_exp_ldexp(x); else if constexpr (MT::MLP && !WIDE) return det_exp_s(x); else return det_exp(x); };
     double k3, k4, dadt = 0.0;
     if constexpr (MT::MLP && WIDE) {
@@ -1710,8 +1880,11 @@ __global__ void __launch_bounds__(64 * (IONODE_IS_LW(MODEL, RT) ? IONODE_LW_TILE
   // TAIL & 16 of an N = 200 tile kernel: FOUR trajectories per tile (MlpTile4: small batches and single calls); lane = 4 b + j holds trajectory j
   constexpr bool T4 = MT::MLP && G == 4 && NT == 13 && (TAIL & 16);
   static_assert(!T4 || NSETS == 1, "the 4-trajectory tile has one column set");
-  constexpr int TPW = MT::MLP ? (T64 ? 64 : (T4 ? 4 : 16 * NSETS)) : (RT > 0 ? RT : 64);
-  constexpr int LPS = (MT::MLP && !T64) ? (T4 ? 4 : 16) : TPW;
+  // TAIL & 32 of an N = 200 tile kernel: ONE trajectory per tile (MlpRow1: a lane owns a row; the reference's own call shape); every lane holds the trajectory
+  constexpr bool T1 = MT::MLP && G == 4 && NT == 13 && (TAIL & 32);
+  static_assert(!T1 || (NSETS == 1 && !T4), "the one-trajectory tile has one column set and is not the 4-trajectory tile");
+  constexpr int TPW = MT::MLP ? (T64 ? 64 : (T1 ? 1 : (T4 ? 4 : 16 * NSETS))) : (RT > 0 ? RT : 64);
+  constexpr int LPS = (MT::MLP && !T64) ? (T1 ? 1 : (T4 ? 4 : 16)) : TPW;
   static_assert(MT::MLP || G == 1, "closed-form models use one wavefront per tile");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1743,7 +1916,7 @@ __global__ void __launch_bounds__(64 * (IONODE_IS_LW(MODEL, RT) ? IONODE_LW_TILE
   // NT slot == 0 of a four-wavefront MLP kernel: the run-time-width tile (MlpGen: any N <= 512 without a tuned tile of its own)
   constexpr bool GEN = MT::MLP && G == 4 && NT == 0;
   using MlpTileT = MlpTile<G, (T64 ? 1 : (RT > 0 ? RT : 1)), (NT > 0 ? NT : 1), ((PD > 0 && !VNET) ? PD : 1), (NSETS > 1 ? 4 : 0)>;
-  using MlpT = typename std::conditional<VNET, MlpLane<(VNET ? PD : 10)>, typename std::conditional<T4, MlpTile4, typename std::conditional<GEN, MlpGen, MlpTileT>::type>::type>::type;
+  using MlpT = typename std::conditional<VNET, MlpLane<(VNET ? PD : 10)>, typename std::conditional<T1, MlpRow1, typename std::conditional<T4, MlpTile4, typename std::conditional<GEN, MlpGen, MlpTileT>::type>::type>::type>::type;
   typename std::conditional<MT::MLP, MlpT, NoMlp>::type mlp;
   if constexpr (MT::MLP) mlp.init(a, smem_t, wave, lane, tile * TPW);
   // lane-wise kernels: interpolant rows + tail buffers; behind the MlpTile region when there is one
@@ -2143,7 +2316,7 @@ __global__ void __launch_bounds__(64 * (IONODE_IS_LW(MODEL, RT) ? IONODE_LW_TILE
       // the two protocol samples per output time of the observation model -- is issued before anything is evaluated: one
       // round trip per accepted step instead of two dependent ones per emitting trajectory.  Samples beyond the first chunk
       // (steps spanning more than 64 outputs) take the plain loop.
-      constexpr int NS = LPS / WPS;
+      constexpr int NS = (LPS >= WPS) ? LPS / WPS : 1;   // (one trajectory per tile: wavefront 0 emits it, the others nothing)
       const bool exact = a.te_exact != 0;
       const bool want_i = (a.i_out != nullptr) || (a.sse_out != nullptr);
       const bool ugrid = a.prot_t == nullptr;
@@ -2155,7 +2328,7 @@ __global__ void __launch_bounds__(64 * (IONODE_IS_LW(MODEL, RT) ? IONODE_LW_TILE
       for (int k = 0; k < NS; ++k) {
         const int jj = wis + WPS * k;
         o_[k] = __builtin_amdgcn_readlane(oi, jj);
-        n_[k] = __builtin_amdgcn_readlane(n_out, jj);
+        n_[k] = (LPS >= WPS || jj < LPS) ? __builtin_amdgcn_readlane(n_out, jj) : 0;
         pv_[k] = a.prot_v + (size_t)__builtin_amdgcn_readlane(pidx, jj) * a.Np;
         tk_[k] = 0.0;
         if (lane < n_[k]) tk_[k] = exact ? te_at(o_[k] + lane) : a.t_eval[o_[k] + lane];
@@ -2379,7 +2552,7 @@ __global__ void __launch_bounds__(64 * (IONODE_IS_LW(MODEL, RT) ? IONODE_LW_TILE
       if (G > 1) {  // trajectory jj belongs to wavefront jj % G
         unsigned long long mine = 0ull;
 #pragma unroll
-        for (int k = 0; k < TPW / G; ++k) mine |= 1ull << (wave + k * G);
+        for (int k = 0; k < (TPW + G - 1) / G; ++k) mine |= 1ull << (wave + k * G);   // (fewer trajectories than wavefronts: masked by lane < LPS above)
         em &= mine;
       }
       int jj = em ? __builtin_ctzll(em) : 0;

@@ -1,4 +1,5 @@
-"""-m gpu, round 5: the run-time-width MLP tile (any N <= 512), every result against the oracle bit for bit."""
+"""-m gpu, round 5: the run-time-width MLP tile (any N <= 512) and the one-trajectory tile of the N = 200 nets (a lane owns a row:
+the reference's own odeint(func, y0, t) call shape), every result against the oracle bit for bit."""
 import numpy as np
 import pytest
 import torch
@@ -73,3 +74,99 @@ def test_run_time_width_tile_with_several_weight_sets_and_a_launch_order(ion, gp
     a, b = capi.dopri5(*args, **kw), capi.dopri5(*args, launch_order=order, **kw)
     torch.cuda.synchronize()
     assert torch.equal(a["y"], b["y"]) and torch.equal(a["stats"], b["stats"])
+
+
+def _kernel(ion, gpu, model, params, pv, y0, te, **kw):
+    g = run_gpu(ion, gpu, model, params, pv, y0, te, **kw)
+    g["kernel"] = ion.capi.lib().ionode_last_kernel_name().decode()
+    return g
+
+
+@pytest.mark.parametrize("name,model", [("s1", K.MODEL_NNF), ("d2", K.MODEL_NND)])
+@pytest.mark.parametrize("f32", [False, True])
+@pytest.mark.parametrize("B", [1, 3, 7])
+def test_one_trajectory_tile_is_bit_identical(ion, gpu, oracle, name, model, f32, B):
+    """tile_waves = 16: ONE trajectory per workgroup, a lane owns a row (v_fmac_f32_dpp, activations broadcast inside quads), the same
+    canonical chains as the 16-column and the 4-trajectory tiles: states, step counters and the fused current trace equal the oracle's
+    and both other kernels' bit for bit -- single call, several trajectories, per-trajectory protocols, one trajectory that fails."""
+    rng = np.random.default_rng(200 * B + f32)
+    w = K.load_weights(name)
+    base = K.P_NN_D if model == K.MODEL_NND else K.P_HH
+    params = np.tile(base, (B, 1)) * rng.uniform(0.9, 1.1, (B, 8))
+    pv = np.stack([K.activation(v)[1] for v in (-20, 20, 40)])
+    te = K.activation(0)[2][:1501]
+    pot = rng.integers(0, 3, B).astype(np.int32)
+    y0 = np.tile(K.NN_Y0, (B, 1)).astype(np.float64)
+    if B > 4:
+        y0[3, 1] = np.nan   # a failing trajectory
+    kw = dict(prot_t0=0.0, prot_dt=1.0, prot_of_traj=pot, max_total_steps=20000)
+    o = oracle.solve(model, params, pv, y0, te, weights=w, mlp_layers=5, mlp_width=200, state_f32=f32, nthreads=4, **kw)
+    g1 = _kernel(ion, gpu, model, params, pv, y0, te, weights=w, L=5, N=200, f32=f32, current=True, tile_waves=16, **kw)
+    g4 = _kernel(ion, gpu, model, params, pv, y0, te, weights=w, L=5, N=200, f32=f32, current=True, tile_waves=2, **kw)
+    g16 = _kernel(ion, gpu, model, params, pv, y0, te, weights=w, L=5, N=200, f32=f32, current=True, tile_waves=4, **kw)
+    assert ", 4, 4, 13, 13, 40>" in g1["kernel"] and ", 4, 4, 13, 13, 24>" in g4["kernel"] and ", 4, 4, 13, 13, 8>" in g16["kernel"]
+    for g in (g1, g4, g16):
+        assert np.array_equal(g["status"], o["status"]) and np.array_equal(g["stats"], o["stats"])
+        assert np.array_equal(g["y"], o["y"], equal_nan=True)
+    assert np.array_equal(g1["i"], g16["i"], equal_nan=True) and np.array_equal(g1["i"], g4["i"], equal_nan=True)
+
+
+@pytest.mark.parametrize("L", [1, 2, 4, 7])
+def test_one_trajectory_tile_other_depths_general_variant_objective_and_images(ion, gpu, oracle, L):
+    """Odd / even hidden-layer counts (the activation buffers ping-pong), an explicit protocol time grid (the GENERAL variant, TAIL slot
+    32) with a step log, the fused objective, no output-grid hint (cooperative scan), and several weight sets (one per trajectory)."""
+    capi = ion.capi
+    rng = np.random.default_rng(L)
+    N, B = 200, 3
+    w = rng.normal(0, 0.1, 2 * N + N + L * (N * N + N) + N + 1).astype(np.float32)
+    params = np.tile(K.P_HH, (B, 1)) * rng.uniform(0.9, 1.1, (B, 8))
+    pt, pv, te = K.atau(30)
+    te = te[:801]
+    o = oracle.solve(K.MODEL_NNF, params, pv, K.NN_Y0, te, weights=w, mlp_layers=L, mlp_width=N, prot_t=pt)
+    slog = torch.zeros((4000, 4), dtype=torch.float64, device=gpu)
+    g = _kernel(ion, gpu, K.MODEL_NNF, params, pv, K.NN_Y0, te, weights=w, L=L, N=N, prot_t=pt, tile_waves=16, step_log=slog)
+    assert ", 4, 4, 13, 13, 32>" in g["kernel"], g["kernel"]
+    assert np.array_equal(g["y"], o["y"]) and np.array_equal(g["stats"], o["stats"])
+    n_att = int(o["stats"][0, 0] + o["stats"][0, 1])
+    assert float(slog[:n_att, 3].sum()) == float(o["stats"][0, 0]) and float(slog[n_att:, 1].abs().sum()) == 0.0
+    g_nohint = _kernel(ion, gpu, K.MODEL_NNF, params, pv, K.NN_Y0, te, weights=w, L=L, N=N, prot_t=pt, tile_waves=16, t_eval_hint=None)
+    assert np.array_equal(g_nohint["y"], o["y"]) and np.array_equal(g_nohint["stats"], o["stats"])
+    # fused objective against the 16-column tile (same sum per trajectory: one wavefront reduces 64-sample chunks in both)
+    kwu = dict(prot_t0=float(pt[0]), prot_dt=float(pt[1] - pt[0]))
+    ref = torch.from_numpy(rng.normal(0, 0.3, (1, te.size))).to(gpu)
+    args = (capi.MODEL_NNF, torch.from_numpy(params).to(gpu), torch.from_numpy(pv[None, :]).to(gpu),
+            torch.tensor([K.NN_Y0], dtype=torch.float64, device=gpu).repeat(B, 1).contiguous(), torch.from_numpy(te).to(gpu))
+    kwo = dict(mlp_packed=torch.from_numpy(capi.mlp_pack(w, L, N)).to(gpu), mlp_layers=L, mlp_width=N, sse_ref=ref, states=False, **kwu)
+    s1, s16 = capi.dopri5(*args, tile_waves=16, **kwo), capi.dopri5(*args, tile_waves=4, **kwo)
+    torch.cuda.synchronize()
+    assert ", 13, 13, 40>" in s1["kernel"] and torch.equal(s1["sse"], s16["sse"]) and bool(torch.isfinite(s1["sse"]).all())
+    # one weight set per trajectory
+    ws = [rng.normal(0, 0.1, w.size).astype(np.float32) for _ in range(B)]
+    packed = torch.from_numpy(np.stack([capi.mlp_pack(x, L, N) for x in ws])).to(gpu)
+    r = capi.dopri5(*args, mlp_packed=packed, mlp_layers=L, mlp_width=N, traj_per_image=1, tile_waves=16, **kwu)
+    torch.cuda.synchronize()
+    for k in range(B):
+        ok = oracle.solve(K.MODEL_NNF, params[k:k + 1], pv, K.NN_Y0, te, weights=ws[k], mlp_layers=L, mlp_width=N, **kwu)
+        assert np.array_equal(r["y"][k:k + 1].cpu().numpy(), ok["y"]) and np.array_equal(r["stats"][k:k + 1].cpu().numpy(), ok["stats"])
+
+
+def test_single_odeint_call_takes_the_one_trajectory_tile(ion, gpu, oracle):
+    """The reference's own call shape -- odeint(func, y0, t) with one trajectory (train-s1.py:319-330) -- runs on the one-trajectory tile,
+    with and without an exactly uniform output grid (linspace(0, 8000, 80001) in fp32 is not: the general variant)."""
+    import ref_style_modules as M
+    from torchdiffeq import odeint
+    func = M.NNf(K.MODELS["s1"][4])
+    M.load_flat_weights(func.net, K.load_weights("s1"))
+    func.eval()
+    pt, pv, te = K.activation(20)
+    func.set_fixed_form_voltage_protocol(pt, pv)
+    with torch.no_grad():
+        y = odeint(func, torch.tensor([K.NN_Y0]), torch.from_numpy(te).float())
+    name = ion.capi.lib().ionode_last_kernel_name().decode()
+    assert ", 4, 4, 13, 13, 32>" in name or ", 4, 4, 13, 13, 40>" in name, name
+    o = oracle.solve(K.MODEL_NNF, K.MODELS["s1"][4], pv, K.NN_Y0, te, weights=K.load_weights("s1"), mlp_layers=5, mlp_width=200,
+                     prot_t0=float(pt[0]), prot_dt=float(pt[1] - pt[0]), state_f32=True)
+    assert np.array_equal(y[:, 0, :].double().cpu().numpy(), o["y"][0])
+    with torch.no_grad():
+        y2 = odeint(func, torch.tensor([K.NN_Y0]), torch.arange(0, 1501, dtype=torch.float32) * 5.0)
+    assert ", 4, 4, 13, 13, 40>" in ion.capi.lib().ionode_last_kernel_name().decode() and bool(torch.isfinite(y2).all())

@@ -93,7 +93,30 @@ def test_weight_pack_is_a_permutation_with_zero_padding(ion, L, N):
                     assert np.array_equal(sc[l, m, :N, e], W[2 * m + e, korder]) and sc[l, m, N, e] == b[2 * m + e]
             assert not sc[l, :, N + 1:].any()
     if N == 200:
-        # N = 200: the image ends with the section of the 4-trajectory tile (MlpTile4): per layer 4 waves x 13 steps x 4 q x 64 lanes x 4
+        # N = 200 (round 5): the image ends with the section of the ONE-trajectory tile (MlpRow1): per layer three full-row wavefronts x 13
+        # steps x 4 r x 64 lanes x float4 over q, the remainder wavefront's 4 steps x 4 r x 64 lanes (every hidden weight exactly once more;
+        # -0.0 where a partial chain has no fourth k-tile), + 4 x 64 accumulator starts
+        lay1 = (3 * 13 * 4 + 4 * 4) * 256 + 256
+        r1 = img[-L * lay1:].reshape(L, lay1)
+        img = img[:-L * lay1]
+        off = 2 * N + N
+        for l in range(L):
+            full = r1[l, :3 * 13 * 4 * 256].reshape(3, 13, 4, 64, 4)
+            rem = r1[l, 3 * 13 * 4 * 256:(3 * 13 * 4 + 16) * 256].reshape(4, 4, 64, 4)
+            Wl = w[off:off + N * N].reshape(N, N); bl = w[off + N * N:off + N * N + N]; off += N * N + N
+            nzf = np.concatenate([full[full != 0], rem[rem != 0]])
+            assert nzf.size == N * N and np.array_equal(np.sort(nzf), np.sort(Wl.reshape(-1)))
+            for (wv, st, r, lane, q) in ((0, 0, 0, 0, 0), (2, 5, 2, 47, 3), (1, 12, 3, 17, 1), (0, 7, 1, 63, 2)):
+                row, k = 64 * wv + lane, 16 * ((st + (lane >> 4)) % 13) + 4 * q + r
+                assert full[wv, st, r, lane, q] == (Wl[row, k] if (row < N and k < N) else 0.0)
+            for (j, r, lane, q) in ((0, 0, 0, 0), (2, 3, 21, 1), (3, 1, 5, 0), (3, 2, 40, 1), (1, 0, 63, 3)):
+                row, kt = 192 + (lane & 15), (lane >> 4) + 4 * j
+                k = 16 * kt + 4 * q + r
+                assert rem[j, r, lane, q] == (Wl[row, k] if (kt < 13 and row < N and k < N) else 0.0)
+            bias = r1[l, (3 * 13 * 4 + 16) * 256:].reshape(4, 64)
+            assert np.array_equal(np.sort(bias[bias != 0]), np.sort(bl))    # every row's bias exactly once (remainder rows: chain 0 only)
+            assert int((np.signbit(rem) & (rem == 0)).sum()) == 3 * 16 * 4 * 4   # step 3 of the chains 1..3: lanes x r x q
+        # ... in front of it the section of the 4-trajectory tile (MlpTile4): per layer 4 waves x 13 steps x 4 q x 64 lanes x 4
         # fragments (every hidden weight once more; -0.0 where the remainder block idles) + 4 x 64 bias float4s
         lay = 4 * 13 * 4 * 256 + 4 * 256
         t4 = img[-L * lay:].reshape(L, lay)
@@ -355,6 +378,8 @@ def test_explicit_64_per_wavefront_rejects_images_that_do_not_fill_a_tile(ion):
     assert capi.launch_geometry(capi.make_desc(tile_waves=8, traj_per_image=16, **kw200))["grid"] == 4
     assert capi.launch_geometry(capi.make_desc(tile_waves=8, traj_per_image=32, **kw200))["grid"] == 2
     assert capi.launch_geometry(capi.make_desc(tile_waves=2, traj_per_image=4, **kw200))["grid"] == 16   # 4-trajectory tiles
+    assert capi.launch_geometry(capi.make_desc(tile_waves=16, traj_per_image=1, **kw200))["grid"] == 64  # one-trajectory tiles: any image granularity
+    assert ", 4, 4, 13, 13, 32>" in capi.kernel_name(capi.make_desc(**dict(kw200, mlp_image_stride=0)))  # 64 trajectories: chosen by itself
 
 
 def test_lane_wise_crossovers_come_from_the_library(ion):

@@ -1,0 +1,49 @@
+"""Dev/bench tool (GPU box): the N = 200 small tiles -- ONE trajectory per tile (tile_waves = 16: a lane owns a row) against FOUR
+(tile_waves = 2: v_mfma_f32_4x4x1) -- on the reference's own call shape: NN-f s00, 10 s sine wave, 2001 outputs, fp32 state.
+python tools/bench_small_tiles.py [--batches 1,4,64,256] [--tiles 16,2] [--f64]"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+ap = argparse.ArgumentParser()
+ap.add_argument("--batches", default="1,4,64,256")
+ap.add_argument("--tiles", default="16,2")
+ap.add_argument("--f64", action="store_true")
+ap.add_argument("--reps", type=int, default=3)
+a = ap.parse_args()
+ion = importlib.import_module("neural-ode-ion-channels_amd")
+import kat_cases as K  # noqa: E402
+capi, P = ion.capi, ion.protocols
+dev = torch.device("cuda:0")
+w = K.load_weights("s1")
+packed = torch.from_numpy(capi.mlp_pack(w, 5, 200)).to(dev)
+Np = 100001
+te = torch.arange(2001, dtype=torch.float64, device=dev) * 5.0
+out = {}
+for B in [int(x) for x in a.batches.split(",")]:
+    pv = P.sinewave(P.sinewave_scales(0, B), n_samples=Np, dt=0.1, xp=torch, device=dev)
+    params = torch.from_numpy(np.tile(K.P_HH, (B, 1))).to(dev)
+    y0 = torch.tensor([[0.0, 1.0]], dtype=torch.float64 if a.f64 else torch.float32, device=dev).repeat(B, 1).contiguous()
+    ref = None
+    for tw in [int(x) for x in a.tiles.split(",")]:
+        ms = []
+        for rep in range(a.reps + 1):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            r = capi.dopri5(capi.MODEL_NNF, params, pv, y0, te, mlp_packed=packed, mlp_layers=5, mlp_width=200, prot_t0=0.0, prot_dt=0.1,
+                            t_eval_hint=(0.0, 5.0), t_eval_exact=True, tile_waves=tw)
+            torch.cuda.synchronize(); ms.append((time.perf_counter() - t0) * 1e3)
+        nfe = float(r["stats"][:, 2].max())
+        same = None if ref is None else bool(torch.equal(ref, r["y"]))
+        ref = r["y"] if ref is None else ref
+        out[f"B{B}_tile{tw}"] = {"ms": min(ms[1:]), "kernel": r["kernel"], "max_nfe": nfe, "us_per_eval": min(ms[1:]) * 1e3 / nfe, "same_bits_as_first": same}
+        print(f"B={B} tile_waves={tw}: {min(ms[1:]):.1f} ms, {min(ms[1:]) * 1e3 / nfe:.2f} us per evaluation of the slowest trajectory, {r['kernel']}, same={same}", flush=True)
+print(json.dumps(out))
