@@ -159,7 +159,7 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false, bool ex
     const bool vnet = t64 && d->mlp_width == 10 && !IONODE_TINY64_MFMA;
     // N = 200, small batches and single calls: 4 trajectories per tile (MlpTile4; tile_waves = 2 forces it, 4 / 8 exclude it)
     // N = 200, single calls and the smallest batches: ONE trajectory per tile (MlpRow1; tile_waves = 16 forces it, 2 / 4 / 8 exclude it)
-    const bool t1 = !t64 && !t32 && NT == 13 && d->mlp_layers >= 1 && d->mlp_layers <= 15 &&
+    const bool t1 = !t64 && !t32 && NT == 13 && d->mlp_layers >= 1 && d->mlp_layers <= ionode::MlpRow1::max_layers() &&
                     (d->tile_waves == 16 || (d->tile_waves == 0 && d->n_traj <= IONODE_TILE1_UPTO));
     const bool t4 = !t64 && !t32 && !t1 && NT == 13 && d->mlp_layers >= 1 && (d->traj_per_image <= 0 || d->traj_per_image % 4 == 0) &&
                     (d->tile_waves == 2 || (d->tile_waves == 0 && d->n_traj <= IONODE_TILE4_UPTO));

@@ -1192,12 +1192,25 @@ struct MlpRow1 {
   static constexpr int FRAGS_FULL = NT * 4, FRAGS_REM = 4 * 4;   // 1 KiB fragments per layer of a full-row wavefront / of the remainder wavefront
   static __host__ __device__ constexpr size_t layer_floats() { return (size_t)(3 * FRAGS_FULL + FRAGS_REM) * 256 + 256; }
   // floats: activations x2 (transposed) + natural copy x2 + accumulator starts [L][256] + wl[208] + bl(4)
-  static __host__ __device__ constexpr size_t lds_bytes(int L) { return ((size_t)2 * SLOTS * 16 + 2 * NP + (size_t)L * 256 + NP + 4) * 4; }
+  static __host__ __device__ constexpr size_t small_bytes(int L) { return ((size_t)2 * SLOTS * 16 + 2 * NP + (size_t)L * 256 + NP + 4) * 4; }
+  // LDS-RESIDENT WEIGHTS: the compute unit's vector-memory path (64 B/clk) is what bounds this tile, and the workgroup has the whole 160 KB of
+  // LDS to itself: the fragments of the first MRES = 2 steps of EVERY hidden layer of the three full-row wavefronts (24 KB per layer) stay in
+  // LDS for the kernel's lifetime; their ring slots are refilled from there instead of from L2 -- 24 of 172 loads per layer less through the
+  // memory path.  The same code for every layer (no per-layer variant: a branch around refills costs hipcc's wait counts their precision).
+  // Stacks of more than 6 hidden layers do not fit: the dispatcher keeps them on the 4-trajectory tile (max_layers()).
+#ifndef IONODE_ROW1_MRES
+#define IONODE_ROW1_MRES 2
+#endif
+  static constexpr int MRES = IONODE_ROW1_MRES;
+  static __host__ __device__ constexpr size_t res_off(int L) { return (small_bytes(L) + 1023) & ~(size_t)1023; }
+  static __host__ __device__ constexpr size_t lds_bytes(int L) { return MRES > 0 ? res_off(L) + (size_t)L * 3 * MRES * 4 * 1024 : small_bytes(L); }
+  static __host__ __device__ constexpr int max_layers() { int L = 1; while (L < 15 && lds_bytes(L + 1) <= 160 * 1024) ++L; return L; }
   static __host__ __device__ constexpr size_t section_off(int L) { return MlpTile4::section_off(L) + (size_t)L * MlpTile4::layer_floats(); }
   f32x4 ring[NT][4];
   float w0b, w0x, w0y;          // this lane's layer-0 row {b0, w00, w01}
   float *As, *Ns;
   const float *B1s, *wlS;
+  const f32x4 *Wres;            // this wavefront's resident fragments in LDS: [layer][step < MRES][r][lane]
   __amdgpu_buffer_rsrc_t rsrc;
   unsigned voff, sec0, lbytes;
   int L, wave, lane, row, tpos;
@@ -1233,6 +1246,17 @@ struct MlpRow1 {
     sec0 = (unsigned)(sec * 4);
     lbytes = (unsigned)(layer_floats() * 4);
     voff = (unsigned)(wave * FRAGS_FULL * 1024 + lane * 16);
+    Wres = reinterpret_cast<const f32x4 *>(smem + res_off(L)) + (size_t)(wave < 3 ? wave : 0) * L * MRES * 4 * 64 + lane;
+    if (MRES > 0 && wave < 3) {
+      f32x4 *dst = reinterpret_cast<f32x4 *>(smem + res_off(L)) + (size_t)wave * L * MRES * 4 * 64 + lane;
+      for (int l = 0; l < L; ++l) {
+        f32x4 f[MRES > 0 ? MRES * 4 : 1];
+#pragma unroll
+        for (int n = 0; n < MRES * 4; ++n) f[n] = frag(sec0 + (unsigned)l * lbytes, n);
+#pragma unroll
+        for (int n = 0; n < MRES * 4; ++n) dst[((size_t)l * MRES * 4 + n) * 64] = f[n];
+      }
+    }
 #pragma unroll
     for (int s = 0; s < NT; ++s)
 #pragma unroll
@@ -1261,8 +1285,9 @@ struct MlpRow1 {
   }
   // NS steps of this lane's chain: step s reads the lane's 16 bytes of slot (slot0 + s * STRIDE) and the ring's fragments 4 s .. 4 s + 3,
   // which are refilled for the coming layer right behind their last use
-  template <int NS, int STRIDE>
-  __device__ __forceinline__ void walk(float &acc, const float *__restrict__ Hw, unsigned lnext) {
+  // NRES: the first NRES steps' ring slots are refilled from the resident copy in LDS (`res`: the coming layer's fragments) instead of from L2
+  template <int NS, int STRIDE, int NRES>
+  __device__ __forceinline__ void walk(float &acc, const float *__restrict__ Hw, unsigned lnext, const f32x4 *__restrict__ res) {
     f32x4 hn = *reinterpret_cast<const f32x4 *>(Hw);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -1271,7 +1296,7 @@ struct MlpRow1 {
       step16(acc, h, ring[s][0], ring[s][1], ring[s][2], ring[s][3]);
 #ifndef IONODE_ROW1_NOREFILL   // timing experiment only (wrong results for L > 1): what the walk costs without its weight stream
 #pragma unroll
-      for (int r = 0; r < 4; ++r) ring[s][r] = frag(lnext, s * 4 + r);
+      for (int r = 0; r < 4; ++r) ring[s][r] = (s < NRES) ? res[(s * 4 + r) * 64] : frag(lnext, s * 4 + r);
 #endif
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1296,13 +1321,13 @@ struct MlpRow1 {
       MSTAMP(2);
       if (wave < 3) {
         // full rows: lane group g walks k-tile (s + g) mod 13 = slot s + g; the lane's 16 bytes of a slot: {h[16 kt + 4 q + (lane & 3)]}, q = 0..3
-        walk<NT, 1>(acc, Ain + g16 + c4, lnext);
+        walk<NT, 1, MRES>(acc, Ain + g16 + c4, lnext, Wres + (size_t)ln * MRES * 4 * 64);
         MSTAMP(3);
         put_h(Aout, Nout, row, tpos, lrelu(acc));
       } else {
         // remainder rows: lane group c runs partial chain c over the k-tiles c, c + 4, c + 8 (, 12: chain 0 only -- the others' step 3 reads
         // the duplicate slots 13..15 against -0.0f weights), then the four chains of a row meet across the lane groups: (p0 + p1) + (p2 + p3)
-        walk<4, 4>(acc, Ain + g16 + c4, lnext);
+        walk<4, 4, 0>(acc, Ain + g16 + c4, lnext, Wres);
         MSTAMP(3);
         const float pair = acc + __shfl_xor(acc, 16);
         const float tot = pair + __shfl_xor(pair, 32);

@@ -19,6 +19,7 @@ ap.add_argument("--batches", default="1,4,64,256")
 ap.add_argument("--tiles", default="16,2")
 ap.add_argument("--f64", action="store_true")
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--stamps", action="store_true", help="library built with -DIONODE_STAMPS: cycles per phase and evaluation of wavefront 0")
 a = ap.parse_args()
 ion = importlib.import_module("neural-ode-ion-channels_amd")
 import kat_cases as K  # noqa: E402
@@ -38,10 +39,16 @@ for B in [int(x) for x in a.batches.split(",")]:
         ms = []
         for rep in range(a.reps + 1):
             torch.cuda.synchronize(); t0 = time.perf_counter()
+            slog = torch.zeros((16, 4), dtype=torch.float64, device=dev) if a.stamps else None
             r = capi.dopri5(capi.MODEL_NNF, params, pv, y0, te, mlp_packed=packed, mlp_layers=5, mlp_width=200, prot_t0=0.0, prot_dt=0.1,
-                            t_eval_hint=(0.0, 5.0), t_eval_exact=True, tile_waves=tw)
+                            t_eval_hint=(0.0, 5.0), t_eval_exact=True, tile_waves=tw, step_log=slog)
             torch.cuda.synchronize(); ms.append((time.perf_counter() - t0) * 1e3)
         nfe = float(r["stats"][:, 2].max())
+        if a.stamps:
+            c = slog.cpu().numpy().reshape(-1)[:16]
+            n0 = float(r["stats"][0, 2])
+            names = {0: "outside-mlp", 1: "layer0+barrier", 2: "layer-prologue", 3: "walk", 4: "store+barrier", 5: "output-layer", 6: "rk-stage/err", 7: "interp+emit", 8: "interp-fit", 9: "cursor", 10: "emit-gather"}
+            print("STAMPS cycles per evaluation (wavefront 0 of tile 0):", {names.get(i, i): int(c[i] / n0) for i in range(16) if c[i] > 0}, "total", int(c.sum() / n0), flush=True)
         same = None if ref is None else bool(torch.equal(ref, r["y"]))
         ref = r["y"] if ref is None else ref
         out[f"B{B}_tile{tw}"] = {"ms": min(ms[1:]), "kernel": r["kernel"], "max_nfe": nfe, "us_per_eval": min(ms[1:]) * 1e3 / nfe, "same_bits_as_first": same}
