@@ -30,8 +30,13 @@ struct RArgs {
   float netscale;
 };
 
+// N <= 200: TWO workgroups per compute unit (two wavefronts per SIMD, <= 256 registers, 70 KB of LDS each): one tile's layer boundaries,
+// barriers and record stores run beside the other's MFMAs.  N = 500 fills the register file and the LDS with one.
+#ifndef IONODE_REGRESS_WG_PER_CU
+#define IONODE_REGRESS_WG_PER_CU 2
+#endif
 template <int NT>
-__global__ void __launch_bounds__(256) ionode_regress_kernel(const RArgs a) {
+__global__ void __launch_bounds__(256, (NT <= 13 ? IONODE_REGRESS_WG_PER_CU : 1)) ionode_regress_kernel(const RArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

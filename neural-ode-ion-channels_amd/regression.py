@@ -61,7 +61,11 @@ class MlpRegression:
         self.recf = lib.ionode_grad_record_floats(L, N)
         self.records = torch.empty(self.tiles * self.recf, dtype=torch.float32, device=dev)
         cus = torch.cuda.get_device_properties(dev).multi_processor_count
-        self.n_wg = int(min(self.tiles, cus))            # persistent grid: one workgroup per CU (115 KB of LDS each)
+        # persistent grid: TWO workgroups per compute unit for N <= 200 (256 registers and 70 KB of LDS each: one tile's layer boundaries
+        # run beside the other's MFMAs), one for N = 500.  IONODE_REGRESS_WG_PER_CU: dev override for A/B runs
+        import os
+        per_cu = int(os.environ.get("IONODE_REGRESS_WG_PER_CU", "2" if N <= 208 else "1"))
+        self.n_wg = int(min(self.tiles, cus * per_cu))
         self.n_slabs = int(max(1, min(cus // (L + 2), self.tiles // 4)))
         self.loss_part = torch.zeros(self.n_wg, dtype=torch.float64, device=dev)
         self.partials = torch.empty((self.n_slabs, partf), dtype=torch.float32, device=dev)
