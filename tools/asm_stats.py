@@ -27,7 +27,7 @@ def unit_flags(unit):
     if unit.startswith("inst_nn"):
         return var("MLPFLAGS")
     if unit == "inst_grad32":
-        return var("GRADFLAGS") + ["-mllvm", "-sink-insts-to-avoid-spills"]
+        return var("GRADFLAGS")
     if unit == "ionode_grad_capi":
         return var("GRADFLAGS")
     m = re.search(r"^%s\.o:.*\n\t\$\(HIPCC\) \$\(FLAGS\) (.*?) \$\(EXTRA\)" % re.escape(unit), mk, re.M)
