@@ -767,8 +767,11 @@ __global__ void __launch_bounds__(256) ionode_dopri5_backward_kernel(const GArgs
 // ---------------------------------------------------------------------------------------------
 constexpr int GRAD_RECOMPUTE_IB = 4;   // iterations per workgroup
 
+#ifndef IONODE_RECOMPUTE_WG_PER_CU
+#define IONODE_RECOMPUTE_WG_PER_CU 1   // 2: ask hipcc for a 256-register build of the N <= 200 kernels (two workgroups per compute unit; A/B)
+#endif
 template <int MODEL, typename S, int NT>
-__global__ void __launch_bounds__(256) ionode_grad_recompute_kernel(const GArgs a) {
+__global__ void __launch_bounds__(256, (NT <= 13 ? IONODE_RECOMPUTE_WG_PER_CU : 1)) ionode_grad_recompute_kernel(const GArgs a) {
   constexpr int D = ModelTraits<MODEL>::D, NPAR = ModelTraits<MODEL>::NPAR;
   static_assert(ModelTraits<MODEL>::MLP && D == 2, "NN-f / NN-d");
   constexpr bool NND = MODEL == IONODE_MODEL_NND;

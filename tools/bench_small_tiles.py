@@ -19,6 +19,7 @@ ap.add_argument("--batches", default="1,4,64,256")
 ap.add_argument("--tiles", default="16,2")
 ap.add_argument("--f64", action="store_true")
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--ref-grid", action="store_true", help="the reference's own output grid: linspace(0, 10000, 100001) in fp32 (not exactly uniform: the GENERAL variants)")
 ap.add_argument("--stamps", action="store_true", help="library built with -DIONODE_STAMPS: cycles per phase and evaluation of wavefront 0")
 a = ap.parse_args()
 ion = importlib.import_module("neural-ode-ion-channels_amd")
@@ -29,6 +30,10 @@ w = K.load_weights("s1")
 packed = torch.from_numpy(capi.mlp_pack(w, 5, 200)).to(dev)
 Np = 100001
 te = torch.arange(2001, dtype=torch.float64, device=dev) * 5.0
+hint, exact = (0.0, 5.0), True
+if a.ref_grid:
+    te = torch.linspace(0.0, 10000.0, 100001, dtype=torch.float32).to(torch.float64).to(dev)   # train-s1.py:48
+    hint, exact = "auto", None
 out = {}
 for B in [int(x) for x in a.batches.split(",")]:
     pv = P.sinewave(P.sinewave_scales(0, B), n_samples=Np, dt=0.1, xp=torch, device=dev)
@@ -41,7 +46,7 @@ for B in [int(x) for x in a.batches.split(",")]:
             torch.cuda.synchronize(); t0 = time.perf_counter()
             slog = torch.zeros((16, 4), dtype=torch.float64, device=dev) if a.stamps else None
             r = capi.dopri5(capi.MODEL_NNF, params, pv, y0, te, mlp_packed=packed, mlp_layers=5, mlp_width=200, prot_t0=0.0, prot_dt=0.1,
-                            t_eval_hint=(0.0, 5.0), t_eval_exact=True, tile_waves=tw, step_log=slog)
+                            t_eval_hint=hint, t_eval_exact=exact, tile_waves=tw, step_log=slog)
             torch.cuda.synchronize(); ms.append((time.perf_counter() - t0) * 1e3)
         nfe = float(r["stats"][:, 2].max())
         if a.stamps:
