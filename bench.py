@@ -343,7 +343,10 @@ def hbm_side_block(legs, pj, lib_sha, pmc_path):
                 nd = max(1, a.get("dispatches", 1))
                 e["valu_issue_frac"] = round(a["SQ_INSTS_VALU"] / nd * 4.0 / (1024.0 * cyc), 4)
                 e["valu_busy"] = round(a["SQ_ACTIVE_INST_VALU"] / nd * 4.0 / (1024.0 * cyc), 4)
-                e["pmc_kernel_ms"] = round(cyc / 2.4e6, 3)
+                e["launch_cycles"] = int(cyc)
+                # shader clock the launch averaged (counter pass's cycles over THIS run's duration: same launch, different runs): the
+                # fp64-heavy 2-state kernel writing 4 TB/s runs power-limited well below the 2.4 GHz the light launches hold
+                e["mean_clock_GHz"] = round(cyc / (v["kernel_ms"] * 1e6), 2)
                 # the binding roof: vector issue when the VALU is busy most of the launch, else the store pattern / latency
                 e["binds"] = "valu-issue" if e["valu_busy"] >= 0.7 else ("store-pattern+valu" if e["valu_busy"] >= 0.55 else "latency")
         except (KeyError, StopIteration, ZeroDivisionError):
