@@ -61,6 +61,33 @@ def test_reference_regression_samples_are_reproduced(oracle):
     assert rel(a[::s], fix["a"]) <= 5e-6 and rel(d[::s], fix["dadt"]) <= 5e-3
 
 
+def test_figure0s_intermediates_are_reproduced(oracle):
+    """Round 5: the same pipeline on figure-0-s's single sweep, where the reference cached EVERY intermediate (figure-0-s.py:139-214):
+    seeded noise on the HH current (:31, :141-144), r(t) of a second solve (:147-153), per-segment Hanning smoothing + interpolating
+    cubic spline -> i.pt / didt.pt (:160-183), a = i / (g r (V - E)) -> a.pt, da/dt -> dadt.pt (:184-205).  Restated with
+    preprocess.py and the oracle's solves: the smoothed current to 2e-6 relative (the fp32 solver noise through a smoother), a to
+    8e-6, di/dt to 5e-3 (a spline derivative at 0.1 ms spacing amplifies that noise ~1e3-fold, as in the s1 test), da/dt to 5e-4."""
+    fix = np.load(os.path.join(K.GOLDEN, "preproc_fig0s.npz"))
+    st = int(fix["stride"])
+    pt = np.linspace(0., 8000., 80001)
+    te = K.f32_linspace(0, 8000, 80001)
+    pv = np.zeros(80001); pv[:10000] = -80; pv[10000:60000] = 40; pv[60000:70000] = -40; pv[70000:75000] = -120; pv[75000:] = -80   # figure-0-s.py:45-56
+    y = oracle.solve(K.MODEL_HH2, K.P_HH, pv, [0.0, 1.0], te, prot_t=pt, state_f32=True)["y"][0]
+    vt, _ = oracle.protocol_v(pv, te, prot_t=pt)
+    np.random.seed(0)                                       # figure-0-s.py:31
+    i_noisy = oracle.current(y, vt, state_f32=True) + np.random.normal(0, 0.1, te.shape)
+    r = y[:, 1]
+    k3, k4 = K.P_HH[4] * np.exp(K.P_HH[5] * vt), K.P_HH[6] * np.exp(-K.P_HH[7] * vt)
+    i_fit, didt = pp.fit_current(te, i_noisy, pt, pv)
+    a, dadt = pp.state_space_samples(i_fit, didt, r, -k3 * r + k4 * (1. - r), vt)
+    assert i_fit.size == int(fix["n"]) == 80001
+    rel = lambda x, yv: float(np.linalg.norm(x - yv) / np.linalg.norm(yv))
+    got = {"i": i_fit[::st], "didt": didt[::st], "a": a[::st], "dadt": dadt[::st]}
+    err = {k: rel(got[k], fix[k]) for k in got}
+    print(err)
+    assert err["i"] <= 2e-6 and err["a"] <= 8e-6 and err["didt"] <= 5e-3 and err["dadt"] <= 5e-4, err   # measured 1.1e-6 / 4.3e-6 / 1.7e-3 / 8.5e-5
+
+
 def test_smooth_properties():
     x = np.random.default_rng(0).normal(size=500)
     for w in ("flat", "hanning", "hamming", "bartlett", "blackman"):
