@@ -1449,8 +1449,11 @@ template <int N> struct MlpLane {
 #pragma unroll
         for (int u = 0; u < GP; ++u)
           if (m0 + u < NPAIR) g[m0 + u] = sh[((size_t)l * NPAIR + m0 + u) * (PB / 2) + N];
+#ifndef IONODE_VNET_SPLIT
+#define IONODE_VNET_SPLIT 0   // > 0: a scheduling barrier after this many k positions (A/B: fewer scalar registers of weights in flight)
+#endif
 #pragma unroll
-        for (int pos = 0; pos < N; ++pos)
+        for (int pos = 0; pos < N; ++pos) {
 #pragma unroll
           for (int u = 0; u < GP; ++u)
             if (m0 + u < NPAIR) {
@@ -1458,6 +1461,8 @@ template <int N> struct MlpLane {
               const int k = k_at(pos);
               g[m0 + u] = (k & 1) ? pk_fma_hi(w, h[k >> 1], g[m0 + u]) : pk_fma_lo(w, h[k >> 1], g[m0 + u]);
             }
+          if (IONODE_VNET_SPLIT > 0 && pos + 1 == IONODE_VNET_SPLIT) __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int u = 0; u < GP; ++u)
           if (m0 + u < NPAIR) g[m0 + u] = lrelu2(g[m0 + u]);

@@ -185,3 +185,30 @@ def test_deep_stacks_stay_off_the_one_trajectory_tile(ion, gpu, oracle):
     g = _kernel(ion, gpu, K.MODEL_NNF, K.P_HH, pv, K.NN_Y0, te, weights=w, L=L, N=N, **kw)
     assert ", 4, 4, 13, 13, 24>" in g["kernel"], g["kernel"]
     assert np.array_equal(g["y"], o["y"]) and np.array_equal(g["stats"], o["stats"])
+
+
+@pytest.mark.parametrize("f32", [False, True])
+def test_one_trajectory_tile_general_variant_nnd_and_checkpoints(ion, gpu, oracle, f32):
+    """The GENERAL variant (TAIL slot 32) of the one-trajectory tile for NN-d in both state dtypes, with what takes a launch off the
+    lean contract all at once: a step log, accepted-step checkpoints (the gradient path's forward) and the fused current trace."""
+    capi = ion.capi
+    w = K.load_weights("d2")
+    B = 2
+    params = np.tile(K.P_NN_D, (B, 1)) * np.random.default_rng(11).uniform(0.9, 1.1, (B, 8))
+    pv = np.stack([K.activation(v)[1] for v in (-20, 40)])
+    te = K.activation(0)[2][:1201]
+    kw = dict(prot_t0=0.0, prot_dt=1.0, prot_of_traj=np.arange(B, dtype=np.int32))
+    o = oracle.solve(K.MODEL_NND, params, pv, K.NN_Y0, te, weights=w, mlp_layers=5, mlp_width=200, state_f32=f32, **kw)
+    cap = int(o["stats"][:, 0].max()) + 4
+    ck = torch.zeros((B, cap, 4 + 16), dtype=torch.float64, device=gpu)
+    slog = torch.zeros((3000, 4), dtype=torch.float64, device=gpu)
+    g = _kernel(ion, gpu, K.MODEL_NND, params, pv, K.NN_Y0, te, weights=w, L=5, N=200, f32=f32, tile_waves=16, step_log=slog, ckpt=ck, current=True, **kw)
+    g16 = _kernel(ion, gpu, K.MODEL_NND, params, pv, K.NN_Y0, te, weights=w, L=5, N=200, f32=f32, tile_waves=4, current=True, **kw)
+    assert ", 4, 4, 13, 13, 32>" in g["kernel"], g["kernel"]
+    assert np.array_equal(g["y"], o["y"]) and np.array_equal(g["stats"], o["stats"]) and np.array_equal(g["i"], g16["i"])
+    ckn = ck.cpu().numpy()
+    for b in range(B):
+        n = int(o["stats"][b, 0])
+        t0, dt = ckn[b, :n, 0], ckn[b, :n, 1]
+        assert np.all(dt > 0) and np.allclose(t0[1:], t0[:-1] + dt[:-1], rtol=0, atol=1e-9) and float(ckn[b, n:].sum()) == 0.0
+        assert int(ckn[b, :n, 3].sum()) == te.size - 1          # every output sample but the first belongs to exactly one accepted step

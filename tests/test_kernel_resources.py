@@ -113,3 +113,21 @@ def test_per_lane_net_issues_packed_fma_with_scalar_weights():
     assert sum("op_sel:[0,1,0]" in l for l in re.findall(r"v_pk_fma_f32[^\n]*", body)) >= 150   # both halves of the activation pairs are used
     assert not re.search(r"v_max_f32(?:_e32|_e64)? (v\d+), \1, \1\b", body)
     assert "scratch_" not in body
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc")
+def test_no_dpp_source_is_read_too_early():
+    """Round 5: the one-trajectory tile's chain links are inline-asm `v_fmac_f32_dpp`; hipcc's hazard recognizer does not look inside
+    inline asm, and gfx9 requires two wait states between a VALU write of a VGPR and a DPP read of it.  The DPP sources come straight
+    from LDS reads (no hazard) -- unless a future compiler puts a vector move in front of one.  Every MLP unit, every kernel, statically."""
+    from concurrent.futures import ThreadPoolExecutor
+    import asm_stats
+    units = ("inst_nnf_f32", "inst_nnf_f64", "inst_nnd_f32", "inst_nnd_f64")
+    with ThreadPoolExecutor(4) as ex:
+        texts = list(ex.map(asm_stats.compile_asm, units))
+    for unit, txt in zip(units, texts):
+        assert txt.count("v_fmac_f32_dpp") >= 8 * 208 * 2, unit          # the links are there (general + lean variant, eight inlined evaluations)
+        bad = asm_stats.dpp_hazards(txt)
+        assert not bad, (unit, bad[:3])
+    probe = "_Zk:\n\tv_mov_b32_e32 v5, v7\n\tv_fmac_f32_dpp v1, v5, v9 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\ts_endpgm\n"
+    assert len(asm_stats.dpp_hazards(probe)) == 1                          # the checker sees what it is looking for

@@ -157,6 +157,54 @@ def kernel_stats(asm):
     return res
 
 
+def dpp_hazards(asm_text, wait_states=2):
+    """Static check of the gfx9 hazard 'VALU writes a VGPR -> a DPP instruction reads it as its DPP source within `wait_states` wait states'.
+    hipcc's hazard recognizer does not look inside inline-asm statements (the one-trajectory tile's v_fmac_f32_dpp links are inline asm; their
+    DPP sources come straight from LDS reads, which are not VALU writes) -- this walks every kernel of the unit and returns
+    [(kernel symbol, dpp instruction, offending instruction)] for DPP sources written by a VALU instruction fewer than wait_states + 1
+    instructions earlier (s_nop N counts N + 1; branches / labels end the window conservatively: a hazard across them is not assumed)."""
+    bad = []
+    for sym, body in re.findall(r"^(_Z\w+):\n(.*?)\n\s+s_endpgm", asm_text, re.S | re.M):
+        window = []   # (distance already accumulated is implicit: list of (n_wait_states, written vgprs)) for the last instructions
+        for raw in body.split("\n"):
+            ins = raw.split(";")[0].strip()
+            if not ins or ins.startswith(".") or ins.startswith("//"):
+                continue
+            if ins.endswith(":"):
+                window = []
+                continue
+            op = ins.split()[0]
+            if "_dpp" in op:
+                ops = [o.strip() for o in ins[len(op):].split(",")]
+                # VOP2 dpp: vdst, src0 (the DPP source), src1;  VOP1 dpp (v_mov_b32_dpp): vdst, src0
+                src = ops[1].split()[0] if len(ops) > 1 else ""
+                dist = 0
+                for ws, written, text in reversed(window):
+                    if dist >= wait_states:
+                        break
+                    if src in written:
+                        bad.append((sym, ins, text))
+                        break
+                    dist += ws
+            written = set()
+            ws = 1
+            if op == "s_nop":
+                ws = int(ins.split()[1]) + 1
+            elif op.startswith("v_") and not op.startswith(("v_cmp", "v_readlane", "v_readfirstlane")):
+                d = ins[len(op):].split(",")[0].strip()
+                m = re.match(r"v\[(\d+):(\d+)\]", d)
+                if m:
+                    written = {"v%d" % i for i in range(int(m.group(1)), int(m.group(2)) + 1)}
+                elif re.match(r"v\d+$", d):
+                    written = {d}
+            if op.startswith(("s_cbranch", "s_branch", "s_setpc", "s_swappc")):
+                window = []
+            else:
+                window.append((ws, written, ins))
+                window = window[-4:]
+    return bad
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     opt = {a.split("=", 1)[0]: (a.split("=", 1)[1] if "=" in a else True) for a in sys.argv[1:] if a.startswith("--")}
