@@ -159,14 +159,15 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false, bool ex
     const bool vnet = t64 && d->mlp_width == 10 && !IONODE_TINY64_MFMA;
     // N = 200, small batches and single calls: 4 trajectories per tile (MlpTile4; tile_waves = 2 forces it, 4 / 8 exclude it)
     // N = 200, single calls and the smallest batches: ONE trajectory per tile (MlpRow1; tile_waves = 16 forces it, 2 / 4 / 8 exclude it)
-    const bool t1 = !t64 && !t32 && NT == 13 && d->mlp_layers >= 1 && d->mlp_layers <= ionode::MlpRow1::max_layers() &&
+    const bool t1 = !t64 && !t32 && NT == 13 && d->mlp_layers >= 1 && d->mlp_layers <= 15 &&
                     (d->tile_waves == 16 || (d->tile_waves == 0 && d->n_traj <= IONODE_TILE1_UPTO));
+    const bool t1deep = t1 && d->mlp_layers > ionode::MlpRow1::max_layers();   // no room for LDS-resident steps: every step streamed
     const bool t4 = !t64 && !t32 && !t1 && NT == 13 && d->mlp_layers >= 1 && (d->traj_per_image <= 0 || d->traj_per_image % 4 == 0) &&
                     (d->tile_waves == 2 || (d->tile_waves == 0 && d->n_traj <= IONODE_TILE4_UPTO));
     // N = 200 tiles: the lean variant when its contract holds (ionode_device.hpp LEANM)
     const bool leanm = !t64 && (NT == 13 || NT == 7 || NT == 32) && d->mlp_layers >= 1 && !explicit_grid && !has_step_log && !d->ckpt && d->t_eval_exact && d->t_eval_dt_hint > 0.0 && d->n_out > 1;
     pl->v = t64 ? find_variant(d->model, f32, 1, NT, 64, t64lean, vnet ? 10 : 1)
-                : find_variant(d->model, f32, ((d->tile_waves == 8 || d->tile_waves == 2 || d->tile_waves == 16) ? 4 : d->tile_waves), NT, NT == 1 ? 1 : -1, (t32 ? 4 : 0) | (leanm ? 8 : 0) | (t4 ? 16 : 0) | (t1 ? 32 : 0));
+                : find_variant(d->model, f32, ((d->tile_waves == 8 || d->tile_waves == 2 || d->tile_waves == 16) ? 4 : d->tile_waves), NT, NT == 1 ? 1 : -1, (t32 ? 4 : 0) | (leanm ? 8 : 0) | (t4 ? 16 : 0) | (t1 ? 32 : 0) | (t1deep ? 64 : 0));
     // any other width up to 512 (table-s1.py:145-153 builds nets of any (n_layers, n_nodes)): the run-time-width tile (MlpGen)
     bool gen = false;
     if (!pl->v && NT >= 2 && NT <= ionode::MlpGen::NT_MAX && (d->tile_waves == 0 || d->tile_waves == 4)) {
@@ -189,7 +190,7 @@ int make_plan(const ionode_desc *d, Plan *pl, bool want_current = false, bool ex
     pl->lds = ((size_t)2 * (NT + Gv - 1) * 64 + (size_t)2 * Rv * Gv * 64 + NP) * 16 + ((size_t)d->mlp_layers * NP + NP + 4) * 4;
     // the asm tile (N = 200): + scratch slot (+ the input exchange of the two-column-set tile), MlpTile::lds_total
     if (gen) pl->lds = ionode::MlpGen::lds_bytes(d->mlp_layers, NT);
-    else if (t1) pl->lds = ionode::MlpRow1::lds_bytes(d->mlp_layers);
+    else if (t1) pl->lds = t1deep ? ionode::MlpRow1Deep::lds_bytes(d->mlp_layers) : ionode::MlpRow1::lds_bytes(d->mlp_layers);
     else if (t4) pl->lds = ionode::MlpTile4::lds_bytes(d->mlp_layers);
     else if (Gv == 4 && NT == 13) pl->lds = t32 ? ionode::MlpTile<4, 4, 13, 13, 4>::lds_total(d->mlp_layers) : ionode::MlpTile<4, 4, 13, 13, 0>::lds_total(d->mlp_layers);
     if (t64) plan_lane_wise(pl, (size_t)((d->n_traj + 63) / 64), (vnet ? (size_t)0 : ((pl->lds + 15) & ~(size_t)15)) + (size_t)ionode::LwLds::bytes(2, t64lean));  // MlpTile region + the lane-wise region

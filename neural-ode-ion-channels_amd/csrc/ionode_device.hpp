@@ -1186,7 +1186,7 @@ struct MlpTile4 {
 // W[64 w + lane][16 ((s + lane / 16) mod 13) + 4 q + r]; wavefront 3: [step j][r][lane = 16 c + i] float4 over q of W[192 + i][16 (c + 4 j) + 4 q + r]
 // (-0.0f for c + 4 j > 12); then per (wavefront, lane) the accumulator start (the row's bias; chains c > 0: 0).
 // ---------------------------------------------------------------------------------------------
-struct MlpRow1 {
+template <int MRES_> struct MlpRow1T {
   static constexpr int GW = 4, NT = 13, NP = 208;
   static constexpr int SLOTS = NT + 3;       // activation buffer, transposed order: k-tile slots 0..15, tiles 0..2 stored twice (slot kt and kt + 13)
   static constexpr int FRAGS_FULL = NT * 4, FRAGS_REM = 4 * 4;   // 1 KiB fragments per layer of a full-row wavefront / of the remainder wavefront
@@ -1197,11 +1197,9 @@ struct MlpRow1 {
   // LDS to itself: the fragments of the first MRES = 2 steps of EVERY hidden layer of the three full-row wavefronts (24 KB per layer) stay in
   // LDS for the kernel's lifetime; their ring slots are refilled from there instead of from L2 -- 24 of 172 loads per layer less through the
   // memory path.  The same code for every layer (no per-layer variant: a branch around refills costs hipcc's wait counts their precision).
-  // Stacks of more than 6 hidden layers do not fit: the dispatcher keeps them on the 4-trajectory tile (max_layers()).
-#ifndef IONODE_ROW1_MRES
-#define IONODE_ROW1_MRES 2
-#endif
-  static constexpr int MRES = IONODE_ROW1_MRES;
+  // Stacks of more than 6 hidden layers do not fit beside two steps per layer: they take the variant without resident steps
+  // (MRES_ = 0, TAIL & 64: every step streamed; up to 15 hidden layers -- architectures s02: 10 x 200).
+  static constexpr int MRES = MRES_;
   static __host__ __device__ constexpr size_t res_off(int L) { return (small_bytes(L) + 1023) & ~(size_t)1023; }
   static __host__ __device__ constexpr size_t lds_bytes(int L) { return MRES > 0 ? res_off(L) + (size_t)L * 3 * MRES * 4 * 1024 : small_bytes(L); }
   static __host__ __device__ constexpr int max_layers() { int L = 1; while (L < 15 && lds_bytes(L + 1) <= 160 * 1024) ++L; return L; }
@@ -1357,6 +1355,12 @@ struct MlpRow1 {
     return out;
   }
 };
+
+#ifndef IONODE_ROW1_MRES
+#define IONODE_ROW1_MRES 2
+#endif
+using MlpRow1 = MlpRow1T<IONODE_ROW1_MRES>;   // nets of at most MlpRow1::max_layers() = 6 hidden layers
+using MlpRow1Deep = MlpRow1T<0>;              // deeper stacks (TAIL & 64)
 
 // ---------------------------------------------------------------------------------------------
 // N = 10 nets (architectures s03-s05) at one trajectory per lane: the net evaluated PER LANE on the vector ALU, weights as
@@ -1702,7 +1706,7 @@ __device__ __forceinline__ void rhs(const KArgs &a, const double *p, double v, b
     // (not for the 64-per-wavefront N <= 16 kernel: two interleaved branch-free exps cost ~30 registers -- it went from 252 to 284
     // VGPRs, i.e. from two wavefronts per SIMD to one, 58 -> 87 ms)
     // (the 4-trajectory tile keeps a 208-register weight ring: the branchy form with one exp in flight, same bits)
-    constexpr bool TIGHT = std::is_same<MLP, MlpTile4>::value || std::is_same<MLP, MlpRow1>::value;
+    constexpr bool TIGHT = std::is_same<MLP, MlpTile4>::value || std::is_same<MLP, MlpRow1>::value || std::is_same<MLP, MlpRow1Deep>::value;
     auto dexp = [](double x) { if constexpr (TIGHT) return det_exp_ldexp(x); else if constexpr (MT::MLP && !WIDE) return det_exp_s(x); else return det_exp(x); };
     double k3, k4, dadt = 0.0;
     if constexpr (MT::MLP && WIDE) {
@@ -1946,7 +1950,7 @@ __global__ void __launch_bounds__(64 * (IONODE_IS_LW(MODEL, RT) ? IONODE_LW_TILE
   // NT slot == 0 of a four-wavefront MLP kernel: the run-time-width tile (MlpGen: any N <= 512 without a tuned tile of its own)
   constexpr bool GEN = MT::MLP && G == 4 && NT == 0;
   using MlpTileT = MlpTile<G, (T64 ? 1 : (RT > 0 ? RT : 1)), (NT > 0 ? NT : 1), ((PD > 0 && !VNET) ? PD : 1), (NSETS > 1 ? 4 : 0)>;
-  using MlpT = typename std::conditional<VNET, MlpLane<(VNET ? PD : 10)>, typename std::conditional<T1, MlpRow1, typename std::conditional<T4, MlpTile4, typename std::conditional<GEN, MlpGen, MlpTileT>::type>::type>::type>::type;
+  using MlpT = typename std::conditional<VNET, MlpLane<(VNET ? PD : 10)>, typename std::conditional<T1, typename std::conditional<(TAIL & 64) != 0, MlpRow1Deep, MlpRow1>::type, typename std::conditional<T4, MlpTile4, typename std::conditional<GEN, MlpGen, MlpTileT>::type>::type>::type>::type;
   typename std::conditional<MT::MLP, MlpT, NoMlp>::type mlp;
   if constexpr (MT::MLP) mlp.init(a, smem_t, wave, lane, tile * TPW);
   // lane-wise kernels: interpolant rows + tail buffers; behind the MlpTile region when there is one

@@ -55,6 +55,8 @@ hipError_t launch(const KArgs &a, unsigned grid, size_t lds, hipStream_t s) {
       IONODE_VARIANT(MODEL, S, F32, 4, 4, 13, 13, 16), IONODE_VARIANT(MODEL, S, F32, 4, 4, 13, 13, 24),   \
       /* N = 200 at ONE trajectory per tile (TAIL & 32: MlpRow1, the reference's own odeint(func, y0, t) call shape), general and lean */ \
       IONODE_VARIANT(MODEL, S, F32, 4, 4, 13, 13, 32), IONODE_VARIANT(MODEL, S, F32, 4, 4, 13, 13, 40),   \
+      /* ... and for stacks of 7 .. 15 hidden layers without LDS-resident steps (TAIL & 64: MlpRow1Deep) */ \
+      IONODE_VARIANT(MODEL, S, F32, 4, 4, 13, 13, 96), IONODE_VARIANT(MODEL, S, F32, 4, 4, 13, 13, 104),  \
       /* lean variants of the N = 100 and N = 500 tiles */                                              \
       IONODE_VARIANT(MODEL, S, F32, 4, 4, 7, 7, 8), IONODE_VARIANT(MODEL, S, F32, 4, 8, 32, 4, 8),        \
       /* any other width up to 512 (NT slot 0: MlpGen, the k-tile count is a run-time value), general and lean */ \

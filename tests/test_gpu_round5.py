@@ -172,19 +172,28 @@ def test_single_odeint_call_takes_the_one_trajectory_tile(ion, gpu, oracle):
     assert ", 4, 4, 13, 13, 40>" in ion.capi.lib().ionode_last_kernel_name().decode() and bool(torch.isfinite(y2).all())
 
 
-def test_deep_stacks_stay_off_the_one_trajectory_tile(ion, gpu, oracle):
+@pytest.mark.parametrize("L", [7, 10, 15])
+def test_deep_stacks_take_the_one_trajectory_tile_without_resident_steps(ion, gpu, oracle, L):
     """The one-trajectory tile keeps two steps of every hidden layer's weights in LDS (24 KB per layer): stacks of more than six hidden
-    layers do not fit beside it, so a single call of such a net (s02: 10 x 200) is served by the 4-trajectory tile -- same bits."""
-    rng = np.random.default_rng(3)
-    L, N = 10, 200
-    w = rng.normal(0, 0.1, 2 * N + N + L * (N * N + N) + N + 1).astype(np.float32)
+    layers do not fit beside them and take the variant that streams every step (TAIL & 64; s02 is 10 x 200) -- same bits as the oracle and
+    as the 4-trajectory tile, which a 16-layer stack falls back to."""
+    rng = np.random.default_rng(3 + L)
+    N = 200
+    w = rng.normal(0, 0.1 if L < 12 else 0.07, 2 * N + N + L * (N * N + N) + N + 1).astype(np.float32)
     pt, pv, te = K.atau(30)
     te = te[:401]
     kw = dict(prot_t0=float(pt[0]), prot_dt=float(pt[1] - pt[0]))
-    o = oracle.solve(K.MODEL_NNF, K.P_HH, pv, K.NN_Y0, te, weights=w, mlp_layers=L, mlp_width=N, **kw)
-    g = _kernel(ion, gpu, K.MODEL_NNF, K.P_HH, pv, K.NN_Y0, te, weights=w, L=L, N=N, **kw)
-    assert ", 4, 4, 13, 13, 24>" in g["kernel"], g["kernel"]
+    B = 3
+    params = np.tile(K.P_HH, (B, 1)) * rng.uniform(0.9, 1.1, (B, 8))
+    o = oracle.solve(K.MODEL_NNF, params, pv, K.NN_Y0, te, weights=w, mlp_layers=L, mlp_width=N, **kw)
+    g = _kernel(ion, gpu, K.MODEL_NNF, params, pv, K.NN_Y0, te, weights=w, L=L, N=N, **kw)
+    assert ", 4, 4, 13, 13, 104>" in g["kernel"], g["kernel"]
     assert np.array_equal(g["y"], o["y"]) and np.array_equal(g["stats"], o["stats"])
+    g4 = _kernel(ion, gpu, K.MODEL_NNF, params, pv, K.NN_Y0, te, weights=w, L=L, N=N, tile_waves=2, **kw)
+    assert ", 4, 4, 13, 13, 24>" in g4["kernel"] and np.array_equal(g4["y"], o["y"])
+    slog = torch.zeros((64, 4), dtype=torch.float64, device=gpu)
+    gg = _kernel(ion, gpu, K.MODEL_NNF, params, pv, K.NN_Y0, te, weights=w, L=L, N=N, step_log=slog, **kw)      # general variant
+    assert ", 4, 4, 13, 13, 96>" in gg["kernel"] and np.array_equal(gg["y"], o["y"])
 
 
 @pytest.mark.parametrize("f32", [False, True])

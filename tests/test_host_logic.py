@@ -380,6 +380,9 @@ def test_explicit_64_per_wavefront_rejects_images_that_do_not_fill_a_tile(ion):
     assert capi.launch_geometry(capi.make_desc(tile_waves=2, traj_per_image=4, **kw200))["grid"] == 16   # 4-trajectory tiles
     assert capi.launch_geometry(capi.make_desc(tile_waves=16, traj_per_image=1, **kw200))["grid"] == 64  # one-trajectory tiles: any image granularity
     assert ", 4, 4, 13, 13, 32>" in capi.kernel_name(capi.make_desc(**dict(kw200, mlp_image_stride=0)))  # 64 trajectories: chosen by itself
+    deep = dict(kw200, mlp_image_stride=0, mlp_layers=10)                                                  # s02: no room for LDS-resident steps
+    assert ", 4, 4, 13, 13, 96>" in capi.kernel_name(capi.make_desc(**deep)) and capi.launch_geometry(capi.make_desc(**deep))["lds_bytes"] < 20 * 1024
+    assert capi.launch_geometry(capi.make_desc(**dict(kw200, mlp_image_stride=0)))["lds_bytes"] > 100 * 1024
 
 
 def test_lane_wise_crossovers_come_from_the_library(ion):
