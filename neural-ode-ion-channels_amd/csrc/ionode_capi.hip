@@ -350,43 +350,48 @@ int ionode_mlp_pack(const float *w, int32_t L, int32_t N, float *out) {
   for (int k = 0; k < N; ++k) dst[k] = src[k];
   dst[NP] = src[N];
   if (NT == 13) {
-    // section of the 4-trajectory tile (ionode_device.hpp MlpTile4): layer | wavefront w | step s (k-tile (s + w) mod 13) | q | lane 4 b + i ->
-    // float4 over r of W[row][16 kt + 4 q + r]; block b = 4 g + u: g < 3 row 16 (w + 4 g) + 4 u + i, g == 3 remainder row 192 + 4 u + i on
-    // the steps that carry chain w (s % 4 == 0, s + w < 13) and -0.0f elsewhere; then per (w, lane) the accumulator start {bias of rows i}
+    // section of the 4-trajectory tile (ionode_device.hpp MlpTile4), round-5 lane layout.  Per layer: wavefronts 0..2: [w][step s][q][lane = 4 b + i]
+    // float4 over r of W[row][16 kt + 4 q + r], block b = 4 g + u: row 16 (4 w + g) + 4 u + i, kt = (s + g) mod 13; wavefront 3 (partial chains of
+    // the remainder rows): [step j][q][lane] float4 over r of W[192 + 4 u + i][16 (c + 4 j) + 4 q + r] with c = g, -0.0f where c + 4 j > 12; then per
+    // (wavefront, lane) the accumulator start float4 {bias of rows i = 0..3 of the lane's block} (chains c > 0: 0)
     float *t4 = dst + NP + 4;
     const float *lsrc = b0 + N;
     for (int l = 0; l < L; ++l) {
       const float *W = lsrc, *b = lsrc + (size_t)N * N;
       float *lay = t4 + (size_t)l * ionode::MlpTile4::layer_floats();
-      for (int wv = 0; wv < 4; ++wv) {
-        for (int st = 0; st < 13; ++st) {
-          const int kt = (st + wv) % 13;
-          const bool chain = (st % 4 == 0) && (st + wv < 13);
+      for (int wv = 0; wv < 3; ++wv)
+        for (int st = 0; st < 13; ++st)
           for (int q = 0; q < 4; ++q)
             for (int lane = 0; lane < 64; ++lane) {
               const int i = lane & 3, bb = lane >> 2, g = bb >> 2, u = bb & 3;
               float *f = lay + ((((size_t)wv * 13 + st) * 4 + q) * 64 + lane) * 4;
+              const int row = 16 * (4 * wv + g) + 4 * u + i, kt = (st + g) % 13;
               for (int r = 0; r < 4; ++r) {
                 const int k = 16 * kt + 4 * q + r;
-                if (g < 3) {
-                  const int row = 16 * (wv + 4 * g) + 4 * u + i;
-                  f[r] = (row < N && k < N) ? W[(size_t)row * N + k] : 0.0f;
-                } else {
-                  const int row = 192 + 4 * u + i;
-                  f[r] = chain ? ((row < N && k < N) ? W[(size_t)row * N + k] : 0.0f) : -0.0f;
-                }
+                f[r] = (row < N && k < N) ? W[(size_t)row * N + k] : 0.0f;
               }
             }
-        }
-        float *bias = lay + (size_t)4 * 13 * 4 * 256 + (size_t)wv * 256;
+      float *rem = lay + (size_t)3 * 13 * 4 * 256;
+      for (int jj = 0; jj < 4; ++jj)
+        for (int q = 0; q < 4; ++q)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int i = lane & 3, bb = lane >> 2, c = bb >> 2, u = bb & 3;
+            float *f = rem + (((size_t)jj * 4 + q) * 64 + lane) * 4;
+            const int row = 192 + 4 * u + i, kt = c + 4 * jj;
+            for (int r = 0; r < 4; ++r) {
+              const int k = 16 * kt + 4 * q + r;
+              f[r] = (kt >= 13) ? -0.0f : ((row < N && k < N) ? W[(size_t)row * N + k] : 0.0f);
+            }
+          }
+      float *bias = rem + (size_t)4 * 4 * 256;
+      for (int wv = 0; wv < 4; ++wv)
         for (int lane = 0; lane < 64; ++lane) {
           const int bb = lane >> 2, g = bb >> 2, u = bb & 3;
           for (int i = 0; i < 4; ++i) {
-            const int row = (g < 3) ? 16 * (wv + 4 * g) + 4 * u + i : 192 + 4 * u + i;
-            bias[lane * 4 + i] = (row < N && (g < 3 || wv == 0)) ? b[row] : 0.0f;
+            const int row = (wv < 3) ? 16 * (4 * wv + g) + 4 * u + i : 192 + 4 * u + i;
+            bias[((size_t)wv * 64 + lane) * 4 + i] = (row < N && (wv < 3 || g == 0)) ? b[row] : 0.0f;
           }
         }
-      }
       lsrc += (size_t)N * N + N;
     }
     // section of the one-trajectory tile (ionode_device.hpp MlpRow1), behind the 4-trajectory tile's.  Per layer: wavefronts 0..2: [w][step s]

@@ -986,17 +986,24 @@ struct MlpTile {
 struct MlpTile4 {
   static constexpr int GW = 4, NT = 13, NP = 208;
   static constexpr int SLOTS = NT + 3;               // k-tile slots per activation buffer: tiles 0..2 are stored twice (slot kt and kt + 13), so
-                                                     // that wavefront w reads its rotated walk kt = (s + w) mod 13 at the LINEAR slot s + w
+                                                     // that a block whose row tile rotates from k-tile g reads its walk kt = (s + g) mod 13 at the LINEAR slot s + g
   static constexpr int ACT = SLOTS * 16;             // float4 per activation buffer: [slot][q][trajectory]
-  static constexpr size_t layer_floats() { return (size_t)4 * NT * 4 * 256 + (size_t)4 * 256; }   // fragments + bias float4 per (wave, lane)
+  // Round 5: the lane layout of the one-trajectory tile (MlpRow1).  Wavefronts 0..2 hold 64 FULL rows each -- 16 blocks of 4 rows: block
+  // b = 4 g + u is rows 16 (4 w + g) + 4 u + i, whose canonical chain rotates from k-tile g (the B operand is read per lane, so the four
+  // block groups of a wavefront walk four rotations) -- and wavefront 3 holds the four partial chains of the sixteen remainder rows (block
+  // 4 c + u: chain c of rows 192 + 4 u + i; 4 steps instead of 13), folded (p0 + p1) + (p2 + p3) across its lane groups.  172 one-KiB weight
+  // loads per layer instead of 208 (round 4: every wavefront 48 rows + a remainder chain): this tile's walk waits on the compute unit's
+  // vector-memory path as much as on the 4x4x1 MFMA's dependent issue (without its refills an evaluation takes 8.4 instead of 10.2 us).
+  static constexpr int FRAGS_FULL = NT * 4, FRAGS_REM = 4 * 4;   // 1 KiB fragments per layer of a full-row wavefront / of the remainder wavefront
+  static constexpr size_t layer_floats() { return (size_t)(3 * FRAGS_FULL + FRAGS_REM) * 256 + (size_t)4 * 256; }   // fragments + accumulator-start float4 per (wave, lane)
   static __host__ __device__ constexpr size_t lds_bytes(int L) {
-    return ((size_t)2 * ACT + (size_t)2 * 4 * 16 + NP) * 16 + ((size_t)NP + 4) * 4 + (size_t)L * 64 * 16;   // activations x2, partial sums x2, W0 rows, wl + bl, accumulator starts [L][wave][block]
+    return ((size_t)2 * ACT + NP) * 16 + ((size_t)NP + 4) * 4 + (size_t)L * 64 * 16;   // activations x2, W0 rows, wl + bl, accumulator starts [L][wave][block]
   }
   f32x4 ring[NT][4];
-  f32x4 wlr[NT];   // Linear(N, 1): this lane's chain q = (lane >> 2) & 3 of the output weights, resident (52 registers; read from LDS per
-                   // evaluation they cost thirteen exposed round trips on the critical path of a single trajectory)
   f32x4 w0r[4];    // layer 0: the four rows {b0, w00, w01, 0} of this lane's output block
-  f32x4 *Hs, *Ps;
+                   // (round 4 also kept the lane's chain of the output weights resident: 52 registers the two walk forms of round 5 need;
+                   // they are read from LDS together with the thirteen activation reads of the output layer -- one round trip)
+  f32x4 *Hs;
   const f32x4 *W0s, *B4s;
   const float *wlS;
   __amdgpu_buffer_rsrc_t rsrc;
@@ -1018,8 +1025,7 @@ struct MlpTile4 {
     L = a.L; wave = wave_; lane = lane_;
     const float *__restrict__ img = a.mlp + (a.traj_per_img > 0 ? (size_t)(first_traj / a.traj_per_img) * (size_t)a.mlp_stride : (size_t)0);
     Hs = reinterpret_cast<f32x4 *>(smem);
-    Ps = Hs + 2 * ACT;
-    f32x4 *w0 = Ps + 2 * 4 * 16;
+    f32x4 *w0 = Hs + 2 * ACT;
     float *ws = reinterpret_cast<float *>(w0 + NP);
     const int tid = wave * 64 + lane;
     const f32x4 *src = reinterpret_cast<const f32x4 *>(img);
@@ -1033,22 +1039,20 @@ struct MlpTile4 {
     const size_t sec = section_off(L);
     for (int i = tid; i < L * 64; i += 256) {
       const int l = i >> 6, wv = (i >> 4) & 3, bb = i & 15;
-      b4[i] = *reinterpret_cast<const f32x4 *>(img + sec + (size_t)l * layer_floats() + (size_t)4 * NT * 4 * 256 + (size_t)wv * 256 + (size_t)bb * 16);
+      b4[i] = *reinterpret_cast<const f32x4 *>(img + sec + (size_t)l * layer_floats() + (size_t)(3 * FRAGS_FULL + FRAGS_REM) * 256 + (size_t)wv * 256 + (size_t)bb * 16);
     }
     B4s = b4;
     const size_t img_bytes = (sec + (size_t)L * layer_floats()) * 4;
     rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(img), 0, (int)img_bytes, 0x00020000);
     sec0 = (unsigned)(sec * 4);
     lbytes = (unsigned)(layer_floats() * 4);
-    voff = (unsigned)(wave * NT * 4 * 1024 + lane * 16);
+    voff = (unsigned)(wave * FRAGS_FULL * 1024 + lane * 16);
 #pragma unroll
     for (int s = 0; s < NT; ++s)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) ring[s][q] = (L > 0) ? frag(sec0, s * 4 + q) : f32x4{0, 0, 0, 0};
+      for (int q = 0; q < 4; ++q) ring[s][q] = (L > 0 && (wave < 3 || s < 4)) ? frag(sec0, s * 4 + q) : f32x4{0, 0, 0, 0};
     {
       const int b = lane >> 2, kq0 = 16 * wave + b;
-#pragma unroll
-      for (int kt = 0; kt < NT; ++kt) wlr[kt] = *reinterpret_cast<const f32x4 *>(wl + 16 * kt + 4 * (b & 3));
 #pragma unroll
       for (int r = 0; r < 4; ++r) w0r[r] = (kq0 < NP / 4) ? src[4 * kq0 + r] : f32x4{0, 0, 0, 0};
     }
@@ -1059,23 +1063,42 @@ struct MlpTile4 {
     H[(kt * 4 + q) * 4 + j] = h;
     if (kt < 3) H[((kt + NT) * 4 + q) * 4 + j] = h;
   }
-  // The remainder k-tile (rows 192 .. 207) arrives as four partial chains; 16 lanes of EVERY wavefront fold them ((p0 + p1) + (p2 + p3),
-  // LeakyReLU) into slot 12 of the input buffer -- identical bits from all four wavefronts, and each wavefront reads slot 12 (late in its
-  // walk) after its own write, so no barrier is needed and the k loop has no special case
-  __device__ __forceinline__ void fold_remainder(f32x4 *__restrict__ Hin, const f32x4 *__restrict__ Pin) const {
-    if (lane < 16) {
-      const int q = lane >> 2, j = lane & 3;
-      const f32x4 p0 = Pin[(0 * 4 + q) * 4 + j], p1 = Pin[(1 * 4 + q) * 4 + j], p2 = Pin[(2 * 4 + q) * 4 + j], p3 = Pin[(3 * 4 + q) * 4 + j];
-      f32x4 h;
+  // The steps of this lane's block: step s reads the four float4 {h[16 kt + 4 q + r]}_r of the lane's trajectory from slot (slot0 + s * stride)
+  // and runs the sixteen MFMAs of the k-tile in the canonical order (r-major, q-minor); the ring's fragments of the step are refilled for the
+  // coming layer right behind their last use.  ONE code path for both kinds of wavefront (two instantiations merged the 208-register ring
+  // through a branch and spilled): the remainder wavefront leaves after its four steps (a wave-uniform exit), its slot stride is a run-time value.
+  __device__ __forceinline__ void walk(f32x4 &acc, const f32x4 *__restrict__ Bw, int sstride, int nsteps, unsigned lnext) {
+    f32x4 hn[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) h[r] = lrelu((p0[r] + p1[r]) + (p2[r] + p3[r]));
-      Hin[((NT - 1) * 4 + q) * 4 + j] = h;
+    for (int q = 0; q < 4; ++q) hn[q] = Bw[q * 4];
+#pragma unroll
+    for (int s = 0; s < NT; ++s) {
+      if (s == 4 && nsteps == 4) break;
+      f32x4 hq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) hq[q] = hn[q];
+      if (s + 1 < NT) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) hn[q] = Bw[(s + 1) * sstride + q * 4];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(ring[s][q][r], hq[q][r], acc, 0, 0, 0);
+#ifndef IONODE_T4_NOREFILL   // timing experiment only (wrong results for L > 1): the walk without its weight stream
+        if (r == 3) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) ring[s][q] = frag(lnext, s * 4 + q);
+        }
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
   __device__ __forceinline__ float eval(float x0, float x1) {
     const int j = lane & 3, b = lane >> 2, g = b >> 2, u = b & 3;
     MSTAMP(0);  // slot 0: everything outside the MLP
-    // layer 0: Linear(2, N) + LeakyReLU; the lane fills output block (kt, q) = (4 wave + b / 4, b % 4) of its trajectory
+    // layer 0: Linear(2, N) + LeakyReLU; the lane fills output block (kt, q) = (4 wave + g, u) = kq / 4, kq % 4 of its trajectory
     {
       const int kq = 16 * wave + b;
       if (kq < NP / 4) {
@@ -1089,71 +1112,53 @@ struct MlpTile4 {
     __syncthreads();
     MSTAMP(1);  // slot 1: layer 0 + barrier
     for (int l = 0; l < L; ++l) {
-      f32x4 *__restrict__ Hin = Hs + (l & 1) * ACT;
+      const f32x4 *__restrict__ Hin = Hs + (l & 1) * ACT;
       f32x4 *__restrict__ Hout = Hs + ((l + 1) & 1) * ACT;
-      const f32x4 *__restrict__ Pin = Ps + (l & 1) * 64;
-      f32x4 *__restrict__ Pout = Ps + ((l + 1) & 1) * 64;
       const int ln = (l + 1 < L) ? l + 1 : 0;   // the ring runs cyclically over the hidden stack (see MlpTile)
       const unsigned lnext = sec0 + (unsigned)ln * lbytes;
-      // accumulators: D[i][j] = VGPR i: bias of row i of my block (the remainder chain w > 0 starts at 0: the image says so);
+      // accumulators: D[i][j] = VGPR i: bias of row i of my block (partial chains c > 0 of the remainder rows start at 0: the image says so);
       // read one layer ahead
       f32x4 acc = acc_next;
       if (l + 1 < L) acc_next = B4s[((l + 1) * 4 + wave) * 16 + b];
-      // this wavefront's walk: k-tile (s + wave) mod 13 = slot s + wave; B operands one step ahead of their use
-      const f32x4 *__restrict__ Bw = Hin + (wave * 4) * 4 + j;
-      f32x4 hn[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) hn[q] = Bw[q * 4];
-      MSTAMP(2);  // slot 2: layer prologue (accumulator start, remainder fold, first B reads issued)
-#pragma unroll
-      for (int s = 0; s < NT; ++s) {
-        f32x4 hq[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) hq[q] = hn[q];
-        // the remainder fold rides in the walk: slot 12 is first read at step 9 (wavefront 3), and the dependent MFMA chain leaves most
-        // issue slots free (17 cycles per MFMA, 8 of them issue)
-        if (s == 2 && l > 0) fold_remainder(Hin, Pin);
-        if (s + 1 < NT) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) hn[q] = Bw[((s + 1) * 4 + q) * 4];
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(ring[s][q][r], hq[q][r], acc, 0, 0, 0);
-          if (r == 3) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) ring[s][q] = frag(lnext, s * 4 + q);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      MSTAMP(3);  // slot 3: the 13 x 16 MFMA walk
-      if (g < 3) {
+      MSTAMP(2);  // slot 2: layer prologue
+      // full rows (wavefronts 0..2): block group g walks k-tile (s + g) mod 13 = slot s + g, 13 steps; remainder rows (wavefront 3): block
+      // group c = g runs partial chain c over the k-tiles c, c + 4, c + 8 (, 12: chain 0 only -- the others' step 3 reads the duplicate slots
+      // 13..15 against -0.0f weights): 4 steps, 4 slots apart
+      walk(acc, Hin + (g * 4) * 4 + j, (wave < 3) ? 16 : 64, (wave < 3) ? NT : 4, lnext);
+      MSTAMP(3);  // slot 3: the MFMA walk
+      if (wave < 3) {
         f32x4 h;
 #pragma unroll
         for (int r = 0; r < 4; ++r) h[r] = lrelu(acc[r]);
-        put_h(Hout, wave + 4 * g, u, j, h);
+        put_h(Hout, 4 * wave + g, u, j, h);
       } else {
-        Pout[(wave * 4 + u) * 4 + j] = acc;   // partial chain `wave` of the remainder tile, pre-activation
+        // the four chains of a row meet across the lane groups: (p0 + p1) + (p2 + p3)
+        f32x4 h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pair = acc[r] + __shfl_xor(acc[r], 16);
+          h[r] = lrelu(pair + __shfl_xor(pair, 32));
+        }
+        if (lane < 16) put_h(Hout, NT - 1, u, j, h);
       }
       __syncthreads();
       MSTAMP(4);  // slot 4: LeakyReLU + store + layer barrier
     }
     // Linear(N, 1): chain q = b & 3 per lane (k = 16 kt + 4 q + r, kt ascending, r ascending), folded ((p0 + p1) + (p2 + p3)) + bl
-    f32x4 *__restrict__ Hin = Hs + (L & 1) * ACT;
+    const f32x4 *__restrict__ Hin = Hs + (L & 1) * ACT;
     const int q = b & 3;
-    // all thirteen activation reads in flight at once (the remainder tile's after its fold): one LDS round trip instead of thirteen
-    f32x4 hl[NT];
+    // all thirteen activation reads in flight at once: one LDS round trip instead of thirteen
+    f32x4 hl[NT], wv[NT];
 #pragma unroll
-    for (int kt = 0; kt < NT - 1; ++kt) hl[kt] = Hin[(kt * 4 + q) * 4 + j];
-    if (L > 0) fold_remainder(Hin, Ps + (L & 1) * 64);
-    hl[NT - 1] = Hin[((NT - 1) * 4 + q) * 4 + j];
+    for (int kt = 0; kt < NT; ++kt) {
+      hl[kt] = Hin[(kt * 4 + q) * 4 + j];
+      wv[kt] = *reinterpret_cast<const f32x4 *>(wlS + 16 * kt + 4 * q);
+    }
     float part = 0.0f;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) part = fmaf(wlr[kt][r], hl[kt][r], part);
+      for (int r = 0; r < 4; ++r) part = fmaf(wv[kt][r], hl[kt][r], part);
     }
     const float pair = part + __shfl_xor(part, 4);    // (p0 + p1) or (p2 + p3): lanes 4 apart hold neighbouring chains
     const float out = (pair + __shfl_xor(pair, 8)) + wlS[NP];

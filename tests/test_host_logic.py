@@ -116,21 +116,31 @@ def test_weight_pack_is_a_permutation_with_zero_padding(ion, L, N):
             bias = r1[l, (3 * 13 * 4 + 16) * 256:].reshape(4, 64)
             assert np.array_equal(np.sort(bias[bias != 0]), np.sort(bl))    # every row's bias exactly once (remainder rows: chain 0 only)
             assert int((np.signbit(rem) & (rem == 0)).sum()) == 3 * 16 * 4 * 4   # step 3 of the chains 1..3: lanes x r x q
-        # ... in front of it the section of the 4-trajectory tile (MlpTile4): per layer 4 waves x 13 steps x 4 q x 64 lanes x 4
-        # fragments (every hidden weight once more; -0.0 where the remainder block idles) + 4 x 64 bias float4s
-        lay = 4 * 13 * 4 * 256 + 4 * 256
+        # ... in front of it the section of the 4-trajectory tile (MlpTile4), round-5 lane layout: per layer three full-row wavefronts x 13 steps
+        # x 4 q x 64 lanes x float4 over r, the remainder wavefront's 4 steps x 4 q x 64 lanes (every hidden weight exactly once more; -0.0 where
+        # a partial chain has no fourth k-tile) + 4 x 64 accumulator-start float4s
+        lay = (3 * 13 * 4 + 16) * 256 + 4 * 256
         t4 = img[-L * lay:].reshape(L, lay)
         img = img[:-L * lay]
         off = 2 * N + N
         for l in range(L):
-            fr = t4[l, :4 * 13 * 4 * 256]
-            Wl = w[off:off + N * N]; bl = w[off + N * N:off + N * N + N]; off += N * N + N
-            nzf = fr[fr != 0]
-            assert nzf.size == N * N and np.array_equal(np.sort(nzf), np.sort(Wl))
-            bias = t4[l, 4 * 13 * 4 * 256:]
+            full = t4[l, :3 * 13 * 4 * 256].reshape(3, 13, 4, 64, 4)
+            rem = t4[l, 3 * 13 * 4 * 256:(3 * 13 * 4 + 16) * 256].reshape(4, 4, 64, 4)
+            Wl = w[off:off + N * N].reshape(N, N); bl = w[off + N * N:off + N * N + N]; off += N * N + N
+            nzf = np.concatenate([full[full != 0], rem[rem != 0]])
+            assert nzf.size == N * N and np.array_equal(np.sort(nzf), np.sort(Wl.reshape(-1)))
+            for (wv, st, q, lane, r) in ((0, 0, 0, 0, 0), (2, 5, 2, 47, 3), (1, 12, 3, 17, 1), (0, 7, 1, 63, 2)):
+                i, bb = lane & 3, lane >> 2
+                row, k = 16 * (4 * wv + (bb >> 2)) + 4 * (bb & 3) + i, 16 * ((st + (bb >> 2)) % 13) + 4 * q + r
+                assert full[wv, st, q, lane, r] == (Wl[row, k] if (row < N and k < N) else 0.0)
+            for (jj, q, lane, r) in ((0, 0, 0, 0), (2, 3, 21, 1), (3, 1, 5, 0), (3, 2, 40, 1), (1, 0, 63, 3)):
+                i, bb = lane & 3, lane >> 2
+                row, kt = 192 + 4 * (bb & 3) + i, (bb >> 2) + 4 * jj
+                k = 16 * kt + 4 * q + r
+                assert rem[jj, q, lane, r] == (Wl[row, k] if (kt < 13 and row < N and k < N) else 0.0)
+            bias = t4[l, (3 * 13 * 4 + 16) * 256:]
             assert np.array_equal(np.sort(bias[bias != 0]), np.sort(np.repeat(bl, 4)))   # every lane of a block (4 trajectories) carries its rows' biases
-            idle = sum(1 for wv in range(4) for st in range(13) if not (st % 4 == 0 and st + wv < 13))
-            assert int((np.signbit(fr) & (fr == 0)).sum()) == idle * 4 * 16 * 4   # idle steps x q x the 16 lanes of block group 3 x r
+            assert int((np.signbit(rem) & (rem == 0)).sum()) == 3 * 16 * 4 * 4          # step 3 of the chains 1..3: lanes x q x r
     nz = img[img != 0]
     assert nz.size == n and np.array_equal(np.sort(nz), np.sort(w))
     with pytest.raises(ion.capi.IonodeError):
