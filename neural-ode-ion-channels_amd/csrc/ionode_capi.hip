@@ -327,15 +327,19 @@ int ionode_mlp_pack(const float *w, int32_t L, int32_t N, float *out) {
         for (int lane = 0; lane < 64; ++lane) {
           const int m = lane & 15, q = lane >> 4;
           float *f0 = dst + (((size_t)wv * FR + pos) * 64 + lane) * 4;
+          // the asm tile's short form of the half-padded k-tile 12 (N <= 200, ionode_device.hpp IONODE_KT12_SHORT): MFMA r = 0 takes
+          // k = 192, 196, 193, 197 from the lane groups q = 0..3, MFMA r = 1 takes 194, 198, 195, 199; r = 2, 3 are not executed
+          const bool short12 = IONODE_KT12_SHORT && NT == 13 && G == 4 && N <= 200 && kt == 12;
+          auto kof = [&](int r) { return short12 ? (r < 2 ? 192 + 4 * (q & 1) + (q >> 1) + 2 * r : N) : 16 * kt + 4 * q + r; };
           for (int e = 0; e < 4 * F; ++e) {
             const int r = e / F, i = e % F, rt = wv + i * G;
-            const int row = 16 * rt + m, k = 16 * kt + 4 * q + r;
+            const int row = 16 * rt + m, k = kof(r);
             f0[(size_t)(e / 4) * 256 + e % 4] = (row < N && k < N) ? W[(size_t)row * N + k] : 0.0f;
           }
           if (Rm > 0 && st % G == 0)
             for (int j = 0; j < Rm; ++j)
               for (int r = 0; r < 4; ++r) {
-                const int row = 16 * (G * F + j) + m, k = 16 * kt + 4 * q + r;
+                const int row = 16 * (G * F + j) + m, k = kof(r);
                 f0[(size_t)(F + j) * 256 + r] = (st + wv < NT && row < N && k < N) ? W[(size_t)row * N + k] : 0.0f;
               }
         }

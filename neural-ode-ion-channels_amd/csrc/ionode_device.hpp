@@ -474,6 +474,16 @@ __device__ __forceinline__ float lrelu(float x) {
 // hidden stack as ONE inline-asm statement with a fixed register map (weight ring in AGPRs a[0:171], working set in
 // v[184:255]) and a software-pipelined layer boundary; same canonical accumulation order, same bits.  -DIONODE_NO_ASM_CORE
 // builds the compiler-scheduled stream instead (A/B, stamps).
+// Round 5: N = 200 pads its contraction index to 208; k-tile 12 holds eight real k and eight padding columns -- two of the four k of each of
+// its MFMAs.  Without the padding terms (exact no-ops) the canonical chain through the tile is 192, 196, 193, 197 | 194, 198, 195, 199: the asm
+// stream runs it as TWO MFMAs per accumulator (tools/gen_mlp_asm.py "short form"), and ionode_mlp_pack lays the tile's A fragments out for it.
+#ifndef IONODE_KT12_SHORT
+#if defined(IONODE_NO_ASM_CORE)
+#define IONODE_KT12_SHORT 0
+#else
+#define IONODE_KT12_SHORT 1
+#endif
+#endif
 #if !defined(IONODE_NO_ASM_CORE)
 #define IONODE_ASM_CORE 1
 #include "mlp_asm_nt13.inc"
@@ -537,6 +547,7 @@ struct MlpTile {
   unsigned lbytes;    // bytes per hidden layer in the image
   unsigned lds0;      // LDS byte address of the tile's region (asm stream)
   int bl_bits;        // bias of Linear(N, 1), wave-uniform (asm stream)
+  int sw12;           // asm stream: the wavefront's index when k-tile 12 may take its two-MFMA form (N <= 200: k >= 200 is padding), else 99
   int L, wave, lane;
 #ifdef IONODE_STAMPS
   Stamps *sp;
@@ -595,6 +606,7 @@ struct MlpTile {
 #endif
       __syncthreads();
       bl_bits = __builtin_amdgcn_readfirstlane(__float_as_int(wlS[NP]));
+      sw12 = (IONODE_KT12_SHORT && a.N <= 200) ? wave : 99;
       return;
     }
     // prime the ring with the first PD steps of hidden layer 0
@@ -748,7 +760,7 @@ struct MlpTile {
                        : [hw_in] "v"(hw0), [hw_out] "v"(hw1), [fw_in] "v"(fw0), [fw_out] "v"(fw1), [pl_in] "v"(pl0), [pl_out] "v"(pl1),
                          [pw_in] "v"(pw0), [pw_out] "v"(pw1), [bias_a] "v"(bias_a), [bias_r] "v"(bias_r), [voff] "v"(voff),
                          [dummy] "v"(dummy), [w0a] "v"(w0a), [w0r] "v"(w0r), [wla] "v"(wla), [x0] "v"(x0), [x1] "v"(x1),
-                         [rsrc] "s"(rsrc), [nl] "s"(nl), [lbytes] "s"(lbytes), [hid0] "s"(hid0), [wave] "s"(wave), [bl] "s"(bl_bits)
+                         [rsrc] "s"(rsrc), [nl] "s"(nl), [lbytes] "s"(lbytes), [hid0] "s"(hid0), [wave] "s"(wave), [bl] "s"(bl_bits), [sw] "s"(sw12)
                        : "memory", "scc", "vcc", IONODE_MLPASM_CLOBBER_V_13, IONODE_MLPASM_CLOBBER_A_13, IONODE_MLPASM_CLOBBER_S_13);
         } else {
           // two column sets: this wavefront's stage inputs belong to set `wave / 2`; the stream exchanges them through LDS
@@ -763,7 +775,7 @@ struct MlpTile {
                          [pw_in] "v"(pw0), [pw_out] "v"(pw1), [bias_a] "v"(bias_a), [bias_r] "v"(bias_r), [voff] "v"(voff),
                          [dummy] "v"(dummy), [w0a] "v"(w0a), [w0r] "v"(w0r), [wla] "v"(wla), [x0] "v"(x0), [x1] "v"(x1),
                          [xchw] "v"(xchw), [xchr] "v"(xch),
-                         [rsrc] "s"(rsrc), [nl] "s"(nl), [lbytes] "s"(lbytes), [hid0] "s"(hid0), [wave] "s"(wave), [bl] "s"(bl_bits),
+                         [rsrc] "s"(rsrc), [nl] "s"(nl), [lbytes] "s"(lbytes), [hid0] "s"(hid0), [wave] "s"(wave), [bl] "s"(bl_bits), [sw] "s"(sw12),
                          [own_h] "s"(own_h), [own_p] "s"(own_p)
                        : "memory", "scc", "vcc", IONODE_MLPASM_CLOBBER_V_13x2, IONODE_MLPASM_CLOBBER_A_13x2, IONODE_MLPASM_CLOBBER_S_13x2);
         }

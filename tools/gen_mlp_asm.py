@@ -44,7 +44,8 @@ G = 4  # wavefronts per tile
 
 
 class Gen:
-    def __init__(self, nt, pd=7, ns=1, sb=84, stamps=False):
+    def __init__(self, nt, pd=7, ns=1, sb=84, stamps=False, short12=True):
+        self.short12 = short12   # k-tile 12 in two MFMAs per accumulator (N <= 200: run-time switch %[sw])
         self.NT = nt
         self.NS = ns
         self.F = nt // G
@@ -69,10 +70,13 @@ class Gen:
         self.HO = [alloc(4) for _ in range(ns)]                             # own tile of the coming layer (B operand of step 0)
         self.X, self.Y = alloc(4), alloc(4)
         names = ["HW_IN", "HW_OUT", "FW_IN", "FW_OUT", "PL_IN", "PL_OUT", "PW_IN", "PW_OUT",
-                 "BIAS_A", "BIAS_R", "VOFF", "DUMMY", "W0A", "W0R", "WLA", "PART", "TMPA", "XCHW", "XCHR"]
+                 "BIAS_A", "BIAS_R", "VOFF", "DUMMY", "W0A", "W0R", "WLA", "PART", "TMPA", "XCHW", "XCHR", "QOFF"]
         for cs in range(ns):
-            names += ["DUP%d" % cs, "LO_TILE%d" % cs, "LO_PART%d" % cs, "FOLDW%d" % cs]
+            names += ["DUP%d" % cs, "LO_TILE%d" % cs, "LO_PART%d" % cs, "FOLDW%d" % cs, "HWS12_%d" % cs]
         self.A = {n: alloc(1) for n in names}
+        if sum(regs) % 2:
+            alloc(1)                                      # (register pairs are 64-bit aligned: VB is a multiple of 4, so parity here is parity there)
+        self.BX = [alloc(2) for _ in range(ns)]          # short form of k-tile 12: its two B operands per column set
         self.STAMPV = alloc(1)
         self.n_vgpr = (sum(regs) + 3) // 4 * 4
         self.VB = 256 - self.n_vgpr
@@ -81,6 +85,7 @@ class Gen:
         self.T = [fix(a) for a in self.T]
         self.B = [[fix(a) for a in row] for row in self.B]
         self.HO = [fix(a) for a in self.HO]
+        self.BX = [fix(a) for a in self.BX]
         self.X, self.Y, self.STAMPV = fix(self.X), fix(self.Y), fix(self.STAMPV)
         self.A = {k: fix(v) for k, v in self.A.items()}
         # --- fixed SGPR map ---
@@ -96,12 +101,17 @@ class Gen:
         self.S_W3 = (s(8), s(9))    # all-ones iff wave < 3
         self.S_C01 = s(10)    # 0.01f
         self.S_LCUR = s(11)   # byte offset of the current layer
-        self.n_sgpr = 12
+        # round 5, the short form of k-tile 12 (see layer()): lanes of the groups q >= 2, the wavefront that owns the short form (or 99), a scratch
+        self.S_QHI = (s(12), s(13))
+        self.S_SW = s(14)
+        self.S_X = s(15)
+        self.n_sgpr = 16
         self.stamps = stamps   # diagnostic build: s_memtime deltas summed per position in the lanes of AGPR a[ring_regs]
         if stamps:
-            self.S_NOW, self.S_LAST, self.S_DT = (s(12), s(13)), s(14), s(15)
-            self.n_sgpr = 16
+            self.S_NOW, self.S_LAST, self.S_DT = (s(16), s(17)), s(18), s(19)
+            self.n_sgpr = 20
         self.lines = []
+        self.ool = []
         self.reset_counters()
 
     # ---------------- in-order queue simulation ----------------
@@ -283,6 +293,16 @@ class Gen:
             if 1 <= u and u + 1 < NT:
                 for cs in range(NS):
                     self.ds_read(self.B[(u + 1) & 1][cs], "HW_IN", cs * self.HSET + (u + 1) * 1024, tag="B%d_%d" % (u + 1, cs))
+            if self.short12 and u == NT - 5:
+                # the two B operands of the short form of k-tile 12 (every wavefront meets that tile once, on one of the four steps that follow):
+                # lane group q wants h[192 + 4 (q & 1) + (q >> 1)] and the value two further: the dwords at +0 and +8 of its own position in slot
+                # 12 stepped back by (q >> 1) * 508 bytes (group q & 1's float4, component q >> 1).  The slot is final: the fold wrote it at step 1.
+                for cs in range(NS):
+                    self.emit("v_sub_u32_e32 v%d, v%d, v%d" % (A["HWS12_%d" % cs], A["FW_IN"], A["QOFF"]))
+                    if cs:
+                        self.emit("v_add_u32_e32 v%d, %d, v%d" % (A["HWS12_%d" % cs], cs * self.HSET, A["HWS12_%d" % cs]))
+                    self.emit("ds_read2_b32 v[%d:%d], v%d offset1:2" % (self.BX[cs], self.BX[cs] + 1, A["HWS12_%d" % cs]))
+                    self.ds_issue("BX%d" % cs)
 
             # ---- side work of this step ----
             if u == 0:
@@ -347,7 +367,61 @@ class Gen:
             if u >= 1:
                 for cs in range(NS):
                     self.wait_ds(self.tag_id["B%d_%d" % (u, cs)])
-            if u == NT - 1:
+            if self.short12 and NT - 4 <= u < NT - 1:
+                # ---- the short form of k-tile 12 (round 5).  N = 200 pads its contraction index to 208: k-tile 12 holds k = 192 .. 199 and eight
+                # padding columns, two of the four k of every MFMA.  The canonical order inside a k-tile is r-major, q-minor -- 192, 196, (200), (204),
+                # 193, 197, ... -- so without the padding terms (exact no-ops) the chain is 192, 196, 193, 197 | 194, 198, 195, 199: TWO MFMAs whose
+                # lane groups q = 0..3 supply those k (ionode_mlp_pack lays the tile's A fragments out that way; the B operands were read into BX
+                # at step NT - 5).  The wavefront that meets k-tile 12 at this step (wave == NT - 1 - u) runs the MFMAs with r < 2 only: 6 of
+                # its 169 MFMAs per layer less.  Two bodies issuing the same memory operations; the short one OUT OF LINE (a taken branch costs
+                # ~40 cycles: the three wavefronts on the ordinary path fall through).
+                lbl = "%=" + "_s%d" % u
+                self.emit("s_cmp_eq_u32 s%d, %d" % (self.S_SW, NT - 1 - u))
+                self.emit("s_cbranch_scc1 .Lshort_" + lbl)
+                st = (self.ds_seq, self.ds_done, self.vm_seq, self.vm_done, dict(self.ring_id), dict(self.tag_id))
+                self.emit_ops(u, ops, 0, side)
+                self.emit(".Ljoin_" + lbl + ":")
+                end0 = (self.ds_seq, self.ds_done, self.vm_seq, self.vm_done)
+                main, self.lines = self.lines, []
+                self.emit(".Lshort_" + lbl + ":")
+                (self.ds_seq, self.ds_done, self.vm_seq, self.vm_done, self.ring_id, self.tag_id) = st
+                self.short_b(u)
+                self.emit_ops(u, [o for o in ops if o[3] < 2], 0, side, renumber=ops, bx=True)
+                self.emit("s_branch .Ljoin_" + lbl)
+                self.ool += self.lines
+                self.lines = main
+                assert (end0[0], end0[2]) == (self.ds_seq, self.vm_seq), "both bodies must issue the same memory operations"
+                self.ds_done, self.vm_done = min(self.ds_done, end0[1]), min(self.vm_done, end0[3])
+            elif u == NT - 1 and self.short12:
+                # the last step: wave 0 owns the K-slice of the remainder tile AND meets k-tile 12 here: its bodies (the short form of everything,
+                # or the full step when the short form is off) are out of line; the other wavefronts fall through the step without the
+                # wave-0-only MFMAs
+                lbl = "%="
+                self.emit("s_cmp_eq_u64 s[%d:%d], 0" % self.S_W0)
+                self.emit("s_cbranch_scc0 .Lw0_" + lbl)
+                st = (self.ds_seq, self.ds_done, self.vm_seq, self.vm_done, dict(self.ring_id), dict(self.tag_id))
+                self.emit_ops(u, [o for o in ops if not o[4]], 0, side, renumber=ops)
+                self.emit(".Ljoin_" + lbl + ":")
+                end0 = (self.ds_seq, self.ds_done, self.vm_seq, self.vm_done)
+                main, self.lines = self.lines, []
+                self.emit(".Lw0_" + lbl + ":")
+                (self.ds_seq, self.ds_done, self.vm_seq, self.vm_done, self.ring_id, self.tag_id) = (st[0], st[1], st[2], st[3], dict(st[4]), dict(st[5]))
+                self.emit("s_cmp_eq_u32 s%d, 0" % self.S_SW)
+                self.emit("s_cbranch_scc0 .Lw0full_" + lbl)
+                self.short_b(u)
+                self.emit_ops(u, [o for o in ops if o[3] < 2], 0, side, renumber=ops, bx=True)
+                self.emit("s_branch .Ljoin_" + lbl)
+                end_s = (self.ds_seq, self.ds_done, self.vm_seq, self.vm_done)
+                self.emit(".Lw0full_" + lbl + ":")
+                (self.ds_seq, self.ds_done, self.vm_seq, self.vm_done, self.ring_id, self.tag_id) = st
+                self.emit_ops(u, ops, 0, side)
+                self.emit("s_branch .Ljoin_" + lbl)
+                end_f = (self.ds_seq, self.ds_done, self.vm_seq, self.vm_done)
+                self.ool += self.lines
+                self.lines = main
+                assert (end0[0], end0[2]) == (end_s[0], end_s[2]) == (end_f[0], end_f[2]), "all bodies must issue the same memory operations"
+                self.ds_done, self.vm_done = min(end0[1], end_s[1], end_f[1]), min(end0[3], end_s[3], end_f[3])  # what all guarantee
+            elif u == NT - 1:
                 # the second half of the last step differs between wave 0 (K-slice owner) and the others: two bodies
                 self.emit_ops(u, ops[:half], 0, side)
                 tail = ops[half:]
@@ -368,7 +442,12 @@ class Gen:
                 self.emit_ops(u, ops, 0, side)
             self.stamp(u)
 
-    def emit_ops(self, u, ops, pos0, side, renumber=None):
+    def short_b(self, u):
+        """short form of k-tile 12: its B operands were read into BX at step NT - 5 (LDS results: no wait states before an MFMA reads them)"""
+        for cs in range(self.NS):
+            self.wait_ds(self.tag_id["BX%d" % cs])
+
+    def emit_ops(self, u, ops, pos0, side, renumber=None, bx=False):
         """MFMAs of a step from position pos0 on, each followed by its side work.  `renumber`: the full op list whose
         positions the side table refers to (body without the wave-0-only MFMAs: side work of a skipped position is issued
         behind the previous emitted MFMA)."""
@@ -384,7 +463,7 @@ class Gen:
                 if u == 0 and r == 0:
                     c = self.T[ai]
                     self.wait_ds(self.tag_id["T%d" % ai])
-                bsrc = self.HO[cs] if u == 0 else self.B[u & 1][cs]
+                bsrc = self.BX[cs] if bx else (self.HO[cs] if u == 0 else self.B[u & 1][cs])
                 self.mfma(self.ACC[cs][ai], self.areg(u, e), bsrc + r, c)
             for fn in side.get(pos, []):
                 fn()
@@ -411,6 +490,13 @@ class Gen:
         e("s_cselect_b64 s[%d:%d], -1, 0" % self.S_W0)
         e("s_cmp_lt_u32 %[wave], 3")
         e("s_cselect_b64 s[%d:%d], -1, 0" % self.S_W3)
+        # short form of k-tile 12: %[sw] = the wavefront's index when the net's width allows it (N <= 200), else 99 (no step ever matches)
+        e("s_mov_b32 s%d, %%[sw]" % self.S_SW)
+        e("s_mov_b32 s%d, 0" % self.S_QHI[0])
+        e("s_mov_b32 s%d, -1" % self.S_QHI[1])
+        e("v_mov_b32_e32 v%d, 0" % A["QOFF"])
+        e("v_mov_b32_e32 v%d, 508" % A["HWS12_0"])
+        e("v_cndmask_b32_e64 v%d, v%d, v%d, s[%d:%d]" % (A["QOFF"], A["QOFF"], A["HWS12_0"], self.S_QHI[0], self.S_QHI[1]))
         self.reset_counters()
         # ---- the stage inputs of every column set.  NS == 1: the statement's own operands.  NS > 1: each wavefront holds the inputs of
         # ITS set (lane 16 q + j: trajectory j); they are exchanged through LDS [set][16] x {x0, x1} behind one barrier.
@@ -502,6 +588,7 @@ class Gen:
         body = None
         for it in range(3):
             start = len(self.lines)
+            self.ool = []
             if it == 0:
                 for (u, k) in self.refill_order():   # ring as primed by init / left by the previous pass
                     where, ut = self.refill_target(u, k)
@@ -513,13 +600,15 @@ class Gen:
                 self.ds_done = self.ds_seq
             self.layer()
             self.bookkeeping()
-            text = self.lines[start:]
+            text = self.lines[start:] + ["// out of line:"] + self.ool
             del self.lines[start:]
             if it >= 1:
                 if body is not None:
                     assert body == text, "wait counts did not reach a fixed point"
                 body = text
-        self.lines += body
+        k_ool = body.index("// out of line:")
+        ool_text = body[k_ool + 1:]
+        self.lines += body[:k_ool]
         # ---- loop control ----
         e("s_add_u32 s%d, s%d, 1" % (self.S_L, self.S_L))
         e("s_cmp_lt_u32 s%d, s%d" % (self.S_L, self.S_NL))
@@ -602,6 +691,11 @@ class Gen:
         e("s_cbranch_scc1 .Lodd_" + lbl)
         e("s_barrier")
         e(".Lodd_" + lbl + ":")
+        if ool_text:
+            # the out-of-line bodies of the layer pass (short form of k-tile 12, wave 0's last step): jumped over once per evaluation
+            e("s_branch .Lend_" + lbl)
+            self.lines += ool_text
+            e(".Lend_" + lbl + ":")
         return self.lines
 
     def bookkeeping(self):
@@ -664,11 +758,13 @@ def main():
     ap.add_argument("--pd", type=int, default=7)
     ap.add_argument("--ns", type=int, default=1, help="16-trajectory column sets per tile (1 or 2)")
     ap.add_argument("--stamps", action="store_true")
+    ap.add_argument("--no-short12", action="store_true", help="A/B: without the two-MFMA form of the half-padded k-tile 12")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
-    g = Gen(a.nt, a.pd, a.ns, stamps=a.stamps)
+    sb = 80 if a.stamps else 84   # (the diagnostic build needs four more scalar registers)
+    g = Gen(a.nt, a.pd, a.ns, sb=sb, stamps=a.stamps, short12=not a.no_short12)
     layers = list(g.gen_layers())
-    init = list(Gen(a.nt, a.pd, a.ns, stamps=a.stamps).gen_init())
+    init = list(Gen(a.nt, a.pd, a.ns, sb=sb, stamps=a.stamps, short12=not a.no_short12).gen_init())
     nmf = sum(1 for l in layers if l.startswith("v_mfma"))
     sfx = "%d" % a.nt + ("x%d" % a.ns if a.ns > 1 else "")
     with open(a.out, "w") as f:
