@@ -75,8 +75,8 @@ typedef struct ionode_desc {
   double obs_e;
   int32_t obs_open_state_only; /* 1: gate = last state (6-state O, train-d1.py:299) */
   int32_t tile_waves;  /* tuning, 0 = auto.  MLP models: wavefronts cooperating on one 16-trajectory tile (1, 4); N <= 16 nets
-                          also 64 = one trajectory per lane, 64 per wavefront (auto from ionode_lane_wise_from() trajectories); N = 200 also 8 / 2 = 32 / 4
-                          trajectories per tile.  Closed-form models: trajectories per wavefront (64 or 16; auto = 16 below ionode_lane_wise_from()) */
+                          also 64 = one trajectory per lane, 64 per wavefront (auto from ionode_lane_wise_from() trajectories); N = 200 also 8 / 2 / 16 = 32 / 4 / 1
+                          trajectories per tile (auto: 1 up to 256 trajectories, 4 up to 1024, 16 up to 8191, 32 beyond).  Closed-form models: trajectories per wavefront (64 or 16; auto = 16 below ionode_lane_wise_from()) */
   double *step_log;    /* optional DEVICE buffer [step_log_cap][4] fp64: (t0, dt, error ratio, accepted) of every
                           step attempt of trajectory 0 -- the per-step trace parity tests compare; NULL = off */
   int64_t step_log_cap;
