@@ -13,6 +13,8 @@ the flat state dict, refresh of the MFMA fragment image.  No host synchronisatio
 import ctypes as C
 import math
 
+import os
+
 import numpy as np
 import torch
 
@@ -63,10 +65,9 @@ class MlpRegression:
         cus = torch.cuda.get_device_properties(dev).multi_processor_count
         # persistent grid: TWO workgroups per compute unit for N <= 200 (256 registers and 70 KB of LDS each: one tile's layer boundaries
         # run beside the other's MFMAs), one for N = 500.  IONODE_REGRESS_WG_PER_CU: dev override for A/B runs
-        import os
         per_cu = int(os.environ.get("IONODE_REGRESS_WG_PER_CU", "2" if N <= 208 else "1"))
         self.n_wg = int(min(self.tiles, cus * per_cu))
-        self.n_slabs = int(max(1, min(cus // (L + 2), self.tiles // 4)))
+        self.n_slabs = int(os.environ.get("IONODE_REGRESS_SLABS", 0)) or int(max(1, min(cus // (L + 2), self.tiles // 4)))   # (env: dev override for A/B runs)
         self.loss_part = torch.zeros(self.n_wg, dtype=torch.float64, device=dev)
         self.partials = torch.empty((self.n_slabs, partf), dtype=torch.float32, device=dev)
         self.grad = torch.zeros_like(self.w)
