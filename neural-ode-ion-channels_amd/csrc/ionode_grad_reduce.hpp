@@ -44,74 +44,97 @@ __global__ void __launch_bounds__(256) ionode_grad_reduce_kernel(const float *__
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int NJOB = L * NCB + 2;                   // job 0 | heavy jobs (layer, column block) | job NJOB - 1
+  const int NJOB = L * NCB + 1;                   // job 0 (both light jobs) | heavy jobs (layer, column block)
   const int jobx = blockIdx.x % NJOB;
   const int slab = blockIdx.x / NJOB;
-  const int job = (jobx == 0) ? 0 : ((jobx == NJOB - 1) ? L + 1 : 1 + (jobx - 1) / NCB);   // 0 | layer 1..L | L + 1
-  const int cb0 = (jobx == 0 || jobx == NJOB - 1) ? 0 : ((jobx - 1) % NCB) * CB;           // first column tile of the block
+  const int job = (jobx == 0) ? 0 : 1 + (jobx - 1) / NCB;   // 0 | layer 1..L
+  const int cb0 = (jobx == 0) ? 0 : ((jobx - 1) % NCB) * CB;   // first column tile of the block
   const int64_t r0 = n_records * slab / n_slabs, r1 = n_records * (slab + 1) / n_slabs;
   const int64_t RECF = grad_record_floats(L, NT);
   float *__restrict__ out = partials + (size_t)slab * grad_partial_floats(L, NT);
   const int m = lane & 15, kk = lane >> 4;
 
-  if (job == 0 || job == L + 1) {
-    // ---- light jobs: one d (or h) tile set per record against per-trajectory scalars, VALU, straight from global ----
-    const bool first = job == 0;
-    float a0[RC], a1[RC], a2[RC];
+  if (job == 0) {
+    // ---- the two light jobs (round 5: ONE workgroup runs both, four records in flight): one d (or h) tile set per record against
+    // per-trajectory scalars, VALU, straight from global.  (Round 4: a workgroup per light job, one record at a time: a dependent load
+    // chain of ~2 us per record -- as long as a heavy job; with both in one pipelined workgroup a slab costs L + 1 workgroups instead of
+    // L + 2, i.e. 42 slabs instead of 36 in one round of workgroups for N = 200, L = 5.)  Summation order per slab: record order, as before.
+    constexpr int NB = 4;
+    for (int lj = 0; lj < 2; ++lj) {
+      const bool first = lj == 0;
+      float a0[RC], a1[RC], a2[RC];
 #pragma unroll
-    for (int i = 0; i < RC; ++i) a0[i] = a1[i] = a2[i] = 0.0f;
-    float sg = 0.0f;
-    for (int64_t rr = r0; rr < r1; ++rr) {
-      const float *rec = records + rr * RECF;
-      const f32x4 *tiles = reinterpret_cast<const f32x4 *>(rec) + (size_t)(first ? (L + 1) * NT : L * NT) * 64;  // D_0 | H_L
-      const float *sc = rec + (size_t)2 * (L + 1) * NT * 256;
-      float s0[4], s1[4];
+      for (int i = 0; i < RC; ++i) a0[i] = a1[i] = a2[i] = 0.0f;
+      float sg = 0.0f;
+      for (int64_t rb = r0; rb < r1; rb += NB) {
+        f32x4 t[NB][RC];
+        float s0[NB][4], s1[NB][4], sd[NB][4], sgl[NB];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        s0[c] = first ? sc[4 * c + kk] : sc[32 + 4 * c + kk];  // x0 | seed
-        s1[c] = first ? sc[16 + 4 * c + kk] : 0.0f;            // x1
+        for (int u = 0; u < NB; ++u) {
+          const int64_t rr = (rb + u < r1) ? rb + u : r1 - 1;   // (past the end: a valid record, its contribution is skipped below)
+          const float *rec = records + rr * RECF;
+          const f32x4 *tiles = reinterpret_cast<const f32x4 *>(rec) + (size_t)(first ? (L + 1) * NT : L * NT) * 64;  // D_0 | H_L
+          const float *sc = rec + (size_t)2 * (L + 1) * NT * 256;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            s0[u][c] = first ? sc[4 * c + kk] : sc[32 + 4 * c + kk];  // x0 | seed
+            s1[u][c] = first ? sc[16 + 4 * c + kk] : 0.0f;            // x1
+            sd[u][c] = sc[32 + 4 * c + kk];
+          }
+          sgl[u] = (lane < 16) ? sc[32 + lane] : 0.0f;
+#pragma unroll
+          for (int i = 0; i < RC; ++i) {
+            const int rt = wave + 4 * i;
+            t[u][i] = (rt < NT) ? tiles[rt * 64 + lane] : f32x4{0, 0, 0, 0};
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          if (rb + u < r1) {
+            if (!first && wave == 0 && lane < 16) sg += sgl[u];
+#pragma unroll
+            for (int i = 0; i < RC; ++i) {
+              const int rt = wave + 4 * i;
+              if (rt < NT) {
+                f32x4 tt = t[u][i];
+                if (first && unit_seed) {
+#pragma unroll
+                  for (int c = 0; c < 4; ++c) tt[c] *= sd[u][c];   // D_0 of a unit-seed record
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                  a0[i] += first ? tt[c] : tt[c] * s0[u][c];
+                  if (first) { a1[i] = fmaf(tt[c], s0[u][c], a1[i]); a2[i] = fmaf(tt[c], s1[u][c], a2[i]); }
+                }
+              }
+            }
+          }
+        }
       }
-      if (!first && wave == 0 && lane < 16) sg += sc[32 + lane];
 #pragma unroll
       for (int i = 0; i < RC; ++i) {
         const int rt = wave + 4 * i;
-        if (rt < NT) {
-          f32x4 t = tiles[rt * 64 + lane];
-          if (first && unit_seed) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) t[c] *= sc[32 + 4 * c + kk];   // D_0 of a unit-seed record
-          }
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            a0[i] += first ? t[c] : t[c] * s0[c];
-            if (first) { a1[i] = fmaf(t[c], s0[c], a1[i]); a2[i] = fmaf(t[c], s1[c], a2[i]); }
+        float v0 = a0[i], v1 = a1[i], v2 = a2[i];
+        v0 += __shfl_xor(v0, 16); v0 += __shfl_xor(v0, 32);
+        v1 += __shfl_xor(v1, 16); v1 += __shfl_xor(v1, 32);
+        v2 += __shfl_xor(v2, 16); v2 += __shfl_xor(v2, 32);
+        if (rt < NT && lane < 16) {
+          if (first) {
+            float *o = out + (size_t)(16 * rt + m) * 4;
+            o[0] = v0; o[1] = v1; o[2] = v2; o[3] = 0.0f;
+          } else {
+            out[(size_t)4 * NP + (size_t)L * ((size_t)NP * NP + NP) + 16 * rt + m] = v0;
           }
         }
       }
-    }
+      if (!first && wave == 0) {
+        float tsum = (lane < 16) ? sg : 0.0f;
 #pragma unroll
-    for (int i = 0; i < RC; ++i) {
-      const int rt = wave + 4 * i;
-      float v0 = a0[i], v1 = a1[i], v2 = a2[i];
-      v0 += __shfl_xor(v0, 16); v0 += __shfl_xor(v0, 32);
-      v1 += __shfl_xor(v1, 16); v1 += __shfl_xor(v1, 32);
-      v2 += __shfl_xor(v2, 16); v2 += __shfl_xor(v2, 32);
-      if (rt < NT && lane < 16) {
-        if (first) {
-          float *o = out + (size_t)(16 * rt + m) * 4;
-          o[0] = v0; o[1] = v1; o[2] = v2; o[3] = 0.0f;
-        } else {
-          out[(size_t)4 * NP + (size_t)L * ((size_t)NP * NP + NP) + 16 * rt + m] = v0;
+        for (int sft = 1; sft < 16; sft <<= 1) tsum += __shfl_xor(tsum, sft);
+        if (lane == 0) {
+          float *o = out + (size_t)4 * NP + (size_t)L * ((size_t)NP * NP + NP) + NP;
+          o[0] = tsum; o[1] = o[2] = o[3] = 0.0f;
         }
-      }
-    }
-    if (!first && wave == 0) {
-      float t = (lane < 16) ? sg : 0.0f;
-#pragma unroll
-      for (int s = 1; s < 16; s <<= 1) t += __shfl_xor(t, s);
-      if (lane == 0) {
-        float *o = out + (size_t)4 * NP + (size_t)L * ((size_t)NP * NP + NP) + NP;
-        o[0] = t; o[1] = o[2] = o[3] = 0.0f;
       }
     }
     return;
@@ -237,7 +260,7 @@ __global__ void __launch_bounds__(256) ionode_grad_reduce_kernel(const float *__
 inline hipError_t launch_grad_reduce(int L, int NT, const float *records, int64_t n_records, int n_slabs, float *partials,
                                      hipStream_t s, int unit_seed = 0) {
   const int CB = (NT <= 13) ? NT : 8, NCB = NT / CB;
-  const unsigned grid = (unsigned)(n_slabs * (L * NCB + 2));
+  const unsigned grid = (unsigned)(n_slabs * (L * NCB + 1));
   const size_t lds = (size_t)2 * (NT + CB) * 64 * 16;
   switch (NT) {
     case 1: hipLaunchKernelGGL(ionode_grad_reduce_kernel<1>, dim3(grid), dim3(256), lds, s, records, n_records, n_slabs, L, partials, unit_seed); break;
