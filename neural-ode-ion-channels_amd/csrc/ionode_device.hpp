@@ -1449,9 +1449,16 @@ template <int N> struct MlpLane {
         if (4 * q + r < N) { if (n == pos) return 4 * q + r; ++n; }
     return -1;
   }
+#ifndef IONODE_VNET_RELOAD
+#define IONODE_VNET_RELOAD 1   // 1: Linear(2, N) and Linear(N, 1) are scalar loads of THIS evaluation (round 5).  0 (rounds 3-4): hipcc hoists
+                               // the 62 loop-invariant scalars out of the attempt loop, cannot keep them in scalar registers next to the hidden
+                               // layers' 110 and parks them in VGPR lanes: 79 v_readlane per evaluation -- vector-ALU work in a vector-issue-bound kernel
+#endif
   __device__ __forceinline__ float eval_tiny64(float x0, float x1) {
     constexpr size_t lstride = (size_t)256 + NP;  // MlpTile<1, 1, 1, 1>::layer_floats(): one fragment + bias[NP]
-    const cfloat *wl = img + 4 * NP + (size_t)L * lstride;   // wl[NP], bl, 3 pad
+    const cfloat *im = img;
+    if (IONODE_VNET_RELOAD) asm volatile("" : "+s"(im));     // (an opaque copy of the pointer: loads through it stay inside this evaluation)
+    const cfloat *wl = im + 4 * NP + (size_t)L * lstride;   // wl[NP], bl, 3 pad
     const cfloat2 *s0 = reinterpret_cast<const cfloat2 *>(wl + NP + 4);   // the scalar section: layer 0 ...
     const cfloat2 *sh = s0 + NPAIR * 4;                                    // ... and the hidden layers
     f32x2 h[NPAIR];
@@ -1471,7 +1478,7 @@ template <int N> struct MlpLane {
         for (int u = 0; u < GP; ++u)
           if (m0 + u < NPAIR) g[m0 + u] = sh[((size_t)l * NPAIR + m0 + u) * (PB / 2) + N];
 #ifndef IONODE_VNET_SPLIT
-#define IONODE_VNET_SPLIT 0   // > 0: a scheduling barrier after this many k positions (A/B: fewer scalar registers of weights in flight)
+#define IONODE_VNET_SPLIT 5   // > 0: a scheduling barrier after this many k positions: half of the 110 weight scalars of a row-pair group in flight, so that the kernel's own uniform state stays in scalar registers (with IONODE_VNET_RELOAD: 539 -> 49 v_readlane per attempt)
 #endif
 #pragma unroll
         for (int pos = 0; pos < N; ++pos) {
@@ -1492,6 +1499,7 @@ template <int N> struct MlpLane {
 #pragma unroll
       for (int m = 0; m < NPAIR; ++m) h[m] = g[m];
     }
+    if (IONODE_VNET_RELOAD) asm volatile("" : "+s"(wl));     // (Linear(N, 1)'s scalars are loaded after the hidden stack, not carried through it)
     float part[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -1647,9 +1655,16 @@ struct NoMlp {
 // func.forward(t, y) of the reference, per lane.  The protocol voltage at the stage time (and whether
 // the time was inside the protocol's range) is looked up by the caller, ahead of the stage.
 // ---------------------------------------------------------------------------------------------
+// (rate constants of one stage voltage; see closed_rates() below)
+template <int MODEL> struct ClosedRates {
+  static constexpr int NR = (MODEL == IONODE_MODEL_MARKOV6) ? 6 : 4;
+  double k[NR];
+  float kf[NR];
+  bool oob32;
+};
 template <int MODEL, typename S, bool WIDE = false, typename MLP>
 __device__ __forceinline__ void rhs(const KArgs &a, const double *p, double v, bool inrange, const S *y, S *f,
-                                    MLP &mlp) {
+                                    MLP &mlp, ClosedRates<IONODE_MODEL_HH2> *cr = nullptr, bool fresh = true) {
   using MT = ModelTraits<MODEL>;
   constexpr bool F32 = sizeof(S) == 4;
 
@@ -1729,22 +1744,36 @@ __device__ __forceinline__ void rhs(const KArgs &a, const double *p, double v, b
     if constexpr (MT::MLP && WIDE) {
       // one trajectory per lane (N <= 16): the closed-form kernels' exp -- addend constants as scalar operands, one v_ldexp_f64, and
       // the three range cases skipped when every lane's arguments are in range (closed_rates); same operations, same bits
+      // (round 5) the rates depend on the stage VOLTAGE only: the integrator says `fresh = false` when every lane of the wavefront sees the
+      // previous stage's voltage again (stage 6 always; every stage on a protocol's plateaus) and the products kept in *cr are reused
       constexpr int NX = HAS_HH_A ? 4 : 2;
-      double x[NX], e[NX];
-      x[0] = p[5] * v; x[1] = -p[7] * v;
-      if constexpr (HAS_HH_A) { x[2] = p[1] * v; x[3] = -p[3] * v; }
-      bool in = true;
+      double kk[4];
+      if (fresh || cr == nullptr) {
+        double x[NX], e[NX];
+        x[0] = p[5] * v; x[1] = -p[7] * v;
+        if constexpr (HAS_HH_A) { x[2] = p[1] * v; x[3] = -p[3] * v; }
+        bool in = true;
 #pragma unroll
-      for (int i = 0; i < NX; ++i) in = in && (__builtin_fabs(x[i]) <= 708.0);
-      if (__ballot(!in) == 0ull) {
+        for (int i = 0; i < NX; ++i) in = in && (__builtin_fabs(x[i]) <= 708.0);
+        if (__ballot(!in) == 0ull) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) e[i] = det_exp_inrange(x[i]);
+          for (int i = 0; i < NX; ++i) e[i] = det_exp_inrange(x[i]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < NX; ++i) e[i] = det_exp_ldexp(x[i]);
+        }
+        kk[2] = p[4] * e[0]; kk[3] = p[6] * e[1];
+        if constexpr (HAS_HH_A) { kk[0] = p[0] * e[2]; kk[1] = p[2] * e[3]; }
+        if (cr != nullptr) {
+          cr->k[2] = kk[2]; cr->k[3] = kk[3];
+          if constexpr (HAS_HH_A) { cr->k[0] = kk[0]; cr->k[1] = kk[1]; }
+        }
       } else {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) e[i] = det_exp_ldexp(x[i]);
+        kk[2] = cr->k[2]; kk[3] = cr->k[3];
+        if constexpr (HAS_HH_A) { kk[0] = cr->k[0]; kk[1] = cr->k[1]; }
       }
-      k3 = p[4] * e[0]; k4 = p[6] * e[1];
-      if constexpr (HAS_HH_A) dadt = (p[0] * e[2]) * (double)one_m_a - (p[2] * e[3]) * (double)av;
+      k3 = kk[2]; k4 = kk[3];
+      if constexpr (HAS_HH_A) dadt = kk[0] * (double)one_m_a - kk[1] * (double)av;
     } else {
       k3 = p[4] * dexp(p[5] * v);
       k4 = p[6] * dexp(-p[7] * v);
@@ -1764,12 +1793,6 @@ __device__ __forceinline__ void rhs(const KArgs &a, const double *p, double v, b
 // Closed-form models, split form of rhs(): the rate constants depend on the stage VOLTAGE only, and the last two stages of a
 // dopri5 attempt share their time (alpha = 1, 1), so the integrator evaluates them once for both (4 of 24 exp per attempt for
 // the 2-state model, 12 of 72 for the 6-state model).  Same expressions as rhs(), same bits.
-template <int MODEL> struct ClosedRates {
-  static constexpr int NR = (MODEL == IONODE_MODEL_MARKOV6) ? 6 : 4;
-  double k[NR];
-  float kf[NR];
-  bool oob32;
-};
 template <int MODEL, typename S>
 __device__ __forceinline__ void closed_rates(const KArgs &a, const double *p, double v, bool inrange, ClosedRates<MODEL> &R) {
   constexpr int NR = ClosedRates<MODEL>::NR;
@@ -2228,7 +2251,12 @@ __global__ void __launch_bounds__(64 * (IONODE_IS_LW(MODEL, RT) ? IONODE_LW_TILE
         for (int jx = 1; jx <= i; ++jx) s = s + k[jx][d] * bd[jx];
         yi[d] = y[d] + s;
       }
-      if constexpr (MT::MLP) rhs<MODEL, S, T64>(a, p, vst[i < 4 ? i : 4], inst[i < 4 ? i : 4], yi, k[i + 1], mlp);
+      if constexpr (MT::MLP && T64) {
+        // the lane-wise nets: the rate constants of the Hodgkin-Huxley terms are reused as in the closed-form kernels below
+        bool fresh = (i == 0);
+        if (i > 0 && i < 5) fresh = __ballot(vst[i] != vst[i > 0 ? i - 1 : 0] || inst[i] != inst[i > 0 ? i - 1 : 0]) != 0ull;
+        rhs<MODEL, S, T64>(a, p, vst[i < 4 ? i : 4], inst[i < 4 ? i : 4], yi, k[i + 1], mlp, &cr, fresh);
+      } else if constexpr (MT::MLP) rhs<MODEL, S, T64>(a, p, vst[i < 4 ? i : 4], inst[i < 4 ? i : 4], yi, k[i + 1], mlp);
       else {
         // rate constants depend on the stage VOLTAGE only: i == 5 shares its stage time with i == 4, and on the holding / step
         // segments of the reference's protocols (Pr3, Pr5, staircase plateaus: train-s1.py:69-95) consecutive stages see the very same
