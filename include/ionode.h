@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define IONODE_ABI_VERSION 8
+#define IONODE_ABI_VERSION 9
 
 /* RHS families (func.forward variants of the reference) */
 #define IONODE_MODEL_HH2 0     /* 2-state Hodgkin-Huxley: Lambda, train-s1.py:134-177; candidate ODEFunc train-d0.py:321-374 */
@@ -254,6 +254,11 @@ int ionode_grad_reduce_unit(int32_t mlp_layers, int32_t mlp_width, const float *
 /* floats of one slab's partial gradient: [NP][4]{db0, dW0[.][0], dW0[.][1], 0} | L x (dW_l [NP][NP] + db_l [NP]) | dwl [NP] +
  * {dbl, 0, 0, 0}, NP = 16 * ceil(N / 16), rows/columns >= N are padding */
 size_t ionode_grad_partial_floats(int32_t mlp_layers, int32_t mlp_width);
+
+/* The slab count that makes one round of workgroups of ionode_grad_reduce() on the current device (256 compute units when there is
+ * none): a slab costs mlp_layers x (column blocks of the width) heavy workgroups + one light one, N = 200 runs two workgroups per
+ * compute unit.  Any n_slabs >= 1 is valid; this one is the fastest.  Since ABI 9. */
+int32_t ionode_grad_reduce_slabs(int32_t mlp_layers, int32_t mlp_width, int64_t n_records);
 
 /* partials[n_slabs][ionode_grad_partial_floats()] = per-slab sums over records [n_records * s / n_slabs, ...); asynchronous */
 int ionode_grad_reduce(int32_t mlp_layers, int32_t mlp_width, const float *records, int64_t n_records, int32_t n_slabs,

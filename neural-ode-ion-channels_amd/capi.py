@@ -21,14 +21,14 @@ STATUS_TEXT = {
     2: "non-finite values in state `y`",
     3: "max_num_steps exceeded",
 }
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 EXPORTS = (
     "ionode_abi_version", "ionode_last_error", "ionode_mlp_packed_floats", "ionode_mlp_pack",
     "ionode_launch_geometry", "ionode_kernel_name", "ionode_last_kernel_name", "ionode_lane_wise_from", "ionode_dopri5", "ionode_protocol_at_outputs",
     "ionode_grad_image_floats", "ionode_grad_pack", "ionode_grad_record_floats", "ionode_dopri5_backward",
     "ionode_grad_packet_doubles", "ionode_dopri5_backward_recompute", "ionode_dopri5_backward_sweep",
-    "ionode_grad_partial_floats", "ionode_grad_reduce", "ionode_grad_reduce_unit", "ionode_grad_last_error",
+    "ionode_grad_partial_floats", "ionode_grad_reduce", "ionode_grad_reduce_unit", "ionode_grad_reduce_slabs", "ionode_grad_last_error",
     "ionode_regress_step", "ionode_adam_step", "ionode_image_refresh",
 )
 
@@ -100,6 +100,8 @@ def lib():
         L.ionode_dopri5_backward_sweep.argtypes = [C.POINTER(IonodeDesc), C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 14
         L.ionode_grad_reduce.restype = C.c_int
         L.ionode_grad_reduce.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
+        L.ionode_grad_reduce_slabs.restype = C.c_int32
+        L.ionode_grad_reduce_slabs.argtypes = [C.c_int32, C.c_int32, C.c_int64]
         L.ionode_grad_reduce_unit.restype = C.c_int
         L.ionode_grad_reduce_unit.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
         L.ionode_regress_step.restype = C.c_int

@@ -176,6 +176,16 @@ static int reduce_impl(int32_t L, int32_t N, const float *records, int64_t n_rec
   return IONODE_OK;
 }
 
+int32_t ionode_grad_reduce_slabs(int32_t L, int32_t N, int64_t n_records) {
+  if (L < 1 || N < 1 || n_records < 1) return 1;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) {
+    (void)hipGetLastError();
+    cus = 256;   // (no device: the plan of an unpartitioned MI355X)
+  }
+  return ionode::grad_reduce_slabs(L, np_of(N) / 16, cus, n_records);
+}
+
 int ionode_grad_reduce(int32_t L, int32_t N, const float *records, int64_t n_records, int32_t n_slabs, float *partials,
                        void *stream) {
   return reduce_impl(L, N, records, n_records, n_slabs, partials, stream, 0);

@@ -23,20 +23,29 @@ __host__ __device__ constexpr size_t grad_partial_floats(int L, int NT) {
   return (size_t)4 * 16 * NT + (size_t)L * ((size_t)256 * NT * NT + 16 * NT) + 16 * NT + 4;
 }
 
+// Column blocks of a heavy job.  N = 500 (NT = 32: 1024 accumulator registers per wavefront) is cut into 4 jobs of 8 column tiles.
+// N = 200 (NT = 13), round 5: TWO jobs of 7 and 6 column tiles (96 accumulator registers per wavefront instead of 172), so that THREE workgroups
+// share a compute unit: one's staging, barrier and LDS reads run beside the others' MFMAs, the light workgroups sit beside heavy ones
+// instead of holding a compute unit of their own, and 2 L + 1 workgroups per slab deal the records out finer (one round: 69 slabs on 768
+// workgroup slots instead of 42 on 256; regression step 1.84 -> 1.71 ms, 46 slabs at two per unit: 1.74).  Both blocks stage the D_l tiles; the sums are the same chains in the same order: same bits.
+__host__ __device__ constexpr int grad_reduce_cb(int NT) { return NT == 13 ? 7 : (NT < 13 ? NT : 8); }
+__host__ __device__ constexpr int grad_reduce_ncb(int NT) { return (NT + grad_reduce_cb(NT) - 1) / grad_reduce_cb(NT); }
+__host__ __device__ constexpr int grad_reduce_wg_per_cu(int NT) { return NT == 13 ? 3 : 1; }   // (168 registers, 40 KB of LDS: three fit)
+
 template <int NT>
 // unit_seed: the records' D tiles were produced with seed 1 (the factored two-phase sweep: the product is linear in the seed, a
 // scalar per trajectory, which the walk writes into the record's scalar block afterwards); they are scaled by it while staged.
-__global__ void __launch_bounds__(256) ionode_grad_reduce_kernel(const float *__restrict__ records, int64_t n_records, int n_slabs,
+__global__ void __launch_bounds__(256, grad_reduce_wg_per_cu(NT)) ionode_grad_reduce_kernel(const float *__restrict__ records, int64_t n_records, int n_slabs,
                                                                  int L, float *__restrict__ partials, int unit_seed) {
   constexpr int NP = 16 * NT;
   constexpr int F = NT / 4;        // full row tiles per wavefront (rt = wave + 4i, every column tile)
   constexpr int R = NT - 4 * F;    // remainder row tiles, their column tiles dealt round-robin over the wavefronts
-  constexpr int RC = (NT + 3) / 4;
-  // column block of a heavy job: the whole NP x NP accumulator for N <= 208; N = 500 (NT = 32: 1024 registers per wavefront)
-  // is cut into NCB = 4 jobs of CB = 8 column tiles each (256 registers), which stage the D_l tiles and their own H_{l-1} tiles
-  constexpr int CB = (NT <= 13) ? NT : 8;
-  constexpr int NCB = NT / CB;
-  static_assert(NT % CB == 0 && (NT - 4 * (NT / 4) == 0 || NCB == 1), "column blocks: whole tiles, no remainder row tiles");
+  // column block of a heavy job (see grad_reduce_cb): CB column tiles from cb0 on (the last block of N = 200 has one tile less: its
+  // seventh is skipped, wave-uniformly); every block stages the D_l tiles and its own H_{l-1} tiles
+  constexpr int CB = grad_reduce_cb(NT);
+  constexpr int NCB = grad_reduce_ncb(NT);
+  constexpr int RC = (CB + 3) / 4;   // column tiles of a remainder row tile per wavefront (block-local tiles ct with ct % 4 == wave)
+  constexpr int RCL = (NT + 3) / 4;  // the light jobs' row tiles per wavefront
   constexpr int STE = (NT + CB) * 64;             // float4 elements staged per record: D_l tiles + this block's H_{l-1} tiles
   constexpr int STG = (STE + 255) / 256;          // float4 loads per thread per record
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -48,7 +57,7 @@ __global__ void __launch_bounds__(256) ionode_grad_reduce_kernel(const float *__
   const int jobx = blockIdx.x % NJOB;
   const int slab = blockIdx.x / NJOB;
   const int job = (jobx == 0) ? 0 : 1 + (jobx - 1) / NCB;   // 0 | layer 1..L
-  const int cb0 = (jobx == 0) ? 0 : ((jobx - 1) % NCB) * CB;   // first column tile of the block
+  const int cb0 = __builtin_amdgcn_readfirstlane((jobx == 0) ? 0 : ((jobx - 1) % NCB) * CB);   // first column tile of the block
   const int64_t r0 = n_records * slab / n_slabs, r1 = n_records * (slab + 1) / n_slabs;
   const int64_t RECF = grad_record_floats(L, NT);
   float *__restrict__ out = partials + (size_t)slab * grad_partial_floats(L, NT);
@@ -62,12 +71,12 @@ __global__ void __launch_bounds__(256) ionode_grad_reduce_kernel(const float *__
     constexpr int NB = 4;
     for (int lj = 0; lj < 2; ++lj) {
       const bool first = lj == 0;
-      float a0[RC], a1[RC], a2[RC];
+      float a0[RCL], a1[RCL], a2[RCL];
 #pragma unroll
-      for (int i = 0; i < RC; ++i) a0[i] = a1[i] = a2[i] = 0.0f;
+      for (int i = 0; i < RCL; ++i) a0[i] = a1[i] = a2[i] = 0.0f;
       float sg = 0.0f;
       for (int64_t rb = r0; rb < r1; rb += NB) {
-        f32x4 t[NB][RC];
+        f32x4 t[NB][RCL];
         float s0[NB][4], s1[NB][4], sd[NB][4], sgl[NB];
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
@@ -83,7 +92,7 @@ __global__ void __launch_bounds__(256) ionode_grad_reduce_kernel(const float *__
           }
           sgl[u] = (lane < 16) ? sc[32 + lane] : 0.0f;
 #pragma unroll
-          for (int i = 0; i < RC; ++i) {
+          for (int i = 0; i < RCL; ++i) {
             const int rt = wave + 4 * i;
             t[u][i] = (rt < NT) ? tiles[rt * 64 + lane] : f32x4{0, 0, 0, 0};
           }
@@ -93,7 +102,7 @@ __global__ void __launch_bounds__(256) ionode_grad_reduce_kernel(const float *__
           if (rb + u < r1) {
             if (!first && wave == 0 && lane < 16) sg += sgl[u];
 #pragma unroll
-            for (int i = 0; i < RC; ++i) {
+            for (int i = 0; i < RCL; ++i) {
               const int rt = wave + 4 * i;
               if (rt < NT) {
                 f32x4 tt = t[u][i];
@@ -112,7 +121,7 @@ __global__ void __launch_bounds__(256) ionode_grad_reduce_kernel(const float *__
         }
       }
 #pragma unroll
-      for (int i = 0; i < RC; ++i) {
+      for (int i = 0; i < RCL; ++i) {
         const int rt = wave + 4 * i;
         float v0 = a0[i], v1 = a1[i], v2 = a2[i];
         v0 += __shfl_xor(v0, 16); v0 += __shfl_xor(v0, 32);
@@ -203,6 +212,7 @@ __global__ void __launch_bounds__(256) ionode_grad_reduce_kernel(const float *__
     }
 #pragma unroll
     for (int ct = 0; ct < CB; ++ct) {
+      if (NT % CB != 0 && cb0 + ct >= NT) break;   // (the short last block; wave-uniform)
       const f32x4 b = Hb[ct * 64 + lane];
       // trajectory group c outer, row tile inner: consecutive MFMAs on different accumulators (issue 32 cycles, result 40)
 #pragma unroll
@@ -233,9 +243,11 @@ __global__ void __launch_bounds__(256) ionode_grad_reduce_kernel(const float *__
   for (int i = 0; i < F; ++i) {
     const int rt = wave + 4 * i;
 #pragma unroll
-    for (int ct = 0; ct < CB; ++ct)
+    for (int ct = 0; ct < CB; ++ct) {
+      if (NT % CB != 0 && cb0 + ct >= NT) break;
 #pragma unroll
       for (int r = 0; r < 4; ++r) W[(size_t)(16 * rt + 4 * kk + r) * NP + 16 * (cb0 + ct) + m] = acc[i][ct][r];
+    }
     float s = (dba[i][0] + dba[i][1]) + (dba[i][2] + dba[i][3]);
     s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
     if (lane < 16 && cb0 == 0) bvec[16 * rt + m] = s;   // the bias gradient once per layer (column block 0)
@@ -245,21 +257,30 @@ __global__ void __launch_bounds__(256) ionode_grad_reduce_kernel(const float *__
     const int rt = 4 * F + j;
 #pragma unroll
     for (int u = 0; u < RC; ++u) {
-      const int ct = 4 * u + wave;
-      if (ct < NT) {
+      const int ct = 4 * u + wave;   // block-local column tile
+      if (ct < CB && cb0 + ct < NT) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) W[(size_t)(16 * rt + 4 * kk + r) * NP + 16 * ct + m] = accr[j][u][r];
+        for (int r = 0; r < 4; ++r) W[(size_t)(16 * rt + 4 * kk + r) * NP + 16 * (cb0 + ct) + m] = accr[j][u][r];
       }
     }
     float s = (dbr[j][0] + dbr[j][1]) + (dbr[j][2] + dbr[j][3]);
     s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
-    if (wave == 0 && lane < 16) bvec[16 * rt + m] = s;
+    if (wave == 0 && lane < 16 && cb0 == 0) bvec[16 * rt + m] = s;
   }
+}
+
+// slabs that make ONE round of workgroups on `cus` compute units (L x NCB heavy workgroups + one light workgroup per slab); at least
+// four records per slab
+inline int grad_reduce_slabs(int L, int NT, int cus, int64_t n_records) {
+  const int64_t slots = (int64_t)cus * grad_reduce_wg_per_cu(NT), per_slab = (int64_t)L * grad_reduce_ncb(NT) + 1;
+  int64_t n = slots / per_slab;
+  if (n > n_records / 4) n = n_records / 4;
+  return n < 1 ? 1 : (int)n;
 }
 
 inline hipError_t launch_grad_reduce(int L, int NT, const float *records, int64_t n_records, int n_slabs, float *partials,
                                      hipStream_t s, int unit_seed = 0) {
-  const int CB = (NT <= 13) ? NT : 8, NCB = NT / CB;
+  const int CB = grad_reduce_cb(NT), NCB = grad_reduce_ncb(NT);
   const unsigned grid = (unsigned)(n_slabs * (L * NCB + 1));
   const size_t lds = (size_t)2 * (NT + CB) * 64 * 16;
   switch (NT) {

@@ -263,7 +263,7 @@ class _Solve(torch.autograd.Function):
             swept.record(main)
             if need_w:
                 n_rec = tiles * (it1 - it0) * 6
-                n_slabs = int(max(1, min(256 // (L + 1), n_rec // 4)))
+                n_slabs = int(os.environ.get("IONODE_GRAD_SLABS", 0)) or int(lib.ionode_grad_reduce_slabs(L, N, n_rec))   # one round of workgroups on this device (env: dev override for A/B runs)
                 side.wait_event(swept)
                 with torch.cuda.stream(side):
                     partials = torch.empty((n_slabs, partf), dtype=torch.float32, device=dev)

@@ -67,7 +67,7 @@ class MlpRegression:
         # run beside the other's MFMAs), one for N = 500.  IONODE_REGRESS_WG_PER_CU: dev override for A/B runs
         per_cu = int(os.environ.get("IONODE_REGRESS_WG_PER_CU", "2" if N <= 208 else "1"))
         self.n_wg = int(min(self.tiles, cus * per_cu))
-        self.n_slabs = int(os.environ.get("IONODE_REGRESS_SLABS", 0)) or int(max(1, min(cus // (L + 1), self.tiles // 4)))   # (L heavy jobs + one workgroup for both light jobs per slab; env: dev override for A/B runs)
+        self.n_slabs = int(os.environ.get("IONODE_REGRESS_SLABS", 0)) or int(lib.ionode_grad_reduce_slabs(L, N, self.tiles))   # (one round of the reduce kernel's workgroups on this device; env: dev override for A/B runs)
         self.loss_part = torch.zeros(self.n_wg, dtype=torch.float64, device=dev)
         self.partials = torch.empty((self.n_slabs, partf), dtype=torch.float32, device=dev)
         self.grad = torch.zeros_like(self.w)

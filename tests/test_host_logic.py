@@ -411,6 +411,19 @@ def test_lane_wise_crossovers_come_from_the_library(ion):
     assert L.ionode_lane_wise_from(capi.MODEL_NNF, 200) == 0
 
 
+def test_reduce_slab_count_makes_one_round_of_workgroups(ion):
+    """Round 5: the slab count of ionode_grad_reduce() comes from the library (host code kept a formula of its own that went stale when the
+    kernel's jobs per slab changed).  Without a device the plan is that of 256 compute units: N = 200 runs three workgroups per unit and two
+    column blocks per layer (768 // 11), N = 500 four column blocks at one per unit (256 // 21), N = 100 one block (256 // 6); never fewer
+    than four records per slab, never fewer than one slab."""
+    L = ion.capi.lib()
+    assert L.ionode_grad_reduce_slabs(5, 200, 8276) == 69
+    assert L.ionode_grad_reduce_slabs(10, 200, 100000) == 768 // 21
+    assert L.ionode_grad_reduce_slabs(5, 500, 8276) == 12
+    assert L.ionode_grad_reduce_slabs(5, 100, 8276) == 42
+    assert L.ionode_grad_reduce_slabs(5, 200, 40) == 10 and L.ionode_grad_reduce_slabs(5, 200, 3) == 1 and L.ionode_grad_reduce_slabs(0, 200, 8) == 1
+
+
 def test_every_width_up_to_512_has_a_kernel_and_an_image(ion):
     """Round 5: widths without a tuned tile go to the run-time-width tile (NT slot 0) instead of
     IONODE_ERR_UNSUPPORTED; the packed image of such a width is the generic layout, and beyond N = 512 the call still refuses."""
