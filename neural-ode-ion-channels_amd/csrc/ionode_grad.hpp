@@ -798,6 +798,19 @@ __global__ void __launch_bounds__(256, (NT <= 13 ? IONODE_RECOMPUTE_WG_PER_CU : 
   const bool pk_writer = wave == 0 && lane < 16;
   const int it_lo = a.it_begin + (int)blockIdx.y * GRAD_RECOMPUTE_IB;
   const int it_hi = (it_lo + GRAD_RECOMPUTE_IB < a.it_end) ? it_lo + GRAD_RECOMPUTE_IB : a.it_end;
+  // Memory round trips of an iteration (round 5).  An iteration is ~140 us of MFMA work behind a chain of dependent loads from HBM-resident
+  // arrays: the step's checkpoint -> its output gradients (four trajectories per wavefront, one after the other) -> six protocol lookups,
+  // one in front of every stage's product -- about a dozen exposed round trips.  Now: the NEXT iteration's checkpoint is fetched while this
+  // one's products run, the four trajectories' first 64 samples are loaded together, and the stage voltages are looked up ahead of the
+  // stages (as the forward kernel does): three round trips.  Same values, same summation order, same bits.
+  double crec[4 + 8 * D];   // the coming iteration's checkpoint record (a clamped, always valid row: what is not wanted is masked below)
+  auto fetch_ckpt = [&](int it) {
+    const int s = nst - 1 - it;
+    const double *rec = ck + (size_t)(s >= 0 ? s : 0) * RECW;
+#pragma unroll
+    for (int i = 0; i < 4 + 8 * D; ++i) crec[i] = rec[i];
+  };
+  if (it_lo < it_hi) fetch_ckpt(it_lo);
   for (int it = it_lo; it < it_hi; ++it) {
     // ---- checkpoint of my step: as in ionode_dopri5_backward_kernel ----
     const int s = nst - 1 - it;
@@ -806,17 +819,17 @@ __global__ void __launch_bounds__(256, (NT <= 13 ? IONODE_RECOMPUTE_WG_PER_CU : 
     double t0 = 0.0, dt = 1.0, y[D], k[7][D];
     int oi = 0, nout = 0;
     {
-      const double *rec = ck + (size_t)(step ? s : 0) * RECW;
       const bool ld = step || initev;
-      if (ld) { t0 = rec[0]; dt = rec[1]; }
-      if (step) { oi = (int)rec[2]; nout = (int)rec[3]; }
+      if (ld) { t0 = crec[0]; dt = crec[1]; }
+      if (step) { oi = (int)crec[2]; nout = (int)crec[3]; }
 #pragma unroll
-      for (int d = 0; d < D; ++d) y[d] = ld ? rec[4 + d] : 0.0;
+      for (int d = 0; d < D; ++d) y[d] = ld ? crec[4 + d] : 0.0;
 #pragma unroll
       for (int jx = 0; jx < 7; ++jx)
 #pragma unroll
-        for (int d = 0; d < D; ++d) k[jx][d] = step ? rec[4 + D + jx * D + d] : 0.0;
+        for (int d = 0; d < D; ++d) k[jx][d] = step ? crec[4 + D + jx * D + d] : 0.0;
     }
+    if (it + 1 < it_hi) fetch_ckpt(it + 1);
     const double t1 = t0 + dt;
     const S t0s = (S)t0, dts_s = (S)dt, t1s = (S)t1;
     const double dts = (double)dts_s;
@@ -824,6 +837,22 @@ __global__ void __launch_bounds__(256, (NT <= 13 ? IONODE_RECOMPUTE_WG_PER_CU : 
     double *__restrict__ pk = a.packets + (tstep * 16 + j) * GRAD_PACKET;
 
     // ---- adjoints of the interpolant coefficients: G_c = sum_k gy[k] * x_k^c over the step's output samples (verbatim) ----
+    // (the first 64 samples of the wavefront's four trajectories: all loads in flight before the first is used)
+    double tk0[4];
+    S gy0[4][D];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int jj = wave + 4 * u;
+      const int n = __builtin_amdgcn_readlane(nout, jj);
+      const int o = __builtin_amdgcn_readlane(oi, jj);
+      const int tr = __builtin_amdgcn_readlane(traj, jj);
+      int idx = o + (lane < n ? lane : 0);
+      idx = idx < Nt ? (idx < 0 ? 0 : idx) : Nt - 1;   // (n == 0: any valid sample; it is not used)
+      tk0[u] = a.k.t_eval[idx];
+      const S *__restrict__ gyb = reinterpret_cast<const S *>(a.grad_y) + (size_t)tr * Nt * D;
+#pragma unroll
+      for (int d = 0; d < D; ++d) gy0[u][d] = gyb[(size_t)idx * D + d];
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int jj = wave + 4 * u;
@@ -841,13 +870,13 @@ __global__ void __launch_bounds__(256, (NT <= 13 ? IONODE_RECOMPUTE_WG_PER_CU : 
         for (int c0 = 0; c0 < n; c0 += 64) {
           if (c0 + lane < n) {
             const int idx = o + c0 + lane;
-            const double tk = a.k.t_eval[idx];
+            const double tk = (c0 == 0) ? tk0[u] : a.k.t_eval[idx];
             const double x = (double)(S)((tk - t0b) / (t1b - t0b));
             double xp = 1.0;
 #pragma unroll
             for (int c = 0; c < 5; ++c) {
 #pragma unroll
-              for (int d = 0; d < D; ++d) P[c][d] += (double)gyb[(size_t)idx * D + d] * xp;
+              for (int d = 0; d < D; ++d) P[c][d] += (double)((c0 == 0) ? gy0[u][d] : gyb[(size_t)idx * D + d]) * xp;
               xp *= x;
             }
           }
@@ -874,11 +903,22 @@ __global__ void __launch_bounds__(256, (NT <= 13 ? IONODE_RECOMPUTE_WG_PER_CU : 
 #pragma unroll
         for (int d = 0; d < D; ++d) pk[4 + c * D + d] = Gs[j * (5 * D) + c * D + d];
     }
+    // stage voltages: pure functions of (t0, dt) -- the five distinct lookups are issued together, ahead of the stages (stage i = 5 shares i = 4's time)
+    double vs0, vs1, vs2, vs3, vs4;
+    {
+      const double tq_init = (double)(S)a.k.t_eval[0];
+      auto look = [&](int i, double &v) {
+        const S ti = (i >= 4) ? R::prev_(t1s) : t0s + (S)kAlpha[i] * dts_s;
+        protocol_v(a.k, pv, step ? (double)ti : tq_init, v);
+      };
+      look(0, vs0); look(1, vs1); look(2, vs2); look(3, vs3); look(4, vs4);
+      // (opaque scalars: from an array hipcc turns the select chain below back into an indexed load -- of a scratch array)
+      asm volatile("" : "+v"(vs0), "+v"(vs1), "+v"(vs2), "+v"(vs3), "+v"(vs4));
+    }
 #pragma unroll 1
     for (int e = 0; e < 6; ++e) {
       const int i = 5 - e;
       double Yi[D];
-      double tq;
       if (step) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
@@ -886,15 +926,15 @@ __global__ void __launch_bounds__(256, (NT <= 13 ? IONODE_RECOMPUTE_WG_PER_CU : 
           for (int jx = 0; jx <= i; ++jx) sacc += k[jx][d] * (kBeta[i][jx] * dts);
           Yi[d] = y[d] + sacc;
         }
-        const S ti = (i >= 4) ? R::prev_(t1s) : t0s + (S)kAlpha[i] * dts_s;
-        tq = (double)ti;
       } else {
 #pragma unroll
         for (int d = 0; d < D; ++d) Yi[d] = y[d];
-        tq = (double)(S)a.k.t_eval[0];
       }
-      double v;
-      protocol_v(a.k, pv, tq, v);
+      double v = vs4;   // (e is wave-uniform: a chain of selects, no indexed register file)
+      if (i == 3) v = vs3;
+      if (i == 2) v = vs2;
+      if (i == 1) v = vs1;
+      if (i == 0) v = vs0;
       const float x0 = (float)(v / 100.0), x1 = (float)Yi[0];
       const double e3 = det_exp(p[5] * v), e4 = det_exp(-p[7] * v);
       double e1 = 0.0, e2 = 0.0;

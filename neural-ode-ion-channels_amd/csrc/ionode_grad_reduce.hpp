@@ -171,12 +171,19 @@ __global__ void __launch_bounds__(256, grad_reduce_wg_per_cu(NT)) ionode_grad_re
                          : base + ((size_t)(l - 1) * NT + cb0) * 64 + (e - NT * 64);            // H_{l-1}, this block's tiles
   };
   f32x4 stg[STG];
+  // a unit-seed record's 16 seeds are STAGED with its tiles (one float per thread 0..15, into 64 bytes behind the tile buffers).  Loaded
+  // from global memory in the iteration that uses them (rounds 3-5) their wait was `s_waitcnt vmcnt(0)` in front of the record's first
+  // MFMA, which also waited for the NEXT record's staging loads -- every record paid a full memory round trip, with or without seeds.
+  float *seedbuf = reinterpret_cast<float *>(buf + (size_t)2 * STE);   // [2][16]
+  auto seed_src = [&](int64_t rr) -> const float * { return records + rr * RECF + (size_t)2 * (L + 1) * NT * 256 + 32 + (threadIdx.x & 15); };
+  float sdg = 1.0f;
   if (r0 < r1) {
 #pragma unroll
     for (int u = 0; u < STG; ++u) {
       const int e = threadIdx.x + 256 * u;
       if (e < STE) buf[e] = *src_of(r0, e);
     }
+    if (unit_seed && threadIdx.x < 16) seedbuf[threadIdx.x] = *seed_src(r0);
   }
   __syncthreads();
   for (int64_t rr = r0; rr < r1; ++rr) {
@@ -190,14 +197,14 @@ __global__ void __launch_bounds__(256, grad_reduce_wg_per_cu(NT)) ionode_grad_re
         const int e = threadIdx.x + 256 * u;
         if (e < STE) stg[u] = *src_of(rr + 1, e);
       }
+      if (unit_seed && threadIdx.x < 16) sdg = *seed_src(rr + 1);
     }
-    f32x4 af[F > 0 ? F : 1], ar[R > 0 ? R : 1];
     f32x4 sd = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
     if (unit_seed) {
-      const float *sc = records + rr * RECF + (size_t)2 * (L + 1) * NT * 256 + 32;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) sd[c] = sc[4 * c + kk];   // this lane's component c is trajectory 4 c + kk
+      for (int c = 0; c < 4; ++c) sd[c] = seedbuf[cur * 16 + 4 * c + kk];   // this lane's component c is trajectory 4 c + kk
     }
+    f32x4 af[F > 0 ? F : 1], ar[R > 0 ? R : 1];
 #pragma unroll
     for (int i = 0; i < F; ++i) {
       af[i] = Db[(wave + 4 * i) * 64 + lane];
@@ -212,7 +219,7 @@ __global__ void __launch_bounds__(256, grad_reduce_wg_per_cu(NT)) ionode_grad_re
     }
 #pragma unroll
     for (int ct = 0; ct < CB; ++ct) {
-      if (NT % CB != 0 && cb0 + ct >= NT) break;   // (the short last block; wave-uniform)
+      if (NT % CB != 0 && ct == CB - 1 && cb0 + ct >= NT) break;   // (the short last block lacks its last tile; wave-uniform)
       const f32x4 b = Hb[ct * 64 + lane];
       // trajectory group c outer, row tile inner: consecutive MFMAs on different accumulators (issue 32 cycles, result 40)
 #pragma unroll
@@ -233,6 +240,7 @@ __global__ void __launch_bounds__(256, grad_reduce_wg_per_cu(NT)) ionode_grad_re
         const int e = threadIdx.x + 256 * u;
         if (e < STE) nb[e] = stg[u];
       }
+      if (unit_seed && threadIdx.x < 16) seedbuf[(cur ^ 1) * 16 + threadIdx.x] = sdg;
     }
     __syncthreads();
   }
@@ -244,7 +252,7 @@ __global__ void __launch_bounds__(256, grad_reduce_wg_per_cu(NT)) ionode_grad_re
     const int rt = wave + 4 * i;
 #pragma unroll
     for (int ct = 0; ct < CB; ++ct) {
-      if (NT % CB != 0 && cb0 + ct >= NT) break;
+      if (NT % CB != 0 && ct == CB - 1 && cb0 + ct >= NT) break;
 #pragma unroll
       for (int r = 0; r < 4; ++r) W[(size_t)(16 * rt + 4 * kk + r) * NP + 16 * (cb0 + ct) + m] = acc[i][ct][r];
     }
@@ -282,7 +290,7 @@ inline hipError_t launch_grad_reduce(int L, int NT, const float *records, int64_
                                      hipStream_t s, int unit_seed = 0) {
   const int CB = grad_reduce_cb(NT), NCB = grad_reduce_ncb(NT);
   const unsigned grid = (unsigned)(n_slabs * (L * NCB + 1));
-  const size_t lds = (size_t)2 * (NT + CB) * 64 * 16;
+  const size_t lds = (size_t)2 * (NT + CB) * 64 * 16 + 128;   // tile buffers + the staged seeds
   switch (NT) {
     case 1: hipLaunchKernelGGL(ionode_grad_reduce_kernel<1>, dim3(grid), dim3(256), lds, s, records, n_records, n_slabs, L, partials, unit_seed); break;
     case 7: hipLaunchKernelGGL(ionode_grad_reduce_kernel<7>, dim3(grid), dim3(256), lds, s, records, n_records, n_slabs, L, partials, unit_seed); break;

@@ -47,12 +47,22 @@ __global__ void __launch_bounds__(256, (NT <= 13 ? IONODE_REGRESS_WG_PER_CU : 1)
   mlp.init(g, smem, wave, lane);
   const int n_tiles = (a.M + 15) / 16;
   double acc = 0.0;
-  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  // a tile's inputs are fetched ONE TILE AHEAD (round 5): loaded at the top of their own tile, their wait -- vmcnt(0), which also covers the
+  // weight ring's refills in flight -- stood in front of the tile's first instruction: one exposed memory round trip per tile
+  struct In { float x0, x1, off, yt; };
+  auto fetch = [&](int tile) -> In {
     const int row = tile * 16 + j;
-    const bool valid = row < a.M;
-    const int r = valid ? row : a.M - 1;
-    const float x0 = a.x[2 * (size_t)r], x1 = a.x[2 * (size_t)r + 1];
-    const float off = a.offset ? a.offset[r] : 0.0f, yt = a.y[r];
+    const int r = row < a.M ? row : a.M - 1;
+    const f32x2 xx = *reinterpret_cast<const f32x2 *>(a.x + 2 * (size_t)r);
+    return In{xx[0], xx[1], a.offset ? a.offset[r] : 0.0f, a.y[r]};
+  };
+  In nxt = fetch((int)blockIdx.x < n_tiles ? (int)blockIdx.x : 0);
+  asm volatile("" : "+v"(nxt.x0), "+v"(nxt.x1), "+v"(nxt.off), "+v"(nxt.yt));   // (waited for here, not behind the loop header: see ionode_grad_reduce.hpp)
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const bool valid = tile * 16 + j < a.M;
+    const In cur = nxt;
+    if (tile + (int)gridDim.x < n_tiles) nxt = fetch(tile + (int)gridDim.x);
+    const float x0 = cur.x0, x1 = cur.x1, off = cur.off, yt = cur.yt;
     const float ns = a.netscale;
     float resid = 0.0f;
     mlp.vjp_from_output(x0, x1, a.records + (size_t)tile * a.record_floats, [&](float net) -> float {
