@@ -768,7 +768,7 @@ __global__ void __launch_bounds__(256) ionode_dopri5_backward_kernel(const GArgs
 constexpr int GRAD_RECOMPUTE_IB = 4;   // iterations per workgroup
 
 #ifndef IONODE_RECOMPUTE_WG_PER_CU
-#define IONODE_RECOMPUTE_WG_PER_CU 1   // 2: ask hipcc for a 256-register build of the N <= 200 kernels (two workgroups per compute unit; A/B)
+#define IONODE_RECOMPUTE_WG_PER_CU 2   // N <= 200: a 256-register build, two workgroups per compute unit (round 5; 1: the 332-register build, one per unit)
 #endif
 template <int MODEL, typename S, int NT>
 __global__ void __launch_bounds__(256, (NT <= 13 ? IONODE_RECOMPUTE_WG_PER_CU : 1)) ionode_grad_recompute_kernel(const GArgs a) {
@@ -786,9 +786,6 @@ __global__ void __launch_bounds__(256, (NT <= 13 ? IONODE_RECOMPUTE_WG_PER_CU : 
   GradMlp<NT> mlp;
   mlp.init(a, smem, wave, lane);
   double *__restrict__ Gs = mlp.gs();
-  double p[NPAR];
-#pragma unroll
-  for (int i = 0; i < NPAR; ++i) p[i] = a.k.params[(size_t)traj * a.k.n_params + i];
   const int pidx = a.k.prot_of_traj ? a.k.prot_of_traj[traj] : (traj % a.k.P);
   const double *__restrict__ pv = a.k.prot_v + (size_t)pidx * a.k.Np;
   const int nst = valid ? a.nacc[traj] : 0;
@@ -810,8 +807,10 @@ __global__ void __launch_bounds__(256, (NT <= 13 ? IONODE_RECOMPUTE_WG_PER_CU : 
 #pragma unroll
     for (int i = 0; i < 4 + 8 * D; ++i) crec[i] = rec[i];
   };
-  if (it_lo < it_hi) fetch_ckpt(it_lo);
+  constexpr bool CKPT_AHEAD = NT > 13 || IONODE_RECOMPUTE_WG_PER_CU < 2;   // (two workgroups per unit: the other one covers the round trip, and the 40 registers are not there)
+  if (CKPT_AHEAD && it_lo < it_hi) fetch_ckpt(it_lo);
   for (int it = it_lo; it < it_hi; ++it) {
+    if (!CKPT_AHEAD) fetch_ckpt(it);
     // ---- checkpoint of my step: as in ionode_dopri5_backward_kernel ----
     const int s = nst - 1 - it;
     const bool step = s >= 0;
@@ -829,7 +828,7 @@ __global__ void __launch_bounds__(256, (NT <= 13 ? IONODE_RECOMPUTE_WG_PER_CU : 
 #pragma unroll
         for (int d = 0; d < D; ++d) k[jx][d] = step ? crec[4 + D + jx * D + d] : 0.0;
     }
-    if (it + 1 < it_hi) fetch_ckpt(it + 1);
+    if (CKPT_AHEAD && it + 1 < it_hi) fetch_ckpt(it + 1);
     const double t1 = t0 + dt;
     const S t0s = (S)t0, dts_s = (S)dt, t1s = (S)t1;
     const double dts = (double)dts_s;
@@ -838,10 +837,10 @@ __global__ void __launch_bounds__(256, (NT <= 13 ? IONODE_RECOMPUTE_WG_PER_CU : 
 
     // ---- adjoints of the interpolant coefficients: G_c = sum_k gy[k] * x_k^c over the step's output samples (verbatim) ----
     // (the first 64 samples of the wavefront's four trajectories: all loads in flight before the first is used)
-    double tk0[4];
-    S gy0[4][D];
+    double tk0[4] = {0.0, 0.0, 0.0, 0.0};
+    S gy0[4][D] = {};
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < (CKPT_AHEAD ? 4 : 0); ++u) {   // (two workgroups per unit: not ahead -- the other workgroup covers the round trips)
       const int jj = wave + 4 * u;
       const int n = __builtin_amdgcn_readlane(nout, jj);
       const int o = __builtin_amdgcn_readlane(oi, jj);
@@ -870,13 +869,13 @@ __global__ void __launch_bounds__(256, (NT <= 13 ? IONODE_RECOMPUTE_WG_PER_CU : 
         for (int c0 = 0; c0 < n; c0 += 64) {
           if (c0 + lane < n) {
             const int idx = o + c0 + lane;
-            const double tk = (c0 == 0) ? tk0[u] : a.k.t_eval[idx];
+            const double tk = (CKPT_AHEAD && c0 == 0) ? tk0[u] : a.k.t_eval[idx];
             const double x = (double)(S)((tk - t0b) / (t1b - t0b));
             double xp = 1.0;
 #pragma unroll
             for (int c = 0; c < 5; ++c) {
 #pragma unroll
-              for (int d = 0; d < D; ++d) P[c][d] += (double)((c0 == 0) ? gy0[u][d] : gyb[(size_t)idx * D + d]) * xp;
+              for (int d = 0; d < D; ++d) P[c][d] += (double)((CKPT_AHEAD && c0 == 0) ? gy0[u][d] : gyb[(size_t)idx * D + d]) * xp;
               xp *= x;
             }
           }
@@ -903,49 +902,57 @@ __global__ void __launch_bounds__(256, (NT <= 13 ? IONODE_RECOMPUTE_WG_PER_CU : 
 #pragma unroll
         for (int d = 0; d < D; ++d) pk[4 + c * D + d] = Gs[j * (5 * D) + c * D + d];
     }
-    // stage voltages: pure functions of (t0, dt) -- the five distinct lookups are issued together, ahead of the stages (stage i = 5 shares i = 4's time)
-    double vs0, vs1, vs2, vs3, vs4;
+    // ---- the six stages' scalar work, AHEAD of their products (round 5): stage voltages (pure functions of (t0, dt): the five distinct
+    // lookups in flight together -- stage i = 5 shares i = 4's time), stage inputs Y_i, rate exponentials, the packet; what a product needs
+    // -- (x0, x1) per trajectory -- waits in LDS (the G_c scratch, read above by the very lanes that write here).  The product loop then
+    // carries none of the step's fp64 state (k[7][D], y, p, the checkpoint in flight): registers for the MFMA stream instead.
+    float *xs = reinterpret_cast<float *>(Gs);   // [6][16][2]
     {
+      double vst[5];
+      double p[NPAR];   // (loaded here, per iteration: 16 registers that need not live through the products)
+#pragma unroll
+      for (int i = 0; i < NPAR; ++i) p[i] = a.k.params[(size_t)traj * a.k.n_params + i];
       const double tq_init = (double)(S)a.k.t_eval[0];
-      auto look = [&](int i, double &v) {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
         const S ti = (i >= 4) ? R::prev_(t1s) : t0s + (S)kAlpha[i] * dts_s;
-        protocol_v(a.k, pv, step ? (double)ti : tq_init, v);
-      };
-      look(0, vs0); look(1, vs1); look(2, vs2); look(3, vs3); look(4, vs4);
-      // (opaque scalars: from an array hipcc turns the select chain below back into an indexed load -- of a scratch array)
-      asm volatile("" : "+v"(vs0), "+v"(vs1), "+v"(vs2), "+v"(vs3), "+v"(vs4));
+        protocol_v(a.k, pv, step ? (double)ti : tq_init, vst[i]);
+      }
+#pragma unroll
+      for (int e = 0; e < 6; ++e) {
+        const int i = 5 - e;
+        double Yi[D];
+        if (step) {
+#pragma unroll
+          for (int d = 0; d < D; ++d) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int jx = 0; jx <= i; ++jx) sacc += k[jx][d] * (kBeta[i][jx] * dts);
+            Yi[d] = y[d] + sacc;
+          }
+        } else {
+#pragma unroll
+          for (int d = 0; d < D; ++d) Yi[d] = y[d];
+        }
+        const double v = vst[i < 4 ? i : 4];
+        const float x0 = (float)(v / 100.0), x1 = (float)Yi[0];
+        const double e3 = det_exp(p[5] * v), e4 = det_exp(-p[7] * v);
+        double e1 = 0.0, e2 = 0.0;
+        if constexpr (NND) { e1 = det_exp(p[1] * v); e2 = det_exp(-p[3] * v); }
+        if (pk_writer) {
+          double *q8 = pk + 16 + 8 * e;
+          q8[0] = v; q8[1] = Yi[0]; q8[2] = Yi[1]; q8[3] = e3; q8[4] = e4; q8[5] = e1; q8[6] = e2;
+          xs[(e * 16 + j) * 2] = x0; xs[(e * 16 + j) * 2 + 1] = x1;
+        }
+      }
     }
+    __syncthreads();
 #pragma unroll 1
     for (int e = 0; e < 6; ++e) {
-      const int i = 5 - e;
-      double Yi[D];
-      if (step) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-          double sacc = 0.0;
-          for (int jx = 0; jx <= i; ++jx) sacc += k[jx][d] * (kBeta[i][jx] * dts);
-          Yi[d] = y[d] + sacc;
-        }
-      } else {
-#pragma unroll
-        for (int d = 0; d < D; ++d) Yi[d] = y[d];
-      }
-      double v = vs4;   // (e is wave-uniform: a chain of selects, no indexed register file)
-      if (i == 3) v = vs3;
-      if (i == 2) v = vs2;
-      if (i == 1) v = vs1;
-      if (i == 0) v = vs0;
-      const float x0 = (float)(v / 100.0), x1 = (float)Yi[0];
-      const double e3 = det_exp(p[5] * v), e4 = det_exp(-p[7] * v);
-      double e1 = 0.0, e2 = 0.0;
-      if constexpr (NND) { e1 = det_exp(p[1] * v); e2 = det_exp(-p[3] * v); }
-      if (pk_writer) {
-        double *q8 = pk + 16 + 8 * e;
-        q8[0] = v; q8[1] = Yi[0]; q8[2] = Yi[1]; q8[3] = e3; q8[4] = e4; q8[5] = e1; q8[6] = e2; q8[7] = 0.0;
-      }
+      const f32x2 xx = *reinterpret_cast<const f32x2 *>(xs + (e * 16 + j) * 2);
       // the WHOLE vector-Jacobian product with seed 1 (it is linear in the seed, a scalar per trajectory): record with unit-seed
       // D tiles, and c = d net / d x1 for the walk
-      const float c1 = mlp.template vjp<false>(x0, x1, 1.0f, a.records ? a.records + (tstep * 6 + e) * a.record_floats : nullptr);
+      const float c1 = mlp.template vjp<false>(xx[0], xx[1], 1.0f, a.records ? a.records + (tstep * 6 + e) * a.record_floats : nullptr);
       if (pk_writer) pk[16 + 8 * e + 7] = (double)c1;
     }
   }

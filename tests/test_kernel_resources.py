@@ -18,15 +18,37 @@ def test_no_kernel_uses_scratch():
     rows = kernel_resources(ion.capi.LIB_PATH)
     names = [r["kernel"] for r in rows]
     assert len(rows) >= 90 and any("ionode_grad_walk_kernel<3, double>" in n for n in names)
-    allowed = ()
+    # round 5: the N = 200 recompute kernels (phase A of the gradient sweep) are built for TWO workgroups per compute unit (256 registers):
+    # the weight ring's 172 registers stay live through an iteration's fp64 prologue, which parks up to 26 values (<= 128 bytes per lane) in
+    # scratch there -- once per ~140 us iteration, never inside a product (test_recompute_kernel_spills_stay_out_of_the_products)
+    allowed = {"ionode_grad_recompute_kernel<2, double, 13>": 128, "ionode_grad_recompute_kernel<2, float, 13>": 128,
+               "ionode_grad_recompute_kernel<3, double, 13>": 128, "ionode_grad_recompute_kernel<3, float, 13>": 128}
     bad = [(r["kernel"], r["scratch_bytes"], r["vgpr_spill"]) for r in rows
-           if r["scratch_bytes"] and not any(a in r["kernel"] for a in allowed)]   # (spills into free AGPRs cost no scratch)
+           if r["scratch_bytes"] > max([v for a, v in allowed.items() if a in r["kernel"]], default=0)]   # (spills into free AGPRs cost no scratch)
     assert not bad, bad
     # the hand-scheduled N = 200 kernels: the asm stream owns a[0:91]; the compiler's own spills must fit the other AGPRs
     for r in rows:
         tail = int(r["kernel"].split(",")[-1].split(">")[0]) if "ionode_dopri5_kernel<" in r["kernel"] else 0
         if "ionode_dopri5_kernel<" in r["kernel"] and ", 4, 4, 13, 13, " in r["kernel"] and not (tail & 16):   # (TAIL & 16: the 4-trajectory tile, no asm stream)
             assert r["vgpr"] <= 512 and 92 <= r["agpr"] <= 256 and r["scratch_bytes"] == 0, r   # vgpr = unified VGPR + AGPR count
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc")
+def test_recompute_kernel_spills_stay_out_of_the_products():
+    """The 256-register recompute kernels may spill in an iteration's prologue (checkpoint, output gradients, stage inputs) -- every
+    scratch instruction must sit in front of the kernel's first MFMA, i.e. outside the six vector-Jacobian products of an iteration."""
+    import re
+    import asm_stats
+    asm = asm_stats.compile_asm("ionode_grad_capi")
+    n = 0
+    for sym, body in re.findall(r"^(_ZN6ionode28ionode_grad_recompute_kernel\w+):[^\n]*\n(.*?)\n\s+s_endpgm", asm, re.S | re.M):
+        lines = body.split("\n")
+        mf = [i for i, l in enumerate(lines) if "v_mfma" in l]
+        sc = [i for i, l in enumerate(lines) if re.match(r"\s+scratch_", l)]
+        assert mf, sym
+        assert not sc or max(sc) < mf[0], (sym, [i for i in sc if i >= mf[0]][:5], mf[0])
+        n += 1
+    assert n == 12, n   # {NN-f, NN-d} x {fp32, fp64} x {N <= 16, 100, 200}
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf") or shutil.which("c++filt") is None, reason="llvm tools")

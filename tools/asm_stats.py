@@ -164,7 +164,7 @@ def dpp_hazards(asm_text, wait_states=2):
     [(kernel symbol, dpp instruction, offending instruction)] for DPP sources written by a VALU instruction fewer than wait_states + 1
     instructions earlier (s_nop N counts N + 1; branches / labels end the window conservatively: a hazard across them is not assumed)."""
     bad = []
-    for sym, body in re.findall(r"^(_Z\w+):\n(.*?)\n\s+s_endpgm", asm_text, re.S | re.M):
+    for sym, body in re.findall(r"^(_Z\w+):[^\n]*\n(.*?)\n\s+s_endpgm", asm_text, re.S | re.M):
         window = []   # (distance already accumulated is implicit: list of (n_wait_states, written vgprs)) for the last instructions
         for raw in body.split("\n"):
             ins = raw.split(";")[0].strip()
