@@ -8,9 +8,11 @@
 // A record is one MLP vector-Jacobian product of one 16-trajectory tile (ionode_grad.hpp); its tiles are stored in the
 // operand layout of v_mfma_f32_16x16x4_f32 with the TRAJECTORY as contraction index: lane = 16*kk + m holds
 // X[16*rt + m][4*c + kk] in component c, so a 1 KiB tile is both an A operand (rows of d) and a B operand (rows of h) of four
-// MFMAs (c = 0..3) with one coalesced 16-byte load per lane.  Workgroup = (job, slab of records): the heavy jobs keep a whole
-// NP x NP accumulator (43 tiles per wavefront for N = 200) in registers, stage each record's 2 x NT tiles through LDS once
-// (double-buffered) and write one partial per slab; the host sums the slabs in fp64 (deterministic, no atomics).
+// MFMAs (c = 0..3) with one coalesced 16-byte load per lane.  Workgroup = (job, slab of records): a heavy job keeps a layer's
+// NP x (column block) accumulator in registers (N = 200, round 5: two blocks of 7 and 6 column tiles, 24 tiles per wavefront, three
+// workgroups per compute unit; N <= 112 the whole NP x NP; N = 500 four blocks), stages each record's NT + CB tiles through LDS once
+// (double-buffered) and writes one partial per slab; the host sums the slabs in fp64 (deterministic, no atomics).  The two light
+// jobs of a slab share one workgroup (four records in flight).  grad_reduce_slabs(): the slab count that makes one round of workgroups.
 // Roofline: 2 * NP^2 * 16 FLOP per 2 * NT KiB of record -> 53 FLOP/B for N = 200: HBM- and MFMA-balanced at ~3 TB/s.
 #pragma once
 
