@@ -43,7 +43,14 @@ rocprofv3 --pmc GRBM_GUI_ACTIVE FETCH_SIZE --output-format csv -d $O/reg2 -- pyt
 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/reg3 -- python3 tools/bench_regression.py --iters 2 > /dev/null 2> $O/reg3.err || exit 1
 [ -d $O/trace_reg ] && find $O/trace_reg -name "*kernel_stats.csv" -exec cp {} $O/${R}_kernel_stats_regression.csv \;
 fi
-for p in reg1 reg2 reg3 pmc1 pmc2 pmc3 pmc4 cf1a cf1b cf1c cf2a cf2b cf2c cf3a cf3b cf3c cf4a cf4b cf4c cf5a cf5b cf5c cf6a cf6b cf6c cf7a cf7b cf7c cf8a cf8b cf8c; do [ -d $O/$p ] && python3 tools/pmc_summary.py $O/$p > $O/$p.json; done
+if [[ $PART == *4* ]]; then
+# round 5: the gradient share's kernels (forward with checkpoints, recompute, walk, reduce): per-kernel time, MFMA / VALU counters
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_grad -- python3 tools/bench_grad.py --reps 1 > $O/${R}_gradient.json 2> $O/trace_grad.err || exit 1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_LDS --output-format csv -d $O/grad1 -- python3 tools/bench_grad.py --reps 1 > /dev/null 2> $O/grad1.err || exit 1
+rocprofv3 --pmc GRBM_GUI_ACTIVE FETCH_SIZE --output-format csv -d $O/grad2 -- python3 tools/bench_grad.py --reps 1 > /dev/null 2> $O/grad2.err || exit 1
+[ -d $O/trace_grad ] && find $O/trace_grad -name "*kernel_stats.csv" -exec cp {} $O/${R}_kernel_stats_gradient.csv \;
+fi
+for p in grad1 grad2 reg1 reg2 reg3 pmc1 pmc2 pmc3 pmc4 cf1a cf1b cf1c cf2a cf2b cf2c cf3a cf3b cf3c cf4a cf4b cf4c cf5a cf5b cf5c cf6a cf6b cf6c cf7a cf7b cf7c cf8a cf8b cf8c; do [ -d $O/$p ] && python3 tools/pmc_summary.py $O/$p > $O/$p.json; done
 [ -d $O/trace ] && find $O/trace -name "*kernel_stats.csv" -exec cp {} $O/${R}_kernel_stats.csv \;
 [ -d $O/trace_legs ] && find $O/trace_legs -name "*kernel_stats.csv" -exec cp {} $O/${R}_kernel_stats_legs.csv \;
 # keep the merge small: drop the raw per-dispatch traces
