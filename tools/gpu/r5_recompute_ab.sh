@@ -1,6 +1,8 @@
 #!/bin/bash
 # round 5: the recompute kernel (phase A of the two-phase sweep) at one and two workgroups per compute unit, after the stage inputs moved
-# ahead of the product loop (variants/recompute2: -DIONODE_RECOMPUTE_WG_PER_CU=2); gradient tests on the in-tree build first
+# ahead of the product loop.  As run: in-tree = the build of its commit (first run: one per unit; second run: the shipped two-per-unit build
+# without the prefetches), variants/recompute2 = tools/ab_one_unit.sh recompute2 ionode_grad_capi.o "-DIONODE_RECOMPUTE_WG_PER_CU=2" of the
+# commit before (two per unit WITH the checkpoint / output-gradient prefetches); gradient tests on the in-tree build first
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 timeout -k 10 600 python3 -m pytest tests/test_gpu_grad.py tests/test_gpu_grad_fuzz.py -x -q -m gpu > gpurun_out/r5_recompute_tests.log 2>&1; rc=$?
